@@ -1,0 +1,321 @@
+"""ctypes front-end of the CPU oracle (oracle/tsdf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from tracking_sdf_amd/.  PARITY UNPINNED vs
+the real reference binary (see tsdf_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtsdf_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (no GPU needed)."""
+    src = os.path.join(_HERE, "tsdf_oracle.c")
+    hdr = os.path.join(_HERE, "tsdf_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        if not os.path.exists(src):
+            raise RuntimeError("oracle sources missing and no prebuilt libtsdf_oracle.so")
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class _Sdf(C.Structure):
+    _fields_ = [("m", C.c_int32), ("width", C.c_float), ("height", C.c_float), ("depth", C.c_float),
+                ("distance_delta", C.c_float), ("distance_epsilon", C.c_float),
+                ("sdf_origin", C.c_double * 3),
+                ("m_div_width", C.c_float), ("m_div_height", C.c_float), ("m_div_depth", C.c_float),
+                ("m_squared", C.c_int32), ("number_of_voxels", C.c_int64),
+                ("D", C.POINTER(C.c_float)), ("W", C.POINTER(C.c_float)),
+                ("Color_W", C.POINTER(C.c_float)), ("R", C.POINTER(C.c_float)),
+                ("G", C.POINTER(C.c_float)), ("B", C.POINTER(C.c_float)),
+                ("global_coords", C.POINTER(C.c_double))]
+
+
+class _Tracker(C.Structure):
+    _fields_ = [("rot", C.c_double * 9), ("trans", C.c_double * 3),
+                ("rot_inv", C.c_double * 9), ("rot_inv_trans", C.c_double * 3),
+                ("K", C.c_double * 9), ("isKFilled", C.c_int32),
+                ("gauss_newton_max_iteration", C.c_int32), ("maximum_twist_diff", C.c_float),
+                ("v_h", C.c_float), ("w_h", C.c_float), ("v_h2", C.c_float), ("w_h2", C.c_float),
+                ("v_h2_width", C.c_float), ("v_h2_height", C.c_float), ("v_h2_depth", C.c_float)]
+
+
+class AccumStats(C.Structure):
+    _fields_ = [("n_samples", C.c_int64), ("n_nan", C.c_int64), ("n_oog", C.c_int64),
+                ("n_fail", C.c_int64), ("n_ok", C.c_int64), ("n_terms", C.c_int64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class TrackStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("stopped", C.c_int32), ("nonfinite", C.c_int32),
+                ("n_terms_last", C.c_int64), ("last_twist", C.c_double * 6)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    fp = C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int32)
+    L.orc_sdf_create.restype = C.POINTER(_Sdf)
+    L.orc_sdf_create.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, dp, C.c_float, C.c_float, C.c_int32]
+    L.orc_sdf_destroy.argtypes = [C.POINTER(_Sdf)]
+    L.orc_get_array_index.restype = C.c_int64
+    L.orc_get_array_index.argtypes = [C.POINTER(_Sdf), ip]
+    L.orc_get_voxel_coordinates_idx.argtypes = [C.POINTER(_Sdf), C.c_int64, ip]
+    L.orc_get_voxel_coordinates.argtypes = [C.POINTER(_Sdf), dp, dp]
+    L.orc_get_global_coordinates.argtypes = [C.POINTER(_Sdf), ip, dp]
+    L.orc_interpolate_distance.restype = C.c_float
+    L.orc_interpolate_distance.argtypes = [C.POINTER(_Sdf), dp, ip]
+    L.orc_create_circle.argtypes = [C.POINTER(_Sdf), C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orc_tracker_create.restype = C.POINTER(_Tracker)
+    L.orc_tracker_create.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.POINTER(_Sdf)]
+    L.orc_tracker_destroy.argtypes = [C.POINTER(_Tracker)]
+    L.orc_tracker_set_K.argtypes = [C.POINTER(_Tracker), dp]
+    L.orc_set_camera_transformation.argtypes = [C.POINTER(_Tracker), dp, dp]
+    L.orc_cloud_create.restype = C.c_void_p
+    L.orc_cloud_create.argtypes = [C.c_int32, C.c_int32, fp, fp, C.POINTER(C.c_uint8)]
+    L.orc_cloud_destroy.argtypes = [C.c_void_p]
+    L.orc_update.restype = C.c_int64
+    L.orc_update.argtypes = [C.POINTER(_Sdf), C.POINTER(_Tracker), C.c_void_p, C.c_int32, C.c_int32]
+    L.orc_get_partial_derivative.restype = C.c_int32
+    L.orc_get_partial_derivative.argtypes = [C.POINTER(_Tracker), C.POINTER(_Sdf), dp, dp, dp, ip, dp]
+    L.orc_perturbed_rotations.argtypes = [C.POINTER(_Tracker), dp]
+    L.orc_accumulate.argtypes = [C.POINTER(_Tracker), C.POINTER(_Sdf), C.c_void_p, C.c_int32, C.c_int32,
+                                 C.c_double, C.c_double, dp, dp, C.POINTER(AccumStats)]
+    L.orc_gn_update.restype = C.c_int32
+    L.orc_gn_update.argtypes = [C.POINTER(_Tracker), dp, dp, dp]
+    L.orc_estimate_new_position.argtypes = [C.POINTER(_Tracker), C.POINTER(_Sdf), C.c_void_p, C.c_int32,
+                                            C.c_int32, C.POINTER(TrackStats)]
+    L.orc_direct_exponential_map.argtypes = [dp, C.c_double, dp]
+    L.orc_inverse3.argtypes = [dp, dp]
+    L.orc_inverse6.restype = C.c_int32
+    L.orc_inverse6.argtypes = [dp, dp]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _d(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} doubles, got {a.size}")
+    return a
+
+
+class Cloud:
+    """Organised cloud + normals in the reference's PCL layout (32-byte AoS)."""
+
+    def __init__(self, xyz, nrm=None, rgb=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        assert xyz.ndim == 3 and xyz.shape[2] == 3, "xyz must be (h, w, 3)"
+        self.height, self.width = xyz.shape[:2]
+        nptr = None
+        if nrm is not None:
+            nrm = np.ascontiguousarray(nrm, dtype=np.float32)
+            assert nrm.shape == xyz.shape
+            nptr = nrm.ctypes.data_as(C.POINTER(C.c_float))
+        cptr = None
+        if rgb is not None:
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            assert rgb.shape == xyz.shape
+            cptr = rgb.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._p = lib().orc_cloud_create(self.width, self.height,
+                                         xyz.ctypes.data_as(C.POINTER(C.c_float)), nptr, cptr)
+        if not self._p:
+            raise MemoryError("orc_cloud_create failed")
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().orc_cloud_destroy(self._p)
+            self._p = None
+
+
+class SDF:
+    """Mirror of the reference's class SDF (sdf.h:35-186)."""
+
+    def __init__(self, m=256, width=6.0, height=6.0, depth=3.5, origin=(-3.0, -3.0, -0.5),
+                 delta=0.3, epsilon=0.025, with_global_coords=False):
+        o = _d(origin, 3)
+        self._p = lib().orc_sdf_create(m, width, height, depth, _dp(o), delta, epsilon,
+                                       1 if with_global_coords else 0)
+        if not self._p:
+            raise MemoryError("orc_sdf_create failed")
+        self.m = m
+        n = m * m * m
+        s = self._p.contents
+        self.D = np.ctypeslib.as_array(s.D, shape=(n,))
+        self.W = np.ctypeslib.as_array(s.W, shape=(n,))
+        self.Color_W = np.ctypeslib.as_array(s.Color_W, shape=(n,))
+        self.R = np.ctypeslib.as_array(s.R, shape=(n,))
+        self.G = np.ctypeslib.as_array(s.G, shape=(n,))
+        self.B = np.ctypeslib.as_array(s.B, shape=(n,))
+
+    @property
+    def c(self):
+        return self._p.contents
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            for k in ("D", "W", "Color_W", "R", "G", "B"):
+                self.__dict__.pop(k, None)
+            lib().orc_sdf_destroy(self._p)
+            self._p = None
+
+    def get_array_index(self, vox):
+        v = np.asarray(vox, dtype=np.int32)
+        return int(lib().orc_get_array_index(self._p, v.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def get_voxel_coordinates_idx(self, idx):
+        v = np.zeros(3, dtype=np.int32)
+        lib().orc_get_voxel_coordinates_idx(self._p, int(idx), v.ctypes.data_as(C.POINTER(C.c_int32)))
+        return v
+
+    def get_voxel_coordinates(self, world):
+        g = _d(world, 3)
+        v = np.zeros(3)
+        lib().orc_get_voxel_coordinates(self._p, _dp(g), _dp(v))
+        return v
+
+    def get_global_coordinates(self, vox):
+        v = np.asarray(vox, dtype=np.int32)
+        g = np.zeros(3)
+        lib().orc_get_global_coordinates(self._p, v.ctypes.data_as(C.POINTER(C.c_int32)), _dp(g))
+        return g
+
+    def interpolate_distance(self, vox):
+        v = _d(vox, 3)
+        ok = C.c_int32(0)
+        val = lib().orc_interpolate_distance(self._p, _dp(v), C.byref(ok))
+        return float(val), bool(ok.value)
+
+    def create_circle(self, radius, cx, cy, cz):
+        lib().orc_create_circle(self._p, radius, cx, cy, cz)
+
+    def update(self, tracker, cloud, with_color=True, threads=0):
+        return int(lib().orc_update(self._p, tracker._p, cloud._p, 1 if with_color else 0, threads))
+
+
+class CameraTracking:
+    """Mirror of the reference's class CameraTracking (camera_tracking.h:12-105)."""
+
+    def __init__(self, sdf, gn_max_iter=20, max_twist_diff=0.001, v_h=1.0, w_h=0.01):
+        self._p = lib().orc_tracker_create(gn_max_iter, max_twist_diff, v_h, w_h, sdf._p)
+        if not self._p:
+            raise MemoryError("orc_tracker_create failed")
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().orc_tracker_destroy(self._p)
+            self._p = None
+
+    @property
+    def c(self):
+        return self._p.contents
+
+    @property
+    def rot(self):
+        return np.array(self.c.rot).reshape(3, 3)
+
+    @property
+    def trans(self):
+        return np.array(self.c.trans)
+
+    @property
+    def rot_inv(self):
+        return np.array(self.c.rot_inv).reshape(3, 3)
+
+    @property
+    def rot_inv_trans(self):
+        return np.array(self.c.rot_inv_trans)
+
+    def set_K(self, K):
+        k = _d(K, 9)
+        lib().orc_tracker_set_K(self._p, _dp(k))
+
+    def set_camera_transformation(self, rot, trans):
+        r, t = _d(rot, 9), _d(trans, 3)
+        lib().orc_set_camera_transformation(self._p, _dp(r), _dp(t))
+
+    def perturbed_rotations(self):
+        out = np.zeros(54)
+        lib().orc_perturbed_rotations(self._p, _dp(out))
+        return out.reshape(6, 3, 3)
+
+    def get_partial_derivative(self, sdf, camera_point, J=None, is_interpolated=False, sdf_val=0.0):
+        """Returns (in_grid, J, is_interpolated, sdf_val); J/flag/val are in-out like the reference's."""
+        rpm = np.zeros(54)
+        lib().orc_perturbed_rotations(self._p, _dp(rpm))
+        p = _d(camera_point, 3)
+        Jb = np.zeros(6) if J is None else _d(J, 6).copy()
+        ok = C.c_int32(1 if is_interpolated else 0)
+        val = C.c_double(sdf_val)
+        ing = lib().orc_get_partial_derivative(self._p, sdf._p, _dp(rpm), _dp(p), _dp(Jb),
+                                               C.byref(ok), C.byref(val))
+        return bool(ing), Jb, bool(ok.value), float(val.value)
+
+    def accumulate(self, sdf, cloud, threads=1, stale_carry=True, own_x0=None, own_x1=None):
+        A = np.zeros(36)
+        b = np.zeros(6)
+        st = AccumStats()
+        x0 = 0.0 if own_x0 is None else float(own_x0)
+        x1 = float(sdf.m) if own_x1 is None else float(own_x1)
+        lib().orc_accumulate(self._p, sdf._p, cloud._p, threads, 1 if stale_carry else 0,
+                             x0, x1, _dp(A), _dp(b), C.byref(st))
+        return A.reshape(6, 6), b, st.as_dict()
+
+    def gn_update(self, A, b):
+        a, bb = _d(A, 36), _d(b, 6)
+        tw = np.zeros(6)
+        stop = lib().orc_gn_update(self._p, _dp(a), _dp(bb), _dp(tw))
+        return bool(stop), tw
+
+    def estimate_new_position(self, sdf, cloud, threads=1, stale_carry=True):
+        st = TrackStats()
+        lib().orc_estimate_new_position(self._p, sdf._p, cloud._p, threads,
+                                        1 if stale_carry else 0, C.byref(st))
+        return {"iterations": int(st.iterations), "stopped": bool(st.stopped),
+                "nonfinite": bool(st.nonfinite), "n_terms_last": int(st.n_terms_last),
+                "last_twist": np.array(st.last_twist)}
+
+
+def direct_exponential_map(v, delta_t=1.0):
+    vv = _d(v, 6)
+    out = np.zeros(12)
+    lib().orc_direct_exponential_map(_dp(vv), float(delta_t), _dp(out))
+    return out.reshape(3, 4)
+
+
+def inverse3(m):
+    a = _d(m, 9)
+    out = np.zeros(9)
+    lib().orc_inverse3(_dp(a), _dp(out))
+    return out.reshape(3, 3)
+
+
+def inverse6(A):
+    a = _d(A, 36)
+    out = np.zeros(36)
+    ok = lib().orc_inverse6(_dp(a), _dp(out))
+    return out.reshape(6, 6), bool(ok)
