@@ -1,0 +1,35 @@
+# Builds the MI355X-native hot path (libtsdf_hip.so, gfx950 only) and the CPU oracle.
+# hipcc cross-compiles for gfx950 without a GPU present.
+ROOT    := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := $(ROOT)tracking_sdf_amd/csrc
+LIBDIR  := $(ROOT)tracking_sdf_amd/lib
+LIB     := $(LIBDIR)/libtsdf_hip.so
+
+# -ffp-contract=off and no fast-math are REQUIRED for parity: every multiply-add of the reference is
+# two roundings (its g++ build sets no -O/-march flags, src/CMakeLists.txt:97-98).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wextra -Wno-unused-parameter
+SRCS := $(CSRC)/tsdf_kernels.hip $(CSRC)/tsdf_api.cpp $(CSRC)/rccl_dyn.cpp
+HDRS := $(CSRC)/tsdf_device.h $(CSRC)/host_math.hpp $(CSRC)/rccl_dyn.hpp $(ROOT)include/tsdf.h
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS) -ldl
+
+oracle:
+	$(MAKE) -C $(ROOT)oracle
+
+# kernel resource usage + ISA for inspection
+asm:
+	@mkdir -p $(ROOT)build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $(CSRC)/tsdf_kernels.hip --cuda-device-only -S -o $(ROOT)build/tsdf_kernels.s \
+	    -Rpass-analysis=kernel-resource-usage 2> $(ROOT)build/resource_usage.txt || true
+
+clean:
+	rm -f $(LIB)
+	$(MAKE) -C $(ROOT)oracle clean
+.PHONY: all oracle asm clean

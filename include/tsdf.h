@@ -1,0 +1,202 @@
+/*
+ * tsdf.h -- C ABI of the MI355X-native tracking_sdf hot path (libtsdf_hip.so).
+ *
+ * One handle = one voxel volume (or one x-slab of it) resident in the HBM of one
+ * GPU + the camera pose / intrinsics the reference keeps in CameraTracking.
+ * It replaces, for the per-frame hot path only, these reference interfaces
+ * (paths relative to the reference's src/):
+ *
+ *   tsdf_create / tsdf_destroy        SDF::SDF                     include/sdf_3d_reconstruction/sdf.h:78-79, src/sdf.cpp:8-51
+ *                                     CameraTracking::CameraTracking  camera_tracking.h:63, src/camera_tracking.cpp:3-18
+ *   tsdf_set_intrinsics               CameraTracking::camera_info_cb  src/camera_tracking.cpp:22-36
+ *   tsdf_set_camera_transformation    CameraTracking::set_camera_transformation  camera_tracking.h:84, src/camera_tracking.cpp:59-65
+ *   tsdf_get_pose                     public fields rot, trans, rot_inv, rot_inv_trans  camera_tracking.h:43-49
+ *   tsdf_set_frame / _device          the borrowed cloud_filtered + normals arguments of the two hot calls
+ *   tsdf_integrate                    SDF::update                  sdf.h:161-163, src/sdf.cpp:224-315
+ *   tsdf_track                        CameraTracking::estimate_new_position  camera_tracking.h:101, src/camera_tracking.cpp:66-245
+ *   tsdf_accumulate                   one Gauss-Newton pass, src/camera_tracking.cpp:81-189 (+ get_partial_derivative :246-363)
+ *   tsdf_gn_update                    src/camera_tracking.cpp:191-239 (+ eigen_utils::direct_exponential_map, src/eigen_utils.cpp:85-128)
+ *   tsdf_sample                       SDF::interpolate_distance    sdf.h:86, src/sdf.cpp:127-163
+ *   tsdf_download / tsdf_upload       the raw D / W (/Color_W,R,G,B) arrays the visualiser reads  sdf.h:41-55, src/sdf.cpp:47-49
+ *
+ * Conventions
+ *   - every call returns int: TSDF_OK (0) or a negative tsdf_status; nothing
+ *     throws or aborts across the ABI; tsdf_last_error() gives a message.
+ *   - matrices are row-major double[9]; vectors double[3].
+ *   - images are organised, row-major, pixel (col,row) at [row*width + col]
+ *     (PCL's at(col,row)); xyz / nrm are float[h*w*3], rgb is uint8[h*w*3];
+ *     NaN marks invalid depth / undefined normal, exactly as in the reference.
+ *   - volume arrays use the reference's linear index  idx = m*m*i + m*j + k
+ *     (i = x slowest, k = z fastest; sdf.h:120).
+ *   - a handle is single-caller (the reference has one ROS spinner thread).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with TSDF_E_NO_DEVICE / TSDF_E_HIP.
+ */
+#ifndef TSDF_H_
+#define TSDF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSDF_ABI_VERSION 1
+
+typedef enum tsdf_status {
+    TSDF_OK = 0,
+    TSDF_E_BADARG = -1,        /* null pointer, bad size, bad slab ...                                 */
+    TSDF_E_NO_DEVICE = -2,     /* no HIP device / device ordinal out of range                           */
+    TSDF_E_HIP = -3,           /* a HIP runtime call failed (message in tsdf_last_error)                */
+    TSDF_E_NO_INTRINSICS = -4, /* tsdf_integrate before tsdf_set_intrinsics (reference: exit(0), sdf.cpp:227-230) */
+    TSDF_E_NO_FRAME = -5,      /* hot call before tsdf_set_frame / tsdf_set_frame_device                */
+    TSDF_E_SINGULAR = -6,      /* normal matrix singular / pose not finite (reference: silent NaN pose, camera_tracking.cpp:191); pose left unchanged */
+    TSDF_E_NO_SAMPLES = -7,    /* no valid tracking sample in the frame; pose left unchanged            */
+    TSDF_E_HALO = -8,          /* a tracking look-up left this rank's slab+halo: halo too small         */
+    TSDF_E_COMM = -9,          /* RCCL / all-reduce hook failure                                        */
+    TSDF_E_NOMEM = -10
+} tsdf_status;
+
+/* All the constants the reference hard-codes. */
+typedef struct tsdf_config {
+    int32_t m;                  /* voxels per axis                       sdf_reconstruction.cpp:85 (256) */
+    float   width, height, depth; /* extent in metres along x, y, z      (6.0, 6.0, 3.5)                 */
+    double  origin[3];          /* world position of the volume corner   (-3,-3,-0.5)                    */
+    float   delta;              /* truncation distance                   (0.3)                           */
+    float   epsilon;            /* weight plateau                        (0.025)                         */
+    int32_t gn_max_iter;        /* Gauss-Newton iterations               sdf_reconstruction.cpp:88 (20)  */
+    float   max_twist_diff;     /* signed stop threshold                 (0.001)                         */
+    float   v_h;                /* translation step, voxels              (1.0)                           */
+    float   w_h;                /* rotation step, radians                (0.01)                          */
+    int32_t pixel_stride;       /* tracker sampling stride               camera_tracking.cpp:162-163 (3) */
+    int32_t stale_carry;        /* 1 = reproduce the carry-over of camera_tracking.cpp:156-159,261-268   */
+    int32_t with_color;         /* 1 = also keep Color_W,R,G,B           sdf.cpp:294-304                 */
+    /* placement: which part of the volume this handle owns, and where it lives */
+    int32_t slab_x0, slab_x1;   /* owned x range [x0,x1); 0,m (or 0,0) = whole volume                    */
+    int32_t halo;               /* extra x layers kept (and integrated) on each side of the slab         */
+    int32_t device;             /* HIP device ordinal                                                    */
+} tsdf_config;
+
+typedef struct tsdf_handle tsdf_handle;
+
+typedef struct tsdf_integrate_stats {
+    int64_t n_updated;          /* voxels whose D/W were rewritten, owned slab only (halo excluded)      */
+    int64_t n_updated_halo;     /* same, halo layers (redundant work, multi-GPU only)                    */
+    int64_t n_voxels;           /* voxels swept (slab + halo)                                            */
+} tsdf_integrate_stats;
+
+typedef struct tsdf_accum_stats {
+    int64_t n_samples;          /* sampled pixels                                                        */
+    int64_t n_nan;              /* NaN xyz                                                               */
+    int64_t n_oog;              /* centre voxel outside the grid                                         */
+    int64_t n_in_grid_owned;    /* in grid and owned by this rank (these do the 13 look-ups)             */
+    int64_t n_ok;               /* owned, all 13 look-ups valid                                          */
+    int64_t n_terms;            /* owned JJ^T/Jr terms added, stale re-adds included                     */
+} tsdf_accum_stats;
+
+typedef struct tsdf_track_stats {
+    int32_t iterations;         /* Gauss-Newton iterations run                                           */
+    int32_t stopped;            /* 1 = signed stop rule fired (camera_tracking.cpp:216-224)              */
+    int64_t n_terms_last;       /* global term count of the last iteration                               */
+    double  last_twist[6];
+} tsdf_track_stats;
+
+/* Host-provided sum all-reduce over ranks of `n` doubles, in place.  Return 0 on success. */
+typedef int (*tsdf_allreduce_fn)(double *buf, int32_t n, void *ctx);
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+int  tsdf_abi_version(void);
+void tsdf_default_config(tsdf_config *cfg);                       /* the reference's hard-coded values */
+int  tsdf_create(const tsdf_config *cfg, tsdf_handle **out);
+void tsdf_destroy(tsdf_handle *h);
+const char *tsdf_last_error(const tsdf_handle *h);               /* h may be NULL: last create() error */
+const char *tsdf_strerror(int status);
+int  tsdf_get_config(const tsdf_handle *h, tsdf_config *cfg);
+
+/* ---- camera state ------------------------------------------------------------------------ */
+int tsdf_set_intrinsics(tsdf_handle *h, const double K[9]);
+int tsdf_set_camera_transformation(tsdf_handle *h, const double rot[9], const double trans[3]);
+int tsdf_get_pose(const tsdf_handle *h, double rot[9], double trans[3],
+                  double rot_inv[9], double rot_inv_trans[3]);    /* any pointer may be NULL */
+
+/* ---- per-frame input ------------------------------------------------------------------------
+ * tsdf_set_frame copies host images to the device (pinned staging, async).  nrm / rgb may be NULL
+ * (tracking needs xyz only; integration needs nrm; rgb is needed only when with_color = 1).
+ * tsdf_set_frame_device borrows DEVICE pointers (same layouts) that must stay valid until the next
+ * set_frame* call or destroy. */
+int tsdf_set_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uint8_t *rgb,
+                   int32_t width, int32_t height);
+int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb,
+                          int32_t width, int32_t height);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+int tsdf_integrate(tsdf_handle *h, tsdf_integrate_stats *stats);  /* SDF::update at the current pose */
+int tsdf_track(tsdf_handle *h, tsdf_track_stats *stats);          /* estimate_new_position: updates the pose */
+/* One accumulation pass at the current pose.  A (6x6 row-major) and b are this rank's partial sums
+ * (NOT all-reduced), so a test can add the partials of several slabs itself. */
+int tsdf_accumulate(tsdf_handle *h, double A[36], double b[6], tsdf_accum_stats *stats);
+/* Solve + exponential map + stop rule + pose update for given (already reduced) A, b.  Host only.
+ * *stop receives the stop-rule result.  On TSDF_E_SINGULAR the pose is left unchanged. */
+int tsdf_gn_update(tsdf_handle *h, const double A[36], const double b[6], double twist[6], int32_t *stop);
+/* Batched SDF::interpolate_distance on the device: vox = n x 3 continuous voxel coordinates (host). */
+int tsdf_sample(tsdf_handle *h, const double *vox, int32_t n, float *val, int32_t *ok);
+
+/* ---- volume I/O (host mirrors for meshing / checkpoints), reference index order, owned slab only:
+ *      arrays hold (slab_x1-slab_x0)*m*m floats starting at voxel (slab_x0,0,0). */
+int tsdf_download(tsdf_handle *h, float *D, float *W);
+int tsdf_upload(tsdf_handle *h, const float *D, const float *W);
+int tsdf_download_color(tsdf_handle *h, float *Color_W, float *R, float *G, float *B);
+int tsdf_upload_color(tsdf_handle *h, const float *Color_W, const float *R, const float *G, const float *B);
+/* Re-integrate nothing, just make halo layers consistent after tsdf_upload on a sharded volume:
+ * uploads D/W for the halo layers too (arrays cover [max(0,x0-halo), min(m,x1+halo)) ). */
+int tsdf_upload_with_halo(tsdf_handle *h, const float *D, const float *W);
+int tsdf_reset(tsdf_handle *h);                                   /* back to the constructor state */
+
+/* ---- multi-GPU (one process per GPU; the volume is sharded in x-slabs) ------------------- */
+/* Owned range of `rank` out of `nranks` for an m-voxel axis (balanced contiguous slabs). */
+int tsdf_slab_range(int32_t m, int32_t nranks, int32_t rank, int32_t *x0, int32_t *x1);
+/* Halo (x layers per side) that covers every tracking look-up of points up to max_range metres
+ * from the world origin: ceil(w_h * max_range * m/width) + ceil(v_h) + 2. */
+int32_t tsdf_halo_for(const tsdf_config *cfg, float max_range);
+/* RCCL path: rank 0 calls tsdf_comm_unique_id, the 128 bytes are broadcast by the host
+ * (torch.distributed / MPI / a file), every rank calls tsdf_comm_init. */
+int tsdf_comm_unique_id(void *id128);
+int tsdf_comm_init(tsdf_handle *h, int32_t nranks, int32_t rank, const void *id128);
+/* Alternative: let the host do the 28-double sum (e.g. torch.distributed); fn = NULL removes it. */
+int tsdf_set_allreduce_hook(tsdf_handle *h, tsdf_allreduce_fn fn, void *ctx);
+/* Sum-all-reduce n doubles through whichever of the two is configured (identity if neither). */
+int tsdf_allreduce(tsdf_handle *h, double *buf, int32_t n);
+
+/* ---- measurement helpers ------------------------------------------------------------------ */
+/* GPU time measured with HIP events recorded on the handle's own stream around each kernel launch
+ * (off by default; tsdf_set_timing(h,1) turns it on), summed since the last reset. */
+typedef struct tsdf_timing {
+    double  integrate_ms;       /* integrate_kernel only                                              */
+    int64_t integrate_launches;
+    double  track_ms;           /* track_kernel + track_final_kernel, one launch pair per GN iteration */
+    int64_t track_launches;
+    double  pack_ms;            /* per-frame image packing kernel                                      */
+    int64_t pack_launches;
+} tsdf_timing;
+/* Cumulative work counters since the last reset (device counters; reading synchronizes). */
+typedef struct tsdf_counters {
+    int64_t n_updated;          /* owned voxels rewritten by tsdf_integrate                            */
+    int64_t n_updated_halo;
+    int64_t n_voxels_swept;
+    int64_t integrate_calls;
+    int64_t track_calls;
+    int64_t track_iterations;   /* Gauss-Newton passes                                                 */
+    int64_t track_in_grid;      /* owned in-grid samples over all passes (each does <= 13 look-ups)    */
+    int64_t track_terms;
+} tsdf_counters;
+int tsdf_set_timing(tsdf_handle *h, int32_t on);
+int tsdf_read_timing(tsdf_handle *h, tsdf_timing *out, int32_t reset);
+int tsdf_read_counters(tsdf_handle *h, tsdf_counters *out, int32_t reset);
+int tsdf_synchronize(tsdf_handle *h);
+/* The hipStream_t the handle launches on, as an opaque pointer (for callers that record their own events). */
+void *tsdf_stream(tsdf_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSDF_H_ */

@@ -1,0 +1,330 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (stated per SURVEY.md section 8c):
+  D, W, colour lanes   bit-exact, except voxels whose weight went through exp() (eps <= d <= delta):
+                       glibc exp vs ROCm ocml exp may differ in the last f64 bit, which after the
+                       f64->f32 narrowing is at most 1 float ulp on W (and what follows from it on D)
+  interpolation        bit-exact
+  A, b (6x6 / 6)       <= 1e-11 relative to the largest entry (f64, different summation order)
+  pose, one GN call    <= 1e-9
+  pose, 10 free frames <= 1e-5 m
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+from tracking_sdf_amd import synth
+from util import make_gpu, make_oracle, scaled_K, sym_rel_err, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+W_, H_ = 160, 120
+
+
+def frames(n, noise=False, holes=0.0, width=W_, height=H_, step=4):
+    seq = synth.Sequence(n_frames=n, width=width, height=height, noise=noise, holes=holes, step=step)
+    return seq, [seq.frame(k) for k in range(n)]
+
+
+def assert_volume_equal(go, oo, m, color=True, max_exp_ulp=1):
+    D, W = go.download()
+    uD, uW = ulp_diff(D, oo.D), ulp_diff(W, oo.W)
+    assert uW.max() <= max_exp_ulp, f"W differs by {uW.max()} ulp"
+    # where W is identical, D must be identical too
+    assert uD[uW == 0].max() == 0
+    frac = float((uW > 0).mean())
+    assert frac < 1e-4, f"{frac:.2e} of the voxels differ in W (expected only rare exp() last-bit cases)"
+    assert uD.max() <= 4
+    if color:
+        cw, r, g, b = go.download_color()
+        for got, want in ((cw, oo.Color_W), (r, oo.R), (g, oo.G), (b, oo.B)):
+            u = ulp_diff(got, want)
+            assert u[uW == 0].max() == 0 and u.max() <= 4
+    return frac
+
+
+@pytest.mark.parametrize("m", [32, 48, 64])
+def test_integrate_one_frame(m):
+    seq, fr = frames(1)
+    K = seq.K
+    oo, ot = make_oracle(m, K)
+    go, gt = make_gpu(m, K)
+    xyz, nrm, rgb = fr[0]
+    n_or = oo.update(ot, orc.Cloud(xyz, nrm, rgb), with_color=True)
+    st = go.update(gt, xyz, nrm, rgb)
+    assert st["n_updated"] == n_or and st["n_voxels"] == m ** 3 and st["n_updated_halo"] == 0
+    assert_volume_equal(go, oo, m)
+
+
+def test_integrate_sequence_ground_truth_poses():
+    """Fusion-only mode (the reference's _useGroundTruth switch): 6 frames at the true poses."""
+    m = 64
+    seq, fr = frames(6, noise=True, holes=0.02)
+    oo, ot = make_oracle(m, seq.K)
+    go, gt = make_gpu(m, seq.K)
+    for k, (xyz, nrm, rgb) in enumerate(fr):
+        ot.set_camera_transformation(seq.R[k], seq.t[k])
+        gt.set_camera_transformation(seq.R[k], seq.t[k])
+        n_or = oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+        st = go.update(gt, xyz, nrm, rgb)
+        assert st["n_updated"] == n_or
+    assert_volume_equal(go, oo, m)
+
+
+def test_integrate_without_color_lanes():
+    m = 32
+    seq, fr = frames(1)
+    oo, ot = make_oracle(m, seq.K)
+    go, gt = make_gpu(m, seq.K, with_color=False)
+    xyz, nrm, rgb = fr[0]
+    oo.update(ot, orc.Cloud(xyz, nrm, rgb), with_color=False)
+    go.update(gt, xyz, nrm)
+    assert_volume_equal(go, oo, m, color=False)
+
+
+def _fused_pair(m, n_fuse=3, noise=False, holes=0.0, **kw):
+    seq, fr = frames(n_fuse + 1, noise=noise, holes=holes)
+    oo, ot = make_oracle(m, seq.K)
+    go, gt = make_gpu(m, seq.K, **kw)
+    for k in range(n_fuse):
+        xyz, nrm, rgb = fr[k]
+        ot.set_camera_transformation(seq.R[k], seq.t[k])
+        oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+    go.upload(oo.D, oo.W)      # identical volumes on both sides
+    return seq, fr, oo, ot, go, gt
+
+
+def test_interpolate_distance_bit_exact():
+    m = 64
+    seq, fr, oo, ot, go, gt = _fused_pair(m)
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-2.0, m + 1.0, size=(20000, 3))
+    pts[:2000] = np.round(pts[:2000])                      # exact corner hits
+    pts[2000:3000, 1] = np.round(pts[2000:3000, 1])
+    pts[3000] = [-0.5, -0.25, 0.75]
+    pts[3001] = [1e12, 3.0, 3.0]
+    pts[3002] = [-1e12, 3.0, 3.0]
+    val, ok = go.interpolate_distance(pts)
+    for i in range(len(pts)):
+        v, k = oo.interpolate_distance(pts[i])
+        assert bool(ok[i]) == k, i
+        if k:
+            assert np.float32(v) == val[i], (i, pts[i], v, val[i])
+        else:
+            assert np.isnan(val[i])
+
+
+@pytest.mark.parametrize("stale", [True, False])
+@pytest.mark.parametrize("holes", [0.0, 0.05])
+def test_accumulate_matches_oracle(stale, holes):
+    m = 64
+    seq, fr, oo, ot, go, gt = _fused_pair(m, holes=holes, stale_carry=stale)
+    k = 3
+    xyz = fr[k][0]
+    for pose in ((seq.R[k], seq.t[k]), (seq.R[k - 1], seq.t[k - 1])):
+        ot.set_camera_transformation(*pose)
+        gt.set_camera_transformation(*pose)
+        A_o, b_o, st_o = ot.accumulate(oo, orc.Cloud(xyz), threads=1, stale_carry=stale)
+        go.set_frame(xyz)
+        A_g, b_g, st_g = gt.accumulate()
+        assert st_g["n_samples"] == st_o["n_samples"] and st_g["n_nan"] == st_o["n_nan"]
+        assert st_g["n_oog"] == st_o["n_oog"] and st_g["n_ok"] == st_o["n_ok"]
+        assert st_g["n_in_grid_owned"] == st_o["n_ok"] + st_o["n_fail"]
+        assert st_g["n_terms"] == st_o["n_terms"] and st_o["n_ok"] > 500
+        assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
+        assert np.array_equal(A_g, A_g.T)
+
+
+def test_accumulate_stale_carry_with_out_of_grid_samples():
+    """A volume smaller than the scene puts whole image regions outside the grid, so the reference's
+    carry-over (camera_tracking.cpp:156-159,261-268) fires on long runs, across wavefront and
+    workgroup boundaries of the tracker kernel."""
+    m = 48
+    vol = dict(width=2.4, height=2.4, depth=2.4, origin=(-1.2, -3.0, -0.2), delta=0.3, epsilon=0.025)
+    seq, fr = frames(3, holes=0.03, width=320, height=240)
+    oo, ot = make_oracle(m, seq.K, vol)
+    go, gt = make_gpu(m, seq.K, vol)
+    for k in range(2):
+        xyz, nrm, rgb = fr[k]
+        ot.set_camera_transformation(seq.R[k], seq.t[k])
+        oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+    go.upload(oo.D, oo.W)
+    ot.set_camera_transformation(seq.R[2], seq.t[2])
+    gt.set_camera_transformation(seq.R[2], seq.t[2])
+    xyz = fr[2][0]
+    A_o, b_o, st_o = ot.accumulate(oo, orc.Cloud(xyz), threads=1, stale_carry=True)
+    A_n, b_n, st_n = ot.accumulate(oo, orc.Cloud(xyz), threads=1, stale_carry=False)
+    go.set_frame(xyz)
+    A_g, b_g, st_g = gt.accumulate()
+    assert st_o["n_oog"] > 1000 and st_o["n_terms"] > st_n["n_terms"] + 20     # the carry really fires
+    assert st_g["n_terms"] == st_o["n_terms"] and st_g["n_oog"] == st_o["n_oog"]
+    assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
+
+
+def test_long_out_of_grid_run_spans_workgroups():
+    """One valid sample followed by > 3 workgroups' worth of out-of-grid samples, then a valid one."""
+    m = 32
+    vol = dict(width=3.2, height=3.2, depth=3.2, origin=(0.0, 0.0, 0.0), delta=0.3, epsilon=0.025)
+    K = scaled_K(64, 48)
+    oo, ot = make_oracle(m, K, vol)
+    oo.create_circle(1.0, 1.6, 1.6, 1.6)
+    go, gt = make_gpu(m, K, vol)
+    go.upload(oo.D, oo.W)
+    eye, zero = np.eye(3), np.zeros(3)
+    ot.set_camera_transformation(eye, zero)
+    gt.set_camera_transformation(eye, zero)
+    ncol, nrow = 40, 30                       # 1200 samples: 5 workgroups of 256
+    xyz = np.full((3 * nrow - 2, 3 * ncol - 2, 3), np.nan, dtype=np.float32)
+    samp = np.full((ncol, nrow, 3), [-5.0, 1.0, 1.0], dtype=np.float32)      # all out of grid
+    samp[0, 5] = (1.7, 1.5, 1.4)               # sample index 5: valid
+    samp[0, 7] = (np.nan, 0, 0)                # NaN samples are transparent
+    samp[30, 2] = (1.2, 1.9, 1.6)              # index 902: valid, ends the run
+    samp[30, 3] = (0.02, 0.02, 0.02)           # in grid, but rotational look-ups fine; keep simple
+    for c in range(ncol):
+        for r in range(nrow):
+            xyz[3 * r, 3 * c] = samp[c, r]
+    A_o, b_o, st_o = ot.accumulate(oo, orc.Cloud(xyz), threads=1, stale_carry=True)
+    go.set_frame(xyz)
+    A_g, b_g, st_g = gt.accumulate()
+    assert st_o["n_terms"] > 900
+    assert st_g["n_terms"] == st_o["n_terms"] and st_g["n_ok"] == st_o["n_ok"]
+    assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
+
+
+def test_track_one_frame_pose():
+    m = 64
+    seq, fr, oo, ot, go, gt = _fused_pair(m, noise=True)
+    k = 3
+    ot.set_camera_transformation(seq.R[k - 1], seq.t[k - 1])
+    gt.set_camera_transformation(seq.R[k - 1], seq.t[k - 1])
+    xyz = fr[k][0]
+    st_o = ot.estimate_new_position(oo, orc.Cloud(xyz), threads=1, stale_carry=True)
+    st_g = gt.estimate_new_position(go, xyz)
+    assert not st_o["nonfinite"]
+    assert st_g["iterations"] == st_o["iterations"] and bool(st_g["stopped"]) == st_o["stopped"]
+    assert np.max(np.abs(gt.rot - ot.rot)) < 1e-9 and np.max(np.abs(gt.trans - ot.trans)) < 1e-9
+    assert np.max(np.abs(gt.rot_inv_trans - ot.rot_inv_trans)) < 1e-9
+    assert np.allclose(st_g["last_twist"], st_o["last_twist"], atol=1e-9)
+
+
+def test_free_running_ten_frames():
+    """The reference's frame rule (sdf_reconstruction.cpp:69-74): frame 1 integrate only, then
+    track -> integrate.  Trajectories must agree to 1e-5 m over 10 frames."""
+    m = 64
+    seq, fr = frames(10, noise=True, holes=0.01, step=2)
+    oo, ot = make_oracle(m, seq.K)
+    go, gt = make_gpu(m, seq.K)
+    worst = 0.0
+    for k, (xyz, nrm, rgb) in enumerate(fr):
+        cloud = orc.Cloud(xyz, nrm, rgb)
+        if k > 0:
+            so = ot.estimate_new_position(oo, cloud, threads=1, stale_carry=True)
+            sg = gt.estimate_new_position(go, xyz)
+            assert not so["nonfinite"]
+            worst = max(worst, float(np.max(np.abs(gt.trans - ot.trans))), float(np.max(np.abs(gt.rot - ot.rot))))
+        oo.update(ot, cloud)
+        go.update(gt, xyz, nrm, rgb)
+    assert worst < 1e-5, worst
+    D, W = go.download()
+    # volumes agree except where a last-bit pose difference flipped a pixel truncation
+    assert float((ulp_diff(W, oo.W) > 1).mean()) < 1e-3
+
+
+def test_slab_shards_sum_to_whole():
+    """x-slab sharding emulated on one GPU: three handles, each a slab + halo."""
+    import tracking_sdf_amd as ts
+    m = 64
+    seq, fr, oo, ot, go, gt = _fused_pair(m, holes=0.02)
+    k = 3
+    xyz, nrm, rgb = fr[k]
+    pose = (seq.R[k], seq.t[k])
+    gt.set_camera_transformation(*pose)
+    go.set_frame(xyz)
+    A, b, st = gt.accumulate()
+    halo = ts.halo_for(go.cfg, 6.0)
+    parts = []
+    nr = 3
+    for r in range(nr):
+        x0, x1 = ts.slab_range(m, nr, r)
+        gs, gtr = make_gpu(m, seq.K, slab=(x0, x1), halo=halo)
+        gs.upload_with_halo(oo.D, oo.W)
+        gtr.set_camera_transformation(*pose)
+        gs.set_frame(xyz)
+        parts.append(gtr.accumulate())
+        # a slab integrates its own layers (+ halo) to the same bits as the whole volume
+        gs.set_frame(xyz, nrm, rgb)
+        sti = gs.update()
+        Ds, Ws = gs.download()
+        go2, gt2 = make_gpu(m, seq.K)
+        go2.upload(oo.D, oo.W)
+        gt2.set_camera_transformation(*pose)
+        go2.update(gt2, xyz, nrm, rgb)
+        Df, Wf = go2.download()
+        sl = slice(x0 * m * m, x1 * m * m)
+        assert np.array_equal(Ds, Df[sl], equal_nan=True) and np.array_equal(Ws, Wf[sl], equal_nan=True)
+        assert sti["n_voxels"] == (min(m, x1 + halo) - max(0, x0 - halo)) * m * m
+    assert sum(p[2]["n_terms"] for p in parts) == st["n_terms"]
+    assert sum(p[2]["n_ok"] for p in parts) == st["n_ok"]
+    assert sym_rel_err(sum(p[0] for p in parts), A) < 1e-12
+    assert sym_rel_err(sum(p[1] for p in parts), b) < 1e-12
+
+
+def test_halo_too_small_is_reported():
+    import tracking_sdf_amd as ts
+    m = 64
+    seq, fr, oo, ot, go, gt = _fused_pair(m)
+    gs, gtr = make_gpu(m, seq.K, slab=(20, 40), halo=0)
+    gs.upload_with_halo(oo.D, oo.W)
+    gtr.set_camera_transformation(seq.R[3], seq.t[3])
+    gs.set_frame(fr[3][0])
+    with pytest.raises(ts.TsdfError) as ei:
+        gtr.accumulate()
+    assert ei.value.code == ts.E_HALO
+
+
+def test_error_paths_leave_pose_untouched():
+    import tracking_sdf_amd as ts
+    m = 32
+    seq, fr = frames(1)
+    go = ts.SDF(m)
+    gt = ts.CameraTracking(sdf=go)
+    xyz, nrm, rgb = fr[0]
+    with pytest.raises(ts.TsdfError) as ei:
+        go.update()                                   # no frame
+    assert ei.value.code == ts.E_NO_FRAME
+    go.set_frame(xyz, nrm, rgb)
+    with pytest.raises(ts.TsdfError) as ei:
+        go.update()                                   # K never set: the reference exits here
+    assert ei.value.code == ts.E_NO_INTRINSICS
+    rot0, trans0 = gt.rot.copy(), gt.trans.copy()
+    with pytest.raises(ts.TsdfError) as ei:
+        gt.estimate_new_position(go, xyz)             # empty volume: no valid sample
+    assert ei.value.code == ts.E_NO_SAMPLES
+    assert np.array_equal(gt.rot, rot0) and np.array_equal(gt.trans, trans0)
+    with pytest.raises(ts.TsdfError) as ei:
+        gt.gn_update(np.zeros((6, 6)), np.ones(6))    # singular: the reference would go NaN silently
+    assert ei.value.code == ts.E_SINGULAR
+    assert np.array_equal(gt.rot, rot0) and np.array_equal(gt.trans, trans0)
+    go.set_frame(xyz)                                 # xyz only: integrate must refuse
+    gt.set_K(seq.K)
+    with pytest.raises(ts.TsdfError):
+        go.update()
+
+
+def test_download_upload_roundtrip_and_reset():
+    import tracking_sdf_amd as ts
+    m = 32
+    go = ts.SDF(m)
+    D, W = go.download()
+    assert np.all(D == np.float32(15.5)) and np.all(W == 0)
+    cw, r, g, b = go.download_color()
+    assert np.all(cw == 0) and np.all(r == np.float32(0.4)) and np.all(b == np.float32(0.4))
+    rng = np.random.default_rng(0)
+    D2 = rng.standard_normal(m ** 3).astype(np.float32)
+    W2 = rng.random(m ** 3).astype(np.float32)
+    go.upload(D2, W2)
+    D3, W3 = go.download()
+    assert np.array_equal(D3, D2) and np.array_equal(W3, W2)
+    go.reset()
+    D, W = go.download()
+    assert np.all(D == np.float32(15.5)) and np.all(W == 0)

@@ -1,0 +1,456 @@
+"""tracking_sdf_amd -- MI355X-native hot path of mees/tracking_sdf behind its own entry points.
+
+This package is a thin ctypes binding of the C ABI in include/tsdf.h (libtsdf_hip.so: hand-written
+gfx950 HIP kernels + the C++ host loop) plus Python mirrors of the reference's two classes,
+``SDF`` (include/sdf_3d_reconstruction/sdf.h) and ``CameraTracking`` (camera_tracking.h), with the
+reference's method names.  There is no CPU fallback: if the shared library is missing or no GPU is
+visible, the compute entry points raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["SDF", "CameraTracking", "TsdfError", "Config", "lib", "lib_path", "build", "slab_range", "halo_for"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+
+# status codes of include/tsdf.h
+OK, E_BADARG, E_NO_DEVICE, E_HIP, E_NO_INTRINSICS, E_NO_FRAME, E_SINGULAR, E_NO_SAMPLES, E_HALO, E_COMM, E_NOMEM = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
+RED_WIDTH = 34
+RED_ALLREDUCE = 30
+
+
+class TsdfError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"tsdf error {code}: {message}")
+        self.code = code
+
+
+class Config(C.Structure):
+    """struct tsdf_config"""
+    _fields_ = [("m", C.c_int32), ("width", C.c_float), ("height", C.c_float), ("depth", C.c_float),
+                ("origin", C.c_double * 3), ("delta", C.c_float), ("epsilon", C.c_float),
+                ("gn_max_iter", C.c_int32), ("max_twist_diff", C.c_float), ("v_h", C.c_float), ("w_h", C.c_float),
+                ("pixel_stride", C.c_int32), ("stale_carry", C.c_int32), ("with_color", C.c_int32),
+                ("slab_x0", C.c_int32), ("slab_x1", C.c_int32), ("halo", C.c_int32), ("device", C.c_int32)]
+
+
+class IntegrateStats(C.Structure):
+    _fields_ = [("n_updated", C.c_int64), ("n_updated_halo", C.c_int64), ("n_voxels", C.c_int64)]
+
+
+class AccumStats(C.Structure):
+    _fields_ = [("n_samples", C.c_int64), ("n_nan", C.c_int64), ("n_oog", C.c_int64),
+                ("n_in_grid_owned", C.c_int64), ("n_ok", C.c_int64), ("n_terms", C.c_int64)]
+
+
+class TrackStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("stopped", C.c_int32), ("n_terms_last", C.c_int64),
+                ("last_twist", C.c_double * 6)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("integrate_ms", C.c_double), ("integrate_launches", C.c_int64),
+                ("track_ms", C.c_double), ("track_launches", C.c_int64),
+                ("pack_ms", C.c_double), ("pack_launches", C.c_int64)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_updated", C.c_int64), ("n_updated_halo", C.c_int64), ("n_voxels_swept", C.c_int64),
+                ("integrate_calls", C.c_int64), ("track_calls", C.c_int64), ("track_iterations", C.c_int64),
+                ("track_in_grid", C.c_int64), ("track_terms", C.c_int64)]
+
+
+def _struct_dict(s):
+    out = {}
+    for k, _ in s._fields_:
+        v = getattr(s, k)
+        out[k] = list(v) if hasattr(v, "__len__") else v
+    return out
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
+
+# every symbol include/tsdf.h declares (checked by tests/test_abi.py against the header text)
+ABI_SYMBOLS = (
+    "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
+    "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
+    "tsdf_set_frame_device", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
+    "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset",
+    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_set_allreduce_hook",
+    "tsdf_allreduce", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
+)
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def build(force: bool = False) -> str:
+    """Compile libtsdf_hip.so for gfx950 with hipcc (works without a GPU)."""
+    import subprocess
+    if force and os.path.exists(_LIB_PATH):
+        os.remove(_LIB_PATH)
+    subprocess.check_call(["make", "-C", _ROOT, "-s", _LIB_PATH])
+    return _LIB_PATH
+
+
+def lib():
+    """Load libtsdf_hip.so.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise TsdfError(E_NO_DEVICE, f"{_LIB_PATH} not built: run `make` (hipcc --offload-arch=gfx950); "
+                                     "there is no CPU fallback")
+    L = C.CDLL(_LIB_PATH)
+    H = C.c_void_p
+    dp, fp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    sig = {
+        "tsdf_abi_version": (C.c_int, []),
+        "tsdf_default_config": (None, [C.POINTER(Config)]),
+        "tsdf_create": (C.c_int, [C.POINTER(Config), C.POINTER(H)]),
+        "tsdf_destroy": (None, [H]),
+        "tsdf_last_error": (C.c_char_p, [H]),
+        "tsdf_strerror": (C.c_char_p, [C.c_int]),
+        "tsdf_get_config": (C.c_int, [H, C.POINTER(Config)]),
+        "tsdf_set_intrinsics": (C.c_int, [H, dp]),
+        "tsdf_set_camera_transformation": (C.c_int, [H, dp, dp]),
+        "tsdf_get_pose": (C.c_int, [H, dp, dp, dp, dp]),
+        "tsdf_set_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
+        "tsdf_set_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+        "tsdf_integrate": (C.c_int, [H, C.POINTER(IntegrateStats)]),
+        "tsdf_track": (C.c_int, [H, C.POINTER(TrackStats)]),
+        "tsdf_accumulate": (C.c_int, [H, dp, dp, C.POINTER(AccumStats)]),
+        "tsdf_gn_update": (C.c_int, [H, dp, dp, dp, ip]),
+        "tsdf_sample": (C.c_int, [H, dp, C.c_int32, fp, ip]),
+        "tsdf_download": (C.c_int, [H, fp, fp]),
+        "tsdf_upload": (C.c_int, [H, fp, fp]),
+        "tsdf_download_color": (C.c_int, [H, fp, fp, fp, fp]),
+        "tsdf_upload_color": (C.c_int, [H, fp, fp, fp, fp]),
+        "tsdf_upload_with_halo": (C.c_int, [H, fp, fp]),
+        "tsdf_reset": (C.c_int, [H]),
+        "tsdf_slab_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, ip, ip]),
+        "tsdf_halo_for": (C.c_int32, [C.POINTER(Config), C.c_float]),
+        "tsdf_comm_unique_id": (C.c_int, [C.c_void_p]),
+        "tsdf_comm_init": (C.c_int, [H, C.c_int32, C.c_int32, C.c_void_p]),
+        "tsdf_set_allreduce_hook": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
+        "tsdf_allreduce": (C.c_int, [H, dp, C.c_int32]),
+        "tsdf_set_timing": (C.c_int, [H, C.c_int32]),
+        "tsdf_read_timing": (C.c_int, [H, C.POINTER(Timing), C.c_int32]),
+        "tsdf_read_counters": (C.c_int, [H, C.POINTER(Counters), C.c_int32]),
+        "tsdf_synchronize": (C.c_int, [H]),
+        "tsdf_stream": (C.c_void_p, [H]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)          # AttributeError here = ABI drift: fail loudly
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def default_config(**overrides) -> Config:
+    cfg = Config()
+    lib().tsdf_default_config(C.byref(cfg))
+    for k, v in overrides.items():
+        if k == "origin":
+            cfg.origin = (C.c_double * 3)(*[float(x) for x in v])
+        else:
+            if not hasattr(cfg, k):
+                raise AttributeError(f"tsdf_config has no field {k}")
+            setattr(cfg, k, v)
+    return cfg
+
+
+def slab_range(m: int, nranks: int, rank: int):
+    x0, x1 = C.c_int32(), C.c_int32()
+    rc = lib().tsdf_slab_range(m, nranks, rank, C.byref(x0), C.byref(x1))
+    if rc:
+        raise TsdfError(rc, "tsdf_slab_range: bad argument")
+    return int(x0.value), int(x1.value)
+
+
+def halo_for(cfg: Config, max_range: float) -> int:
+    return int(lib().tsdf_halo_for(C.byref(cfg), float(max_range)))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _d(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
+class SDF:
+    """The reference's ``class SDF`` (sdf.h:35-186) with the volume resident in HBM.
+
+    ``SDF(m, width, height, depth, sdf_origin, distance_delta, distance_epsilon)`` as in sdf.h:78-79;
+    keyword extras select colour lanes, the x-slab this rank owns and the device.
+    """
+
+    def __init__(self, m=256, width=6.0, height=6.0, depth=3.5, sdf_origin=(-3.0, -3.0, -0.5),
+                 distance_delta=0.3, distance_epsilon=0.025, *, with_color=True, slab=None, halo=0,
+                 device=0, stale_carry=True, gn_max_iter=20, max_twist_diff=0.001, v_h=1.0, w_h=0.01,
+                 pixel_stride=3):
+        L = lib()
+        cfg = default_config(m=int(m), width=float(width), height=float(height), depth=float(depth),
+                             origin=sdf_origin, delta=float(distance_delta), epsilon=float(distance_epsilon),
+                             with_color=1 if with_color else 0, halo=int(halo), device=int(device),
+                             stale_carry=1 if stale_carry else 0, gn_max_iter=int(gn_max_iter),
+                             max_twist_diff=float(max_twist_diff), v_h=float(v_h), w_h=float(w_h),
+                             pixel_stride=int(pixel_stride))
+        if slab is not None:
+            cfg.slab_x0, cfg.slab_x1 = int(slab[0]), int(slab[1])
+        self._h = C.c_void_p()
+        rc = L.tsdf_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            self._h = None
+            raise TsdfError(rc, L.tsdf_last_error(None).decode())
+        got = Config()
+        L.tsdf_get_config(self._h, C.byref(got))
+        self.cfg = got
+        self.m = int(got.m)
+        self.m_div_width = float(np.float32(got.m) / np.float32(got.width))
+        self.m_div_height = float(np.float32(got.m) / np.float32(got.height))
+        self.m_div_depth = float(np.float32(got.m) / np.float32(got.depth))
+        self._keep = []          # callbacks / borrowed tensors kept alive
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc:
+            raise TsdfError(rc, lib().tsdf_last_error(self._h).decode() or lib().tsdf_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tsdf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def slab(self):
+        return int(self.cfg.slab_x0), int(self.cfg.slab_x1)
+
+    def get_number_of_voxels(self):
+        return self.m ** 3
+
+    # -- frames (the cloud_filtered / normals arguments of the reference's hot calls)
+    def set_frame(self, xyz, normals=None, rgb=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        if xyz.ndim != 3 or xyz.shape[2] != 3:
+            raise ValueError("xyz must be (height, width, 3)")
+        h, w = xyz.shape[:2]
+        nptr = cptr = None
+        if normals is not None:
+            normals = np.ascontiguousarray(normals, dtype=np.float32)
+            assert normals.shape == xyz.shape
+            nptr = _fptr(normals)
+        if rgb is not None:
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            assert rgb.shape == xyz.shape
+            cptr = rgb.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(lib().tsdf_set_frame(self._h, _fptr(xyz), nptr, cptr, w, h))
+
+    def set_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
+        """Borrow device pointers (ints, e.g. torch.Tensor.data_ptr()) of images already in HBM."""
+        self._keep = [keep]
+        self._check(lib().tsdf_set_frame_device(self._h, C.c_void_p(d_xyz), C.c_void_p(d_normals or 0),
+                                                C.c_void_p(d_rgb or 0), int(width), int(height)))
+
+    # -- SDF::update(camera_tracking, cloud_filtered, normals), sdf.h:161-163
+    def update(self, camera_tracking=None, cloud_filtered=None, normals=None, rgb=None, want_stats=True):
+        if cloud_filtered is not None:
+            self.set_frame(cloud_filtered, normals, rgb)
+        if want_stats:
+            st = IntegrateStats()
+            self._check(lib().tsdf_integrate(self._h, C.byref(st)))
+            return _struct_dict(st)
+        self._check(lib().tsdf_integrate(self._h, None))
+        return None
+
+    # -- SDF::interpolate_distance, sdf.h:86 (batched; voxel coordinates like the reference's argument)
+    def interpolate_distance(self, voxel_coordinates):
+        v = np.ascontiguousarray(voxel_coordinates, dtype=np.float64).reshape(-1, 3)
+        val = np.zeros(len(v), dtype=np.float32)
+        ok = np.zeros(len(v), dtype=np.int32)
+        self._check(lib().tsdf_sample(self._h, _dptr(v), len(v), _fptr(val), ok.ctypes.data_as(C.POINTER(C.c_int32))))
+        return val, ok.astype(bool)
+
+    # -- host mirrors of D/W (what the reference hands to its mesher, sdf.cpp:47-49)
+    def download(self):
+        n = (self.cfg.slab_x1 - self.cfg.slab_x0) * self.m * self.m
+        D = np.empty(n, dtype=np.float32)
+        W = np.empty(n, dtype=np.float32)
+        self._check(lib().tsdf_download(self._h, _fptr(D), _fptr(W)))
+        return D, W
+
+    def upload(self, D, W):
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1)
+        W = np.ascontiguousarray(W, dtype=np.float32).reshape(-1)
+        n = (self.cfg.slab_x1 - self.cfg.slab_x0) * self.m * self.m
+        assert D.size == n and W.size == n
+        self._check(lib().tsdf_upload(self._h, _fptr(D), _fptr(W)))
+
+    def upload_with_halo(self, D_full, W_full):
+        """Upload this rank's stored layers (slab + halo) out of full-volume host arrays."""
+        m = self.m
+        xs = max(0, self.cfg.slab_x0 - self.cfg.halo)
+        xe = min(m, self.cfg.slab_x1 + self.cfg.halo)
+        D = np.ascontiguousarray(np.asarray(D_full, dtype=np.float32).reshape(m, m, m)[xs:xe]).reshape(-1)
+        W = np.ascontiguousarray(np.asarray(W_full, dtype=np.float32).reshape(m, m, m)[xs:xe]).reshape(-1)
+        self._check(lib().tsdf_upload_with_halo(self._h, _fptr(D), _fptr(W)))
+
+    def download_color(self):
+        n = (self.cfg.slab_x1 - self.cfg.slab_x0) * self.m * self.m
+        out = [np.empty(n, dtype=np.float32) for _ in range(4)]
+        self._check(lib().tsdf_download_color(self._h, *[_fptr(a) for a in out]))
+        return tuple(out)
+
+    def upload_color(self, Color_W, R, G, B):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in (Color_W, R, G, B)]
+        self._check(lib().tsdf_upload_color(self._h, *[_fptr(a) for a in arrs]))
+
+    def reset(self):
+        self._check(lib().tsdf_reset(self._h))
+
+    # -- multi-GPU plumbing
+    def comm_init(self, nranks, rank, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(lib().tsdf_comm_init(self._h, nranks, rank, buf))
+
+    def set_allreduce_hook(self, fn):
+        """fn(np.ndarray[float64]) sums the array over ranks in place."""
+        if fn is None:
+            self._hook = None
+            self._check(lib().tsdf_set_allreduce_hook(self._h, C.cast(None, ALLREDUCE_FN), None))
+            return
+
+        def _tramp(buf, n, _ctx):
+            try:
+                fn(np.ctypeslib.as_array(buf, shape=(n,)))
+                return 0
+            except Exception:
+                return 1
+        self._hook = ALLREDUCE_FN(_tramp)
+        self._check(lib().tsdf_set_allreduce_hook(self._h, self._hook, None))
+
+    def allreduce(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1)
+        self._check(lib().tsdf_allreduce(self._h, _dptr(a), a.size))
+        return a
+
+    # -- measurement
+    def set_timing(self, on=True):
+        self._check(lib().tsdf_set_timing(self._h, 1 if on else 0))
+
+    def read_timing(self, reset=False):
+        t = Timing()
+        self._check(lib().tsdf_read_timing(self._h, C.byref(t), 1 if reset else 0))
+        return _struct_dict(t)
+
+    def read_counters(self, reset=False):
+        c = Counters()
+        self._check(lib().tsdf_read_counters(self._h, C.byref(c), 1 if reset else 0))
+        return _struct_dict(c)
+
+    def synchronize(self):
+        self._check(lib().tsdf_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return lib().tsdf_stream(self._h)
+
+
+class CameraTracking:
+    """The reference's ``class CameraTracking`` (camera_tracking.h:12-105).
+
+    Constructor arguments follow the *definition* (camera_tracking.cpp:3-4):
+    ``(gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf)``; the steps are applied when the
+    volume handle is created, so they are taken from ``sdf`` and only checked here.
+    Pose state lives in the same native handle as the volume.
+    """
+
+    def __init__(self, gauss_newton_max_iteration=20, maximum_twist_diff=0.001, v_h=1.0, w_h=0.01, sdf: SDF = None):
+        if sdf is None:
+            raise ValueError("CameraTracking needs the SDF it tracks against")
+        c = sdf.cfg
+        want = (int(gauss_newton_max_iteration), np.float32(maximum_twist_diff), np.float32(v_h), np.float32(w_h))
+        have = (int(c.gn_max_iter), np.float32(c.max_twist_diff), np.float32(c.v_h), np.float32(c.w_h))
+        if want != have:
+            raise ValueError(f"tracker constants {want} differ from the ones the volume was created with {have}")
+        self.sdf = sdf
+        self.isKFilled = False
+
+    def _pose(self):
+        rot, trans, ri, rit = np.zeros(9), np.zeros(3), np.zeros(9), np.zeros(3)
+        self.sdf._check(lib().tsdf_get_pose(self.sdf._h, _dptr(rot), _dptr(trans), _dptr(ri), _dptr(rit)))
+        return rot.reshape(3, 3), trans, ri.reshape(3, 3), rit
+
+    # public fields of camera_tracking.h:43-49
+    @property
+    def rot(self):
+        return self._pose()[0]
+
+    @property
+    def trans(self):
+        return self._pose()[1]
+
+    @property
+    def rot_inv(self):
+        return self._pose()[2]
+
+    @property
+    def rot_inv_trans(self):
+        return self._pose()[3]
+
+    def set_K(self, K):
+        """camera_info_cb (camera_tracking.cpp:22-36)."""
+        k = _d(K, 9)
+        self.K = k.reshape(3, 3).copy()
+        self.sdf._check(lib().tsdf_set_intrinsics(self.sdf._h, _dptr(k)))
+        self.isKFilled = True
+
+    def set_camera_transformation(self, rot, trans):
+        r, t = _d(rot, 9), _d(trans, 3)
+        self.sdf._check(lib().tsdf_set_camera_transformation(self.sdf._h, _dptr(r), _dptr(t)))
+
+    def estimate_new_position(self, sdf: SDF = None, point_cloud=None):
+        """camera_tracking.h:101.  ``point_cloud`` = xyz (h, w, 3); None keeps the frame already set."""
+        s = sdf or self.sdf
+        if point_cloud is not None:
+            s.set_frame(point_cloud)
+        st = TrackStats()
+        s._check(lib().tsdf_track(s._h, C.byref(st)))
+        return _struct_dict(st)
+
+    def accumulate(self):
+        """One Gauss-Newton accumulation at the current pose: (A 6x6, b 6, stats), this rank's part only."""
+        A, b, st = np.zeros(36), np.zeros(6), AccumStats()
+        self.sdf._check(lib().tsdf_accumulate(self.sdf._h, _dptr(A), _dptr(b), C.byref(st)))
+        return A.reshape(6, 6), b, _struct_dict(st)
+
+    def gn_update(self, A, b):
+        a, bb, tw, stop = _d(A, 36), _d(b, 6), np.zeros(6), C.c_int32(0)
+        self.sdf._check(lib().tsdf_gn_update(self.sdf._h, _dptr(a), _dptr(bb), _dptr(tw), C.byref(stop)))
+        return bool(stop.value), tw

@@ -1,0 +1,797 @@
+// tsdf_api.cpp -- the C ABI of include/tsdf.h: handle, device memory, frame staging, the host-side
+// Gauss-Newton loop (reference src/camera_tracking.cpp:66-245) driving the HIP kernels, slab
+// sharding and the per-iteration all-reduce (RCCL or a host hook).  No torch types, no exceptions
+// across the boundary, no CPU fallback.
+#include "../../include/tsdf.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_math.hpp"
+#include "rccl_dyn.hpp"
+#include "tsdf_device.h"
+
+using namespace tsdf;
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_create_error;
+
+struct EventPair { hipEvent_t a = nullptr, b = nullptr; };
+
+}  // namespace
+
+struct tsdf_handle {
+    tsdf_config cfg{};
+    Grid grid{};
+    hm::Pose pose{};
+    double K[9]{};
+    bool have_K = false;
+    float v_h2_w = 0, v_h2_h = 0, v_h2_d = 0, wh2 = 0;
+
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float2* dw = nullptr;
+    float4* crgb = nullptr;
+    int64_t n_stored = 0;          // voxels in [xs, xe)
+    unsigned long long* counters = nullptr;     // device, kNumCounters
+    unsigned long long* counters_host = nullptr;  // pinned
+
+    // frame
+    int32_t fw = 0, fh = 0, ncols = 0, nrows = 0, n_samples = 0;
+    bool have_frame = false, frame_has_nrm = false, frame_has_rgb = false;
+    float* in_xyz = nullptr; float* in_nrm = nullptr; uint8_t* in_rgb = nullptr;   // device staging (owned)
+    float* pin_xyz = nullptr; float* pin_nrm = nullptr; uint8_t* pin_rgb = nullptr;  // pinned host staging
+    size_t in_cap = 0;             // pixels the staging buffers hold
+    float4* pn = nullptr;          // 2 x float4 per pixel
+    float4* samples = nullptr;
+    size_t pn_cap = 0, samples_cap = 0;
+
+    // tracker reduction buffers
+    double* partials = nullptr; size_t partials_cap = 0;   // blocks x kRedWidth
+    double* red_dev = nullptr;     // kRedWidth
+    double* red_host = nullptr;    // pinned, kRedWidth
+
+    // comm
+    rccl::Comm comm;
+    tsdf_allreduce_fn hook = nullptr;
+    void* hook_ctx = nullptr;
+
+    // measurement
+    bool timing = false;
+    std::vector<EventPair> ev_pool;   // pending integrate/pack pairs
+    std::vector<int> ev_kind;         // 0 = integrate, 1 = pack
+    size_t ev_used = 0;
+    EventPair ev_track;
+    tsdf_timing tm{};
+    tsdf_counters cnt{};
+    unsigned long long cnt_base[kNumCounters]{};
+
+    std::string err;
+};
+
+namespace {
+
+int fail(tsdf_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else { std::lock_guard<std::mutex> lk(g_err_mu); g_create_error = buf; }
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail((h), TSDF_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+int bind_device(tsdf_handle* h) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    return TSDF_OK;
+}
+
+void free_frame(tsdf_handle* h) {
+    if (h->in_xyz) (void)hipFree(h->in_xyz);
+    if (h->in_nrm) (void)hipFree(h->in_nrm);
+    if (h->in_rgb) (void)hipFree(h->in_rgb);
+    if (h->pin_xyz) (void)hipHostFree(h->pin_xyz);
+    if (h->pin_nrm) (void)hipHostFree(h->pin_nrm);
+    if (h->pin_rgb) (void)hipHostFree(h->pin_rgb);
+    h->in_xyz = h->in_nrm = nullptr; h->in_rgb = nullptr;
+    h->pin_xyz = h->pin_nrm = nullptr; h->pin_rgb = nullptr;
+    h->in_cap = 0;
+}
+
+int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_staging) {
+    const size_t npix = (size_t)w * hh;
+    const int32_t st = h->cfg.pixel_stride;
+    const int32_t ncols = (w + st - 1) / st, nrows = (hh + st - 1) / st;
+    const size_t ns = (size_t)ncols * nrows;
+    if (npix > h->pn_cap) {
+        if (h->pn) (void)hipFree(h->pn);
+        h->pn = nullptr; h->pn_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->pn, npix * 2 * sizeof(float4)));
+        h->pn_cap = npix;
+    }
+    if (ns > h->samples_cap) {
+        if (h->samples) (void)hipFree(h->samples);
+        h->samples = nullptr; h->samples_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->samples, ns * sizeof(float4)));
+        h->samples_cap = ns;
+    }
+    const size_t nb = (size_t)track_num_blocks((int32_t)ns);
+    if (nb > h->partials_cap) {
+        if (h->partials) (void)hipFree(h->partials);
+        h->partials = nullptr; h->partials_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->partials, nb * kRedWidth * sizeof(double)));
+        h->partials_cap = nb;
+    }
+    if (need_staging && npix > h->in_cap) {
+        free_frame(h);
+        HIP_TRY(h, hipMalloc((void**)&h->in_xyz, npix * 3 * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->in_nrm, npix * 3 * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->in_rgb, npix * 3));
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_xyz, npix * 3 * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_nrm, npix * 3 * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_rgb, npix * 3, hipHostMallocDefault));
+        h->in_cap = npix;
+    }
+    h->fw = w; h->fh = hh; h->ncols = ncols; h->nrows = nrows; h->n_samples = (int32_t)ns;
+    return TSDF_OK;
+}
+
+// ---- event timing -------------------------------------------------------------------------------
+
+int drain_events(tsdf_handle* h) {
+    if (h->ev_used == 0) return TSDF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
+        if (h->ev_kind[i] == 0) { h->tm.integrate_ms += ms; h->tm.integrate_launches++; }
+        else { h->tm.pack_ms += ms; h->tm.pack_launches++; }
+    }
+    h->ev_used = 0;
+    return TSDF_OK;
+}
+
+int timed_begin(tsdf_handle* h, int kind, EventPair** out) {
+    *out = nullptr;
+    if (!h->timing) return TSDF_OK;
+    if (h->ev_used == h->ev_pool.size()) {
+        if (h->ev_pool.size() >= 4096) {
+            int rc = drain_events(h);
+            if (rc) return rc;
+        } else {
+            EventPair ep;
+            HIP_TRY(h, hipEventCreate(&ep.a));
+            HIP_TRY(h, hipEventCreate(&ep.b));
+            h->ev_pool.push_back(ep);
+            h->ev_kind.push_back(0);
+        }
+    }
+    EventPair* ep = &h->ev_pool[h->ev_used];
+    h->ev_kind[h->ev_used] = kind;
+    h->ev_used++;
+    HIP_TRY(h, hipEventRecord(ep->a, h->stream));
+    *out = ep;
+    return TSDF_OK;
+}
+
+int timed_end(tsdf_handle* h, EventPair* ep) {
+    if (ep) HIP_TRY(h, hipEventRecord(ep->b, h->stream));
+    return TSDF_OK;
+}
+
+int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb) {
+    EventPair* ep;
+    int rc = timed_begin(h, 1, &ep);
+    if (rc) return rc;
+    HIP_TRY(h, launch_pack(h->stream, xyz, nrm, rgb, h->fw, h->fh, h->cfg.pixel_stride, h->pn, h->samples,
+                           h->ncols, h->nrows));
+    rc = timed_end(h, ep);
+    if (rc) return rc;
+    h->have_frame = true;
+    h->frame_has_nrm = nrm != nullptr;
+    h->frame_has_rgb = rgb != nullptr;
+    return TSDF_OK;
+}
+
+void fill_track_params(const tsdf_handle* h, TrackParams& p) {
+    p.g = h->grid;
+    std::memcpy(p.rot, h->pose.rot, sizeof p.rot);
+    std::memcpy(p.trans, h->pose.trans, sizeof p.trans);
+    hm::perturbed_rotations(h->pose, h->cfg.w_h, p.rpm);
+    p.v_h = h->cfg.v_h;
+    p.vh2[0] = h->v_h2_w; p.vh2[1] = h->v_h2_h; p.vh2[2] = h->v_h2_d;
+    p.wh2 = h->wh2;
+    p.n_samples = h->n_samples;
+    p.stale_carry = h->cfg.stale_carry;
+}
+
+// Launch one accumulation pass and wait for its kRedWidth-double result row in h->red_host.
+// reduce_ranks: sum the leading kRedAllreduce entries over ranks (RCCL on the device buffer, or hook).
+int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
+    TrackParams p;
+    fill_track_params(h, p);
+    const bool use_rccl = reduce_ranks && h->comm.active();
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
+    HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
+                            use_rccl ? nullptr : h->red_host));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
+    if (use_rccl) {
+        std::string cerr;
+        if (!h->comm.allreduce_sum_f64(h->red_dev, kRedAllreduce, h->stream, &cerr))
+            return fail(h, TSDF_E_COMM, "RCCL all-reduce failed: %s", cerr.c_str());
+        HIP_TRY(h, hipMemcpyAsync(h->red_host, h->red_dev, kRedWidth * sizeof(double), hipMemcpyDeviceToHost,
+                                  h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->timing) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_track.a, h->ev_track.b));
+        h->tm.track_ms += ms;
+        h->tm.track_launches++;
+    }
+    h->cnt.track_iterations++;
+    h->cnt.track_in_grid += (int64_t)h->red_host[30];
+    h->cnt.track_terms += (int64_t)h->red_host[27];
+    if (reduce_ranks && !use_rccl && h->hook) {
+        if (h->hook(h->red_host, kRedAllreduce, h->hook_ctx) != 0)
+            return fail(h, TSDF_E_COMM, "all-reduce hook reported failure");
+    }
+    if (h->red_host[28] > 0.0)
+        return fail(h, TSDF_E_HALO,
+                    "%.0f tracking look-ups left the stored layers [%d,%d) of this rank: halo=%d is too small",
+                    h->red_host[28], h->grid.xs, h->grid.xe, h->cfg.halo);
+    return TSDF_OK;
+}
+
+void unpack_normal_equations(const double* row, double A[36], double b[6]) {
+    int e = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) { A[6 * a + c] = row[e]; A[6 * c + a] = row[e]; ++e; }
+    for (int a = 0; a < 6; ++a) b[a] = row[21 + a];
+}
+
+int check_ready(tsdf_handle* h, bool need_frame) {
+    if (!h) return TSDF_E_BADARG;
+    if (need_frame && !h->have_frame) return fail(h, TSDF_E_NO_FRAME, "no frame: call tsdf_set_frame first");
+    return bind_device(h);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int tsdf_abi_version(void) { return TSDF_ABI_VERSION; }
+
+void tsdf_default_config(tsdf_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->m = 256; c->width = 6.0f; c->height = 6.0f; c->depth = 3.5f;      // sdf_reconstruction.cpp:83-85
+    c->origin[0] = -3.0; c->origin[1] = -3.0; c->origin[2] = -0.5;
+    c->delta = 0.3f; c->epsilon = 0.025f;
+    c->gn_max_iter = 20; c->max_twist_diff = 0.001f; c->v_h = 1.0f; c->w_h = 0.01f;   // :88
+    c->pixel_stride = 3;                                                   // camera_tracking.cpp:162-163
+    c->stale_carry = 1;
+    c->with_color = 1;
+    c->slab_x0 = 0; c->slab_x1 = 0; c->halo = 0; c->device = 0;
+}
+
+const char* tsdf_strerror(int s) {
+    switch (s) {
+        case TSDF_OK: return "ok";
+        case TSDF_E_BADARG: return "bad argument";
+        case TSDF_E_NO_DEVICE: return "no usable HIP device";
+        case TSDF_E_HIP: return "HIP runtime error";
+        case TSDF_E_NO_INTRINSICS: return "camera intrinsics not set";
+        case TSDF_E_NO_FRAME: return "no frame set";
+        case TSDF_E_SINGULAR: return "normal equations singular or pose not finite";
+        case TSDF_E_NO_SAMPLES: return "no valid tracking samples";
+        case TSDF_E_HALO: return "slab halo too small";
+        case TSDF_E_COMM: return "all-reduce failure";
+        case TSDF_E_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char* tsdf_last_error(const tsdf_handle* h) {
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    return g_create_error.c_str();
+}
+
+int tsdf_slab_range(int32_t m, int32_t nranks, int32_t rank, int32_t* x0, int32_t* x1) {
+    if (m <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || !x0 || !x1) return TSDF_E_BADARG;
+    const int64_t q = m / nranks, r = m % nranks;      // the first r ranks get one extra layer
+    const int64_t lo = q * rank + (rank < r ? rank : r);
+    *x0 = (int32_t)lo;
+    *x1 = (int32_t)(lo + q + (rank < r ? 1 : 0));
+    return TSDF_OK;
+}
+
+int32_t tsdf_halo_for(const tsdf_config* c, float max_range) {
+    if (!c || c->m <= 0 || !(c->width > 0)) return -1;
+    const double per_m = (double)c->m / (double)c->width;
+    return (int32_t)std::ceil((double)c->w_h * (double)max_range * per_m) + (int32_t)std::ceil((double)c->v_h) + 2;
+}
+
+int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
+    if (!cfg || !out) return fail(nullptr, TSDF_E_BADARG, "tsdf_create: null argument");
+    *out = nullptr;
+    if (cfg->m < 2 || cfg->m > 4096 || !(cfg->width > 0) || !(cfg->height > 0) || !(cfg->depth > 0) ||
+        cfg->pixel_stride < 1 || cfg->gn_max_iter < 0 || cfg->halo < 0)
+        return fail(nullptr, TSDF_E_BADARG, "tsdf_create: bad config (m=%d stride=%d)", cfg->m, cfg->pixel_stride);
+    int32_t x0 = cfg->slab_x0, x1 = cfg->slab_x1;
+    if (x0 == 0 && x1 == 0) x1 = cfg->m;
+    if (x0 < 0 || x1 > cfg->m || x0 >= x1) return fail(nullptr, TSDF_E_BADARG, "tsdf_create: bad slab [%d,%d)", x0, x1);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, TSDF_E_NO_DEVICE, "no HIP device visible (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, TSDF_E_NO_DEVICE, "device ordinal %d out of range (%d devices)", cfg->device, ndev);
+
+    tsdf_handle* h = new (std::nothrow) tsdf_handle();
+    if (!h) return fail(nullptr, TSDF_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->cfg.slab_x0 = x0; h->cfg.slab_x1 = x1;
+    h->device = cfg->device;
+
+    Grid& g = h->grid;
+    g.m = cfg->m;
+    g.own_x0 = x0; g.own_x1 = x1;
+    g.xs = x0 - cfg->halo < 0 ? 0 : x0 - cfg->halo;
+    g.xe = x1 + cfg->halo > cfg->m ? cfg->m : x1 + cfg->halo;
+    g.cell_w = cfg->width / ((float)cfg->m);       // sdf.h:154-156
+    g.cell_h = cfg->height / ((float)cfg->m);
+    g.cell_d = cfg->depth / ((float)cfg->m);
+    g.m_div_w = cfg->m / cfg->width;               // sdf.cpp:19-21
+    g.m_div_h = cfg->m / cfg->height;
+    g.m_div_d = cfg->m / cfg->depth;
+    std::memcpy(g.origin, cfg->origin, sizeof g.origin);
+    g.delta = cfg->delta; g.epsilon = cfg->epsilon;
+
+    // camera_tracking.cpp:5-17
+    const double rot0[9] = {1, 0, 0, 0, 0, -1, 0, -1, 0};
+    const double trans0[3] = {0, 0, 1};
+    hm::set_pose(h->pose, rot0, trans0);
+    const float v_h2 = 2 * cfg->v_h;
+    h->v_h2_w = v_h2 / g.m_div_w;
+    h->v_h2_h = v_h2 / g.m_div_h;
+    h->v_h2_d = v_h2 / g.m_div_d;
+    h->wh2 = 2 * cfg->w_h;
+
+    auto bail = [&](int code) { std::string msg = h->err; tsdf_destroy(h); fail(nullptr, code, "%s", msg.c_str()); return code; };
+#define CREATE_TRY(expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e2__ = (expr);                                                                     \
+        if (e2__ != hipSuccess) {                                                                     \
+            fail(h, TSDF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e2__));                     \
+            return bail(e2__ == hipErrorOutOfMemory ? TSDF_E_NOMEM : TSDF_E_HIP);                     \
+        }                                                                                             \
+    } while (0)
+    CREATE_TRY(hipSetDevice(h->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
+    CREATE_TRY(hipMalloc((void**)&h->dw, (size_t)h->n_stored * sizeof(float2)));
+    if (cfg->with_color) CREATE_TRY(hipMalloc((void**)&h->crgb, (size_t)h->n_stored * sizeof(float4)));
+    CREATE_TRY(hipMalloc((void**)&h->counters, kNumCounters * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(h->counters, 0, kNumCounters * sizeof(unsigned long long), h->stream));
+    CREATE_TRY(hipHostMalloc((void**)&h->counters_host, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    CREATE_TRY(hipMalloc((void**)&h->red_dev, kRedWidth * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&h->red_host, kRedWidth * sizeof(double), hipHostMallocDefault));
+    CREATE_TRY(hipEventCreate(&h->ev_track.a));
+    CREATE_TRY(hipEventCreate(&h->ev_track.b));
+    CREATE_TRY(launch_fill(h->stream, g, h->dw, h->crgb, cfg->width + cfg->height + cfg->depth));   // sdf.cpp:29
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    *out = h;
+    return TSDF_OK;
+}
+
+void tsdf_destroy(tsdf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->comm.destroy();
+    free_frame(h);
+    if (h->pn) (void)hipFree(h->pn);
+    if (h->samples) (void)hipFree(h->samples);
+    if (h->partials) (void)hipFree(h->partials);
+    if (h->red_dev) (void)hipFree(h->red_dev);
+    if (h->red_host) (void)hipHostFree(h->red_host);
+    if (h->counters) (void)hipFree(h->counters);
+    if (h->counters_host) (void)hipHostFree(h->counters_host);
+    if (h->dw) (void)hipFree(h->dw);
+    if (h->crgb) (void)hipFree(h->crgb);
+    for (auto& ep : h->ev_pool) { if (ep.a) (void)hipEventDestroy(ep.a); if (ep.b) (void)hipEventDestroy(ep.b); }
+    if (h->ev_track.a) (void)hipEventDestroy(h->ev_track.a);
+    if (h->ev_track.b) (void)hipEventDestroy(h->ev_track.b);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int tsdf_get_config(const tsdf_handle* h, tsdf_config* cfg) {
+    if (!h || !cfg) return TSDF_E_BADARG;
+    *cfg = h->cfg;
+    return TSDF_OK;
+}
+
+int tsdf_reset(tsdf_handle* h) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    HIP_TRY(h, launch_fill(h->stream, h->grid, h->dw, h->crgb, h->cfg.width + h->cfg.height + h->cfg.depth));
+    const double rot0[9] = {1, 0, 0, 0, 0, -1, 0, -1, 0};
+    const double trans0[3] = {0, 0, 1};
+    hm::set_pose(h->pose, rot0, trans0);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TSDF_OK;
+}
+
+// ---- camera state ---------------------------------------------------------------------------------
+
+int tsdf_set_intrinsics(tsdf_handle* h, const double K[9]) {
+    if (!h || !K) return TSDF_E_BADARG;
+    std::memcpy(h->K, K, sizeof h->K);
+    h->have_K = true;
+    return TSDF_OK;
+}
+
+int tsdf_set_camera_transformation(tsdf_handle* h, const double rot[9], const double trans[3]) {
+    if (!h || !rot || !trans) return TSDF_E_BADARG;
+    hm::set_pose(h->pose, rot, trans);
+    return TSDF_OK;
+}
+
+int tsdf_get_pose(const tsdf_handle* h, double rot[9], double trans[3], double rot_inv[9], double rot_inv_trans[3]) {
+    if (!h) return TSDF_E_BADARG;
+    if (rot) std::memcpy(rot, h->pose.rot, sizeof h->pose.rot);
+    if (trans) std::memcpy(trans, h->pose.trans, sizeof h->pose.trans);
+    if (rot_inv) std::memcpy(rot_inv, h->pose.rot_inv, sizeof h->pose.rot_inv);
+    if (rot_inv_trans) std::memcpy(rot_inv_trans, h->pose.rot_inv_trans, sizeof h->pose.rot_inv_trans);
+    return TSDF_OK;
+}
+
+// ---- frames ------------------------------------------------------------------------------------------
+
+int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
+    if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame: bad argument") : TSDF_E_BADARG;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    // the pinned staging buffers may still feed the previous frame's async copies
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(h->pin_xyz, xyz, npix * 3 * sizeof(float));
+    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, h->pin_xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (nrm) {
+        std::memcpy(h->pin_nrm, nrm, npix * 3 * sizeof(float));
+        HIP_TRY(h, hipMemcpyAsync(h->in_nrm, h->pin_nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    if (rgb) {
+        std::memcpy(h->pin_rgb, rgb, npix * 3);
+        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->stream));
+    }
+    return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr);
+}
+
+int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
+    if (!h || !d_xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_device: bad argument") : TSDF_E_BADARG;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, false);
+    if (rc) return rc;
+    return run_pack(h, d_xyz, d_nrm, d_rgb);
+}
+
+// ---- hot path ----------------------------------------------------------------------------------------
+
+int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "camera matrix not received (reference: sdf.cpp:227-230 exits)");
+    if (!h->frame_has_nrm) return fail(h, TSDF_E_NO_FRAME, "tsdf_integrate needs normals in the current frame");
+    if (h->cfg.with_color && !h->frame_has_rgb)
+        return fail(h, TSDF_E_NO_FRAME, "with_color=1 needs rgb in the current frame");
+    IntegrateParams p;
+    p.g = h->grid;
+    std::memcpy(p.rot_inv, h->pose.rot_inv, sizeof p.rot_inv);
+    std::memcpy(p.rot_inv_trans, h->pose.rot_inv_trans, sizeof p.rot_inv_trans);
+    std::memcpy(p.K, h->K, sizeof p.K);
+    p.width = h->fw; p.height = h->fh;
+    p.with_color = h->cfg.with_color;
+    unsigned long long before[kNumCounters];
+    if (stats) {
+        HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof before, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(before, h->counters_host, sizeof before);
+    }
+    EventPair* ep;
+    rc = timed_begin(h, 0, &ep);
+    if (rc) return rc;
+    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters));
+    rc = timed_end(h, ep);
+    if (rc) return rc;
+    h->cnt.integrate_calls++;
+    h->cnt.n_voxels_swept += h->n_stored;
+    if (stats) {
+        HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof before, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        stats->n_updated = (int64_t)(h->counters_host[kCntUpdatedOwned] - before[kCntUpdatedOwned]);
+        stats->n_updated_halo = (int64_t)(h->counters_host[kCntUpdatedHalo] - before[kCntUpdatedHalo]);
+        stats->n_voxels = h->n_stored;
+    }
+    return TSDF_OK;
+}
+
+int tsdf_accumulate(tsdf_handle* h, double A[36], double b[6], tsdf_accum_stats* stats) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!A || !b) return fail(h, TSDF_E_BADARG, "tsdf_accumulate: null output");
+    rc = accumulate_pass(h, false);
+    if (rc) return rc;
+    unpack_normal_equations(h->red_host, A, b);
+    if (stats) {
+        stats->n_samples = (int64_t)h->red_host[33];
+        stats->n_nan = (int64_t)h->red_host[32];
+        stats->n_oog = (int64_t)h->red_host[31];
+        stats->n_in_grid_owned = (int64_t)h->red_host[30];
+        stats->n_ok = (int64_t)h->red_host[29];
+        stats->n_terms = (int64_t)h->red_host[27];
+    }
+    return TSDF_OK;
+}
+
+int tsdf_gn_update(tsdf_handle* h, const double A[36], const double b[6], double twist[6], int32_t* stop) {
+    if (!h || !A || !b) return TSDF_E_BADARG;
+    double tw[6];
+    bool st = false;
+    if (!hm::gn_step(h->pose, A, b, h->cfg.max_twist_diff, tw, &st))
+        return fail(h, TSDF_E_SINGULAR, "normal equations singular or pose not finite; pose left unchanged");
+    if (twist) std::memcpy(twist, tw, sizeof tw);
+    if (stop) *stop = st ? 1 : 0;
+    return TSDF_OK;
+}
+
+int tsdf_track(tsdf_handle* h, tsdf_track_stats* stats) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    bool stop = false;
+    int g = 0;
+    double A[36], b[6], twist[6] = {0, 0, 0, 0, 0, 0};
+    int64_t n_terms = 0;
+    h->cnt.track_calls++;
+    for (g = 0; g < h->cfg.gn_max_iter && !stop; ++g) {            // camera_tracking.cpp:79
+        rc = accumulate_pass(h, true);
+        if (rc) return rc;
+        n_terms = (int64_t)h->red_host[27];
+        if (n_terms == 0) return fail(h, TSDF_E_NO_SAMPLES, "no valid tracking sample (iteration %d); pose left unchanged", g);
+        unpack_normal_equations(h->red_host, A, b);
+        if (!hm::gn_step(h->pose, A, b, h->cfg.max_twist_diff, twist, &stop))
+            return fail(h, TSDF_E_SINGULAR, "normal equations singular at iteration %d; pose left unchanged", g);
+    }
+    if (stats) {
+        stats->iterations = g;
+        stats->stopped = stop ? 1 : 0;
+        stats->n_terms_last = n_terms;
+        std::memcpy(stats->last_twist, twist, sizeof twist);
+    }
+    return TSDF_OK;
+}
+
+int tsdf_sample(tsdf_handle* h, const double* vox, int32_t n, float* val, int32_t* ok) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!vox || !val || !ok || n < 0) return fail(h, TSDF_E_BADARG, "tsdf_sample: bad argument");
+    if (n == 0) return TSDF_OK;
+    double* dv = nullptr; float* dval = nullptr; int32_t* dok = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&dv, (size_t)n * 3 * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void**)&dval, (size_t)n * sizeof(float)));
+    HIP_TRY(h, hipMalloc((void**)&dok, (size_t)n * sizeof(int32_t)));
+    hipError_t e = hipMemcpyAsync(dv, vox, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_sample(h->stream, h->grid, h->dw, dv, n, dval, dok);
+    if (e == hipSuccess) e = hipMemcpyAsync(val, dval, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ok, dok, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(dv); (void)hipFree(dval); (void)hipFree(dok);
+    if (e != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_sample: %s", hipGetErrorString(e));
+    for (int32_t i = 0; i < n; ++i)
+        if (ok[i] < 0) return fail(h, TSDF_E_HALO, "tsdf_sample: point %d reads outside the stored layers", i);
+    return TSDF_OK;
+}
+
+// ---- volume I/O --------------------------------------------------------------------------------------
+
+namespace {
+
+// Copy `planes` float arrays of `n` voxels between host and the interleaved device layout, through a
+// bounded device scratch (chunked so a 2048^3 slab does not need a second copy of itself).
+int volume_io(tsdf_handle* h, bool download, bool color, int64_t first, int64_t n, float* const* host) {
+    const int planes = color ? 4 : 2;
+    const int64_t chunk = (int64_t)1 << 24;     // 16 Mi voxels per pass
+    float* scratch = nullptr;
+    const int64_t cap = n < chunk ? n : chunk;
+    HIP_TRY(h, hipMalloc((void**)&scratch, (size_t)cap * planes * sizeof(float)));
+    hipError_t e = hipSuccess;
+    for (int64_t off = 0; off < n && e == hipSuccess; off += chunk) {
+        const int64_t c = (n - off) < chunk ? (n - off) : chunk;
+        float* pl[4] = {scratch, scratch + cap, scratch + 2 * cap, scratch + 3 * cap};
+        if (download) {
+            if (color) e = launch_split4(h->stream, h->crgb + first + off, pl[0], pl[1], pl[2], pl[3], c);
+            else e = launch_split(h->stream, h->dw + first + off, pl[0], pl[1], c);
+            for (int q = 0; q < planes && e == hipSuccess; ++q)
+                e = hipMemcpyAsync(host[q] + off, pl[q], (size_t)c * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        } else {
+            for (int q = 0; q < planes && e == hipSuccess; ++q)
+                e = hipMemcpyAsync(pl[q], host[q] + off, (size_t)c * sizeof(float), hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) {
+                if (color) e = launch_merge4(h->stream, h->crgb + first + off, pl[0], pl[1], pl[2], pl[3], c);
+                else e = launch_merge(h->stream, h->dw + first + off, pl[0], pl[1], c);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(scratch);
+    if (e != hipSuccess) return fail(h, TSDF_E_HIP, "volume I/O: %s", hipGetErrorString(e));
+    return TSDF_OK;
+}
+
+}  // namespace
+
+int tsdf_download(tsdf_handle* h, float* D, float* W) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!D || !W) return fail(h, TSDF_E_BADARG, "tsdf_download: null output");
+    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
+    float* host[4] = {D, W, nullptr, nullptr};
+    return volume_io(h, true, false, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+}
+
+int tsdf_upload(tsdf_handle* h, const float* D, const float* W) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!D || !W) return fail(h, TSDF_E_BADARG, "tsdf_upload: null input");
+    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
+    float* host[4] = {const_cast<float*>(D), const_cast<float*>(W), nullptr, nullptr};
+    return volume_io(h, false, false, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+}
+
+int tsdf_upload_with_halo(tsdf_handle* h, const float* D, const float* W) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!D || !W) return fail(h, TSDF_E_BADARG, "tsdf_upload_with_halo: null input");
+    float* host[4] = {const_cast<float*>(D), const_cast<float*>(W), nullptr, nullptr};
+    return volume_io(h, false, false, 0, h->n_stored, host);
+}
+
+int tsdf_download_color(tsdf_handle* h, float* Color_W, float* R, float* G, float* B) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!h->crgb) return fail(h, TSDF_E_BADARG, "volume was created with with_color=0");
+    if (!Color_W || !R || !G || !B) return fail(h, TSDF_E_BADARG, "tsdf_download_color: null output");
+    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
+    float* host[4] = {Color_W, R, G, B};
+    return volume_io(h, true, true, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+}
+
+int tsdf_upload_color(tsdf_handle* h, const float* Color_W, const float* R, const float* G, const float* B) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!h->crgb) return fail(h, TSDF_E_BADARG, "volume was created with with_color=0");
+    if (!Color_W || !R || !G || !B) return fail(h, TSDF_E_BADARG, "tsdf_upload_color: null input");
+    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
+    float* host[4] = {const_cast<float*>(Color_W), const_cast<float*>(R), const_cast<float*>(G), const_cast<float*>(B)};
+    return volume_io(h, false, true, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------------------
+
+int tsdf_comm_unique_id(void* id128) {
+    if (!id128) return TSDF_E_BADARG;
+    std::string err;
+    if (!rccl::unique_id(id128, &err)) return fail(nullptr, TSDF_E_COMM, "ncclGetUniqueId: %s", err.c_str());
+    return TSDF_OK;
+}
+
+int tsdf_comm_init(tsdf_handle* h, int32_t nranks, int32_t rank, const void* id128) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!id128 || nranks <= 0 || rank < 0 || rank >= nranks) return fail(h, TSDF_E_BADARG, "tsdf_comm_init: bad argument");
+    std::string err;
+    if (!h->comm.init(nranks, rank, id128, &err)) return fail(h, TSDF_E_COMM, "ncclCommInitRank: %s", err.c_str());
+    return TSDF_OK;
+}
+
+int tsdf_set_allreduce_hook(tsdf_handle* h, tsdf_allreduce_fn fn, void* ctx) {
+    if (!h) return TSDF_E_BADARG;
+    h->hook = fn;
+    h->hook_ctx = ctx;
+    return TSDF_OK;
+}
+
+int tsdf_allreduce(tsdf_handle* h, double* buf, int32_t n) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!buf || n < 0 || n > kRedWidth) return fail(h, TSDF_E_BADARG, "tsdf_allreduce: n must be in [0,%d]", kRedWidth);
+    if (h->comm.active()) {
+        std::string err;
+        HIP_TRY(h, hipMemcpyAsync(h->red_dev, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (!h->comm.allreduce_sum_f64(h->red_dev, n, h->stream, &err)) return fail(h, TSDF_E_COMM, "RCCL all-reduce failed: %s", err.c_str());
+        HIP_TRY(h, hipMemcpyAsync(buf, h->red_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return TSDF_OK;
+    }
+    if (h->hook) {
+        if (h->hook(buf, n, h->hook_ctx) != 0) return fail(h, TSDF_E_COMM, "all-reduce hook reported failure");
+    }
+    return TSDF_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------
+
+int tsdf_set_timing(tsdf_handle* h, int32_t on) {
+    if (!h) return TSDF_E_BADARG;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if (!on) { rc = drain_events(h); if (rc) return rc; }
+    h->timing = on != 0;
+    return TSDF_OK;
+}
+
+int tsdf_read_timing(tsdf_handle* h, tsdf_timing* out, int32_t reset) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    rc = drain_events(h);
+    if (rc) return rc;
+    if (out) *out = h->tm;
+    if (reset) h->tm = tsdf_timing{};
+    return TSDF_OK;
+}
+
+int tsdf_read_counters(tsdf_handle* h, tsdf_counters* out, int32_t reset) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->cnt.n_updated = (int64_t)(h->counters_host[kCntUpdatedOwned] - h->cnt_base[kCntUpdatedOwned]);
+    h->cnt.n_updated_halo = (int64_t)(h->counters_host[kCntUpdatedHalo] - h->cnt_base[kCntUpdatedHalo]);
+    if (out) *out = h->cnt;
+    if (reset) {
+        for (int i = 0; i < kNumCounters; ++i) h->cnt_base[i] = h->counters_host[i];
+        h->cnt = tsdf_counters{};
+    }
+    return TSDF_OK;
+}
+
+int tsdf_synchronize(tsdf_handle* h) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TSDF_OK;
+}
+
+void* tsdf_stream(tsdf_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

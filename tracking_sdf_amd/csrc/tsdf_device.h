@@ -1,0 +1,77 @@
+// tsdf_device.h -- parameter blocks and launch entry points shared by the HIP kernels
+// (tsdf_kernels.hip) and the C-ABI host side (tsdf_api.cpp).  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace tsdf {
+
+// Width of one reduction row produced by the tracker kernels (doubles).
+//   [0..20]  upper triangle of sum J J^T (row-major: 00 01 .. 05 11 12 .. 55)
+//   [21..26] sum r J
+//   [27]     number of terms added (stale re-adds included)
+//   [28]     look-ups that left this rank's slab+halo (must be 0)
+//   [29]     owned samples with all 13 look-ups valid
+//   [30]     owned in-grid samples
+//   [31]     out-of-grid samples   [32] NaN samples   [33] sampled pixels
+constexpr int kRedWidth = 34;
+constexpr int kRedAllreduce = 30;   // the leading part that is summed over ranks
+constexpr int kTrackBlock = 256;    // threads per tracker workgroup (4 wavefronts)
+constexpr int kIntegrateBlock = 256;
+
+// Geometry of the stored part of the volume.  Device layout: one float2 {D,W} per voxel
+// (and one float4 {Color_W,R,G,B} when colour is kept), reference index order
+// idx = m*m*i + m*j + k restricted to i in [xs, xe)  (x-slab + halo), k fastest.
+struct Grid {
+    int32_t m;
+    int32_t xs, xe;          // stored x layers [xs, xe)
+    int32_t own_x0, own_x1;  // owned x layers (slab without halo)
+    float cell_w, cell_h, cell_d;     // extent / (float)m, float quotients (sdf.h:154-156)
+    float m_div_w, m_div_h, m_div_d;  // m / extent, float quotients (sdf.cpp:19-21)
+    double origin[3];
+    float delta, epsilon;
+};
+
+struct IntegrateParams {
+    Grid g;
+    double rot_inv[9];
+    double rot_inv_trans[3];
+    double K[9];
+    int32_t width, height;
+    int32_t with_color;
+};
+
+struct TrackParams {
+    Grid g;
+    double rot[9];
+    double trans[3];
+    double rpm[54];          // r1p r1m r2p r2m r3p r3m  (camera_tracking.cpp:92-145)
+    float v_h;
+    float vh2[3];            // 2 v_h / m_div_{w,h,d}   (camera_tracking.cpp:13-17)
+    float wh2;               // 2 * w_h as a float product (camera_tracking.cpp:331)
+    int32_t n_samples;
+    int32_t stale_carry;
+};
+
+// cumulative device counters (unsigned long long each)
+enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntSwept = 2, kNumCounters = 4 };
+
+hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0);
+hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
+                       int32_t width, int32_t height, int32_t stride,
+                       float4* pn, float4* samples, int32_t ncols, int32_t nrows);
+hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
+                            const float4* pn, unsigned long long* counters);
+// partials: nblocks x kRedWidth doubles; red_dev / red_host: kRedWidth doubles each (red_host may be null)
+hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
+                        double* partials, double* red_dev, double* red_host);
+int track_num_blocks(int32_t n_samples);
+hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const double* vox, int32_t n,
+                         float* val, int32_t* ok);
+hipError_t launch_split(hipStream_t s, const float2* dw, float* d, float* w, int64_t n);
+hipError_t launch_merge(hipStream_t s, float2* dw, const float* d, const float* w, int64_t n);
+hipError_t launch_split4(hipStream_t s, const float4* c, float* a, float* r, float* g, float* b, int64_t n);
+hipError_t launch_merge4(hipStream_t s, float4* c, const float* a, const float* r, const float* g, const float* b, int64_t n);
+
+}  // namespace tsdf
