@@ -162,6 +162,7 @@ int32_t tsdf_halo_for(const tsdf_config *cfg, float max_range);
  * (torch.distributed / MPI / a file), every rank calls tsdf_comm_init. */
 int tsdf_comm_unique_id(void *id128);
 int tsdf_comm_init(tsdf_handle *h, int32_t nranks, int32_t rank, const void *id128);
+int tsdf_comm_finalize(tsdf_handle *h);                          /* drop the RCCL communicator (hook, if any, takes over) */
 /* Alternative: let the host do the 28-double sum (e.g. torch.distributed); fn = NULL removes it. */
 int tsdf_set_allreduce_hook(tsdf_handle *h, tsdf_allreduce_fn fn, void *ctx);
 /* Sum-all-reduce n doubles through whichever of the two is configured (identity if neither). */

@@ -328,3 +328,44 @@ def test_download_upload_roundtrip_and_reset():
     go.reset()
     D, W = go.download()
     assert np.all(D == np.float32(15.5)) and np.all(W == 0)
+
+
+def test_rccl_single_rank_allreduce_and_hook():
+    """The in-library RCCL path (dlopen'ed librccl) with a 1-rank communicator, and the host hook."""
+    import ctypes
+    import tracking_sdf_amd as ts
+    go = ts.SDF(32)
+    buf = ctypes.create_string_buffer(128)
+    assert ts.lib().tsdf_comm_unique_id(buf) == 0
+    go.comm_init(1, 0, buf.raw)
+    v = np.arange(30, dtype=np.float64) * 0.25
+    assert np.array_equal(go.allreduce(v.copy()), v)
+    go.comm_finalize()
+    calls = []
+
+    def hook(arr):
+        calls.append(arr.size)
+        arr *= 2.0            # pretend a second rank holds the same partial sums
+    go.set_allreduce_hook(hook)
+    assert np.array_equal(go.allreduce(v.copy()), 2 * v)
+    assert calls == [30]
+    go.set_allreduce_hook(None)
+    assert np.array_equal(go.allreduce(v.copy()), v)
+
+
+def test_track_with_hook_doubles_normal_equations_consistently():
+    """A hook that doubles A and b (two identical ranks) must leave the solution, hence the pose, unchanged."""
+    m = 64
+    seq, fr, oo, ot, go, gt = _fused_pair(m, noise=True)
+    xyz = fr[3][0]
+    gt.set_camera_transformation(seq.R[2], seq.t[2])
+    st1 = gt.estimate_new_position(go, xyz)
+    rot1, trans1 = gt.rot.copy(), gt.trans.copy()
+
+    def hook(arr):
+        arr *= 2.0
+    go.set_allreduce_hook(hook)
+    gt.set_camera_transformation(seq.R[2], seq.t[2])
+    st2 = gt.estimate_new_position(go, xyz)
+    assert st2["iterations"] == st1["iterations"] and st2["n_terms_last"] == 2 * st1["n_terms_last"]
+    assert np.max(np.abs(gt.rot - rot1)) < 1e-12 and np.max(np.abs(gt.trans - trans1)) < 1e-12

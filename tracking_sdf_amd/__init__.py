@@ -83,7 +83,7 @@ ABI_SYMBOLS = (
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_set_frame_device", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset",
-    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_set_allreduce_hook",
+    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
 
@@ -142,6 +142,7 @@ def lib():
         "tsdf_halo_for": (C.c_int32, [C.POINTER(Config), C.c_float]),
         "tsdf_comm_unique_id": (C.c_int, [C.c_void_p]),
         "tsdf_comm_init": (C.c_int, [H, C.c_int32, C.c_int32, C.c_void_p]),
+        "tsdf_comm_finalize": (C.c_int, [H]),
         "tsdf_set_allreduce_hook": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
         "tsdf_allreduce": (C.c_int, [H, dp, C.c_int32]),
         "tsdf_set_timing": (C.c_int, [H, C.c_int32]),
@@ -338,6 +339,9 @@ class SDF:
     def comm_init(self, nranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(lib().tsdf_comm_init(self._h, nranks, rank, buf))
+
+    def comm_finalize(self):
+        self._check(lib().tsdf_comm_finalize(self._h))
 
     def set_allreduce_hook(self, fn):
         """fn(np.ndarray[float64]) sums the array over ranks in place."""

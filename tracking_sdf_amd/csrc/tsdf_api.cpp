@@ -724,6 +724,14 @@ int tsdf_comm_init(tsdf_handle* h, int32_t nranks, int32_t rank, const void* id1
     return TSDF_OK;
 }
 
+int tsdf_comm_finalize(tsdf_handle* h) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->comm.destroy();
+    return TSDF_OK;
+}
+
 int tsdf_set_allreduce_hook(tsdf_handle* h, tsdf_allreduce_fn fn, void* ctx) {
     if (!h) return TSDF_E_BADARG;
     h->hook = fn;
