@@ -62,11 +62,27 @@ def horn_rmse(est, gt):
     return float(np.sqrt(np.mean(np.sum((al - gt) ** 2, axis=1))))
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, seq, frames):
     """The reference's CPU path (the oracle restatement: same loop structure, 24 B/voxel
     global_coords table, AoS clouds, OpenMP) timed on this box's host cores on a bounded sample."""
     import oracle as orc
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = max(1, min(args.cpu_baseline_frames, len(frames) - 1))
     oo = orc.SDF(args.m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025, with_global_coords=True)
     ot = orc.CameraTracking(oo)

@@ -369,3 +369,40 @@ def test_track_with_hook_doubles_normal_equations_consistently():
     st2 = gt.estimate_new_position(go, xyz)
     assert st2["iterations"] == st1["iterations"] and st2["n_terms_last"] == 2 * st1["n_terms_last"]
     assert np.max(np.abs(gt.rot - rot1)) < 1e-12 and np.max(np.abs(gt.trans - trans1)) < 1e-12
+
+
+@pytest.mark.parametrize("roll_deg", [90.0, 35.0])
+def test_integrate_rolled_camera_uses_other_record_layout(roll_deg):
+    """A camera rolled about its optical axis maps voxel k-rows to image ROWS: the packed pixel records
+    switch to row-major order.  Results must not depend on the layout."""
+    m = 64
+    seq, fr = frames(1)
+    a = np.deg2rad(roll_deg)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    R = seq.R[0] @ Rz
+    xyz, nrm, rgb = synth.render_frame(R, seq.t[0], seq.K, W_, H_, noise=True, holes=0.02,
+                                       rng=np.random.default_rng(5))
+    oo, ot = make_oracle(m, seq.K)
+    go, gt = make_gpu(m, seq.K)
+    ot.set_camera_transformation(R, seq.t[0])
+    gt.set_camera_transformation(R, seq.t[0])
+    n_or = oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+    st = go.update(gt, xyz, nrm, rgb)
+    assert st["n_updated"] == n_or and n_or > 1000
+    assert_volume_equal(go, oo, m)
+
+
+def test_integrate_general_intrinsics_disable_row_clip():
+    """A K whose last row is not (0,0,1) turns the per-row frustum clip off; results still match."""
+    m = 32
+    seq, fr = frames(1)
+    K = seq.K.copy()
+    K[2] = [1e-4, -2e-4, 1.0]
+    K[0, 1] = 0.3
+    oo, ot = make_oracle(m, K)
+    go, gt = make_gpu(m, K)
+    xyz, nrm, rgb = fr[0]
+    n_or = oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+    st = go.update(gt, xyz, nrm, rgb)
+    assert st["n_updated"] == n_or
+    assert_volume_equal(go, oo, m)

@@ -49,6 +49,7 @@ struct tsdf_handle {
 
     // frame
     int32_t fw = 0, fh = 0, ncols = 0, nrows = 0, n_samples = 0;
+    int32_t pix_su = 1, pix_sv = 0;   // layout of the packed pixel records of the current frame
     bool have_frame = false, frame_has_nrm = false, frame_has_rgb = false;
     float* in_xyz = nullptr; float* in_nrm = nullptr; uint8_t* in_rgb = nullptr;   // device staging (owned)
     float* pin_xyz = nullptr; float* pin_nrm = nullptr; uint8_t* pin_rgb = nullptr;  // pinned host staging
@@ -199,12 +200,25 @@ int timed_end(tsdf_handle* h, EventPair* ep) {
     return TSDF_OK;
 }
 
+// Record layout for this frame: along one voxel k-row the projection moves by
+// d(u,v)/dk ~ (K row 0 . c, K row 1 . c) with c = third column of rot_inv (evaluated on the optical
+// axis).  If it moves mostly down the image, store the records column-major so that the gather of 64
+// consecutive k reads neighbouring records; otherwise row-major.  Results do not depend on it.
+void choose_pixel_layout(tsdf_handle* h) {
+    const double* Ri = h->pose.rot_inv;
+    const double du = h->have_K ? h->K[0] * Ri[2] + h->K[1] * Ri[5] : Ri[2];
+    const double dv = h->have_K ? h->K[3] * Ri[2] + h->K[4] * Ri[5] : Ri[5];
+    if (std::fabs(dv) >= std::fabs(du)) { h->pix_su = h->fh; h->pix_sv = 1; }
+    else { h->pix_su = 1; h->pix_sv = h->fw; }
+}
+
 int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb) {
+    choose_pixel_layout(h);
     EventPair* ep;
     int rc = timed_begin(h, 1, &ep);
     if (rc) return rc;
-    HIP_TRY(h, launch_pack(h->stream, xyz, nrm, rgb, h->fw, h->fh, h->cfg.pixel_stride, h->pn, h->samples,
-                           h->ncols, h->nrows));
+    HIP_TRY(h, launch_pack(h->stream, xyz, nrm, rgb, h->fw, h->fh, h->cfg.pixel_stride, h->pix_su, h->pix_sv,
+                           h->pn, h->samples, h->ncols, h->nrows));
     rc = timed_end(h, ep);
     if (rc) return rc;
     h->have_frame = true;
@@ -521,6 +535,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     std::memcpy(p.rot_inv_trans, h->pose.rot_inv_trans, sizeof p.rot_inv_trans);
     std::memcpy(p.K, h->K, sizeof p.K);
     p.width = h->fw; p.height = h->fh;
+    p.pix_su = h->pix_su; p.pix_sv = h->pix_sv;
     p.with_color = h->cfg.with_color;
     unsigned long long before[kNumCounters];
     if (stats) {

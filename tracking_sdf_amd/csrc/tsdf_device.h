@@ -39,6 +39,7 @@ struct IntegrateParams {
     double rot_inv_trans[3];
     double K[9];
     int32_t width, height;
+    int32_t pix_su, pix_sv;  // record index of pixel (col,row) = col*pix_su + row*pix_sv
     int32_t with_color;
 };
 
@@ -59,7 +60,7 @@ enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntSwept = 2, kNumCou
 
 hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0);
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
-                       int32_t width, int32_t height, int32_t stride,
+                       int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
                        float4* pn, float4* samples, int32_t ncols, int32_t nrows);
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters);

@@ -58,12 +58,16 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 
 // ------------------------------------------------------------------------------------------------
 // frame packing.  Pixel record = 2 x float4: {Px,Py,Pz, rgb bits} {Nx,Ny,Nz, 0}.  One 32-byte
-// sector per projected voxel instead of three scattered plane reads.  The tracker's sample list is
+// sector per projected voxel instead of three scattered plane reads.  Records are stored row-major
+// or column-major (pix_su / pix_sv), whichever makes the pixels hit by 64 consecutive k of one voxel
+// row neighbours in memory: a k-row projects to a near-vertical image line for an upright camera,
+// and with row-major records every lane of the gather then pulls its own 128-byte line through L2
+// (measured: 0.6 ms of L2->L1 line traffic per 512^3 frame, the v1 bottleneck).  The tracker's sample list is
 // written in the reference's visiting order: columns outer, rows inner, both with `stride`.
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz, const float* __restrict__ nrm,
                                                     const uint8_t* __restrict__ rgb, int width, int height,
-                                                    int stride, float4* __restrict__ pn,
+                                                    int stride, int pix_su, int pix_sv, float4* __restrict__ pn,
                                                     float4* __restrict__ samples, int ncols, int nrows) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= width * height) return;
@@ -73,9 +77,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
     if (nrm) { nx = nrm[3 * pix + 0]; ny = nrm[3 * pix + 1]; nz = nrm[3 * pix + 2]; }
     unsigned c = 0;
     if (rgb) c = (unsigned)rgb[3 * pix + 0] | ((unsigned)rgb[3 * pix + 1] << 8) | ((unsigned)rgb[3 * pix + 2] << 16);
-    pn[2 * pix + 0] = make_float4(px, py, pz, __uint_as_float(c));
-    pn[2 * pix + 1] = make_float4(nx, ny, nz, 0.0f);
     const int col = pix % width, row = pix / width;
+    const long long rec = (long long)col * pix_su + (long long)row * pix_sv;   // row- or column-major records
+    pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
+    pn[2 * rec + 1] = make_float4(nx, ny, nz, 0.0f);
     if (col % stride == 0 && row % stride == 0) {
         const int ci = col / stride, rj = row / stride;
         if (ci < ncols && rj < nrows) samples[ci * nrows + rj] = make_float4(px, py, pz, 0.0f);
@@ -83,76 +88,132 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
 }
 
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
-                       int32_t width, int32_t height, int32_t stride,
+                       int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
                        float4* pn, float4* samples, int32_t ncols, int32_t nrows) {
     const int n = width * height;
-    pack_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(xyz, nrm, rgb, width, height, stride, pn, samples,
-                                                              ncols, nrows);
+    pack_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(xyz, nrm, rgb, width, height, stride, pix_su, pix_sv, pn,
+                                                              samples, ncols, nrows);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // TSDF integration.
 //
-// Work decomposition: a tile = RPB whole k-rows (fixed i, RPB consecutive j) so that one wavefront
-// covers 64 consecutive k of one row = one 512-byte contiguous {D,W} segment: perfectly coalesced
-// RMW.  Tiles are dealt so that each XCD (workgroups b and b+8 share one, MI355X_MICROARCH.md) sweeps
-// its own contiguous eighth of the slab: the workgroups of one XCD then project into one narrow
-// band of the image, which stays in that XCD's 4 MiB L2.
-// Voxels that fail a test (behind camera / outside image / NaN pixel / d > delta) touch no volume
-// memory at all: algorithmic traffic is 16 B (48 B with colour) per *updated* voxel.
+// The reference visits all m^3 voxels and rejects most of them (behind the camera / outside the
+// image / NaN pixel / d > delta).  Rejected voxels cost no HBM traffic, so a kernel that evaluates
+// the full f64 projection for every voxel is ALU-bound on the rejects (round-1 v1: 0.61 ms at 512^3
+// for 9 M updated voxels).  v2 culls per k-ROW first:
+//
+//   * a row (fixed i,j; k = 0..m-1) is a straight segment in camera space, pc(k) = Q0 + k Q1, and
+//     each frustum test (z >= 0, u > -1, u < W, v > -1, v < H) is affine in k, so the set of k that
+//     can pass is one interval [klo, khi], obtained from five divisions per ROW instead of two per
+//     VOXEL.  The interval is widened by one voxel each side and every voxel inside it still runs
+//     the reference's exact test, so the cull never changes a result;
+//   * one workgroup = 64 consecutive rows (wave w takes rows 4r+w: 16 rows per wavefront, lanes
+//     0..15 do the row clips); the wave then walks only the 64-voxel chunks that intersect
+//     [klo, khi]: 64 lanes = 64 consecutive k = one 512-byte {D,W} segment, perfectly coalesced;
+//   * one workgroup per tile, not persistent: tiles differ by 50x in work, the hardware dispatcher
+//     is the load balancer.
+//
+// Algorithmic traffic: 16 B (48 B with colour) per *updated* voxel + the 32-byte pixel records.
+
+constexpr int kRowsPerTile = 64;
+constexpr int kRowsPerWave = kRowsPerTile / (kIntegrateBlock / 64);   // 16
 
 struct IntegrateTiling {
-    int rpb;             // rows per tile (a divisor of m)
-    int iters;           // per-thread iterations = ceil(rpb*m/256)
-    int tiles_per_layer; // m / rpb
-    long long n_tiles;   // (xe-xs) * tiles_per_layer
+    long long n_rows;    // (xe-xs) * m
     int log2m;           // >= 0 when m is a power of two
+    int clip;            // 1 = K has the usual last row (0,0,k22>0): row clipping is valid
 };
+
+// interval of k (real-valued) on which a + k*b > 0, intersected into [lo, hi]
+__device__ __forceinline__ void clip_affine(double a, double b, double& lo, double& hi) {
+    if (b > 0.0) { const double t = -a / b; if (t > lo) lo = t; }
+    else if (b < 0.0) { const double t = -a / b; if (t < hi) hi = t; }
+    else if (a < -1.0e-9) { lo = 1.0; hi = 0.0; }   // row parallel to this plane and clearly outside it
+    // (b == 0 and a within rounding of 0: leave it to the exact per-voxel test)
+}
 
 template <bool COLOR>
 __global__ __launch_bounds__(kIntegrateBlock) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, float2* __restrict__ dw, float4* __restrict__ crgb,
     const float4* __restrict__ pn, unsigned long long* __restrict__ counters) {
     const int m = p.g.m;
-    const int tid = threadIdx.x;
-    // XCD-aware tile ownership
-    const int xcd = blockIdx.x & 7;
-    const int slot = blockIdx.x >> 3;
-    const int slots = gridDim.x >> 3;
-    const long long per_xcd = (tl.n_tiles + 7) / 8;
-    const long long t_lo = per_xcd * xcd;
-    long long t_hi = t_lo + per_xcd;
-    if (t_hi > tl.n_tiles) t_hi = tl.n_tiles;
-
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double ox = p.g.origin[0], oy = p.g.origin[1], oz = p.g.origin[2];
     const double cw = (double)p.g.cell_w, ch = (double)p.g.cell_h, cd = (double)p.g.cell_d;
     const float delta = p.g.delta, eps = p.g.epsilon;
-    const int tile_vox = tl.rpb * m;
+    const long long row0 = (long long)blockIdx.x * kRowsPerTile;
     unsigned n_own = 0, n_halo = 0;
 
-    for (long long t = t_lo + slot; t < t_hi; t += slots) {
-        const int il = (int)(t / tl.tiles_per_layer);                 // layer inside the stored slab
-        const int j0 = (int)(t - (long long)il * tl.tiles_per_layer) * tl.rpb;
+    // ---- per-row clip: lane r (< 16) owns row row0 + 4 r + wv
+    int klo_v = 1, khi_v = 0;
+    {
+        const long long row = row0 + 4 * lane + wv;
+        if (lane < kRowsPerWave && row < tl.n_rows) {
+            int il, j;
+            if (tl.log2m >= 0) { il = (int)(row >> tl.log2m); j = (int)(row & (m - 1)); }
+            else { il = (int)(row / m); j = (int)(row - (long long)il * m); }
+            klo_v = 0; khi_v = m - 1;
+            if (tl.clip) {
+                const double gx = cw * ((double)(il + p.g.xs) + 0.5) + ox;
+                const double gy = ch * ((double)j + 0.5) + oy;
+                const double gz0 = cd * 0.5 + oz;               // k = 0
+                // pc(k) = Q0 + k Q1
+                double Q0[3], Q1[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    Q0[a] = (p.rot_inv[3 * a] * gx + p.rot_inv[3 * a + 1] * gy) + p.rot_inv[3 * a + 2] * gz0 + p.rot_inv_trans[a];
+                    Q1[a] = p.rot_inv[3 * a + 2] * cd;
+                }
+                // ij = K pc, with K's last row (0,0,k22): ij2 = k22 * pcz has the sign of pcz
+                const double a0 = row3(&p.K[0], Q0[0], Q0[1], Q0[2]), b0 = row3(&p.K[0], Q1[0], Q1[1], Q1[2]);
+                const double a1 = row3(&p.K[3], Q0[0], Q0[1], Q0[2]), b1 = row3(&p.K[3], Q1[0], Q1[1], Q1[2]);
+                const double a2 = p.K[8] * Q0[2], b2 = p.K[8] * Q1[2];
+                double lo = -1.0, hi = (double)m;
+                clip_affine(a2, b2, lo, hi);                                   // pcz > 0 (>= handled by the margin)
+                clip_affine(a0 + a2, b0 + b2, lo, hi);                         // u > -1
+                clip_affine((double)p.width * a2 - a0, (double)p.width * b2 - b0, lo, hi);     // u < W
+                clip_affine(a1 + a2, b1 + b2, lo, hi);                         // v > -1
+                clip_affine((double)p.height * a2 - a1, (double)p.height * b2 - b1, lo, hi);   // v < H
+                if (!(lo <= hi + 1.0e-6)) { klo_v = 1; khi_v = 0; }            // empty (or NaN): nothing can pass
+                else {
+                    // widen by one voxel per side; the exact test below decides inside
+                    const double l2 = floor(lo) - 1.0, h2 = ceil(hi) + 1.0;
+                    klo_v = l2 < 0.0 ? 0 : (l2 > (double)(m - 1) ? m : (int)l2);
+                    khi_v = h2 > (double)(m - 1) ? m - 1 : (h2 < 0.0 ? -1 : (int)h2);
+                }
+            }
+        }
+    }
+
+    // ---- walk the rows of this wave
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int klo = __builtin_amdgcn_readlane(klo_v, r);
+        const int khi = __builtin_amdgcn_readlane(khi_v, r);
+        if (klo > khi) continue;                                   // wave-uniform
+        const long long row = row0 + 4 * r + wv;
+        int il, j;
+        if (tl.log2m >= 0) { il = (int)(row >> tl.log2m); j = (int)(row & (m - 1)); }
+        else { il = (int)(row / m); j = (int)(row - (long long)il * m); }
         const int i = il + p.g.xs;
         const bool owned = (i >= p.g.own_x0 && i < p.g.own_x1);
         // get_global_coordinates, sdf.h:153-157: (extent/(float)m) * (i + 0.5) + origin
         const double gx = cw * ((double)i + 0.5) + ox;
-        const long long layer_base = (long long)il * m * m;
+        const double gy = ch * ((double)j + 0.5) + oy;
+        // first two terms of rot_inv * g (Eigen order: (r0*gx + r1*gy) + r2*gz), shared by the row
+        const double sx = p.rot_inv[0] * gx + p.rot_inv[1] * gy;
+        const double sy = p.rot_inv[3] * gx + p.rot_inv[4] * gy;
+        const double sz = p.rot_inv[6] * gx + p.rot_inv[7] * gy;
+        const long long row_base = row * m;
 
-        for (int v = 0; v < tl.iters; ++v) {
-            const int lin = v * kIntegrateBlock + tid;
-            if (lin >= tile_vox) break;
-            int r, k;
-            if (tl.log2m >= 0) { r = lin >> tl.log2m; k = lin & (m - 1); }
-            else { r = lin / m; k = lin - r * m; }
-            const int j = j0 + r;
-            const double gy = ch * ((double)j + 0.5) + oy;
+        for (int k = (klo & ~63) + lane; k <= khi; k += 64) {
+            if (k < klo) continue;
             const double gz = cd * ((double)k + 0.5) + oz;
             // project_world_to_camera, camera_tracking.cpp:51-54
-            const double pcx = row3(&p.rot_inv[0], gx, gy, gz) + p.rot_inv_trans[0];
-            const double pcy = row3(&p.rot_inv[3], gx, gy, gz) + p.rot_inv_trans[1];
-            const double pcz = row3(&p.rot_inv[6], gx, gy, gz) + p.rot_inv_trans[2];
+            const double pcx = (sx + p.rot_inv[2] * gz) + p.rot_inv_trans[0];
+            const double pcy = (sy + p.rot_inv[5] * gz) + p.rot_inv_trans[1];
+            const double pcz = (sz + p.rot_inv[8] * gz) + p.rot_inv_trans[2];
             if (pcz < 0) continue;                                              // sdf.cpp:247-249
             // project_camera_to_image_plane, camera_tracking.cpp:40-47
             const double ij0 = row3(&p.K[0], pcx, pcy, pcz);
@@ -164,7 +225,7 @@ __global__ __launch_bounds__(kIntegrateBlock) void integrate_kernel(
             // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
             if (!(u > -1.0 && u < (double)p.width && w > -1.0 && w < (double)p.height)) continue;
             const int iu = (int)u, iw = (int)w;
-            const long long pix = (long long)iw * p.width + iu;
+            const long long pix = (long long)iu * p.pix_su + (long long)iw * p.pix_sv;
             const float4 P = pn[2 * pix + 0];
             const float4 N = pn[2 * pix + 1];
             if (is_nan(P.x) || is_nan(P.y) || is_nan(N.x) || is_nan(N.y) || is_nan(N.z)) continue;  // :260
@@ -181,7 +242,7 @@ __global__ __launch_bounds__(kIntegrateBlock) void integrate_kernel(
             if (d_new > delta) continue;                                        // sdf.cpp:280-283
             if (d_new < -delta) d_new = -delta;                                 // sdf.cpp:285-287
 
-            const long long idx = layer_base + (long long)j * m + k;
+            const long long idx = row_base + k;
             const float2 old = dw[idx];                                         // {D, W}
             const float w_sum = old.y + w_new;                                  // sdf.cpp:289-292
             const float d_out = (old.y * old.x + w_new * d_new) / w_sum;
@@ -202,17 +263,17 @@ __global__ __launch_bounds__(kIntegrateBlock) void integrate_kernel(
         }
     }
 
-    // one atomic per counter per workgroup (<= 2048 workgroups): wave shuffle, then LDS across the 4 waves
+    // one atomic per counter per workgroup that updated anything: wave shuffle, then LDS across the 4 waves
     __shared__ unsigned s_cnt[2][kIntegrateBlock / 64];
     for (int off = 32; off > 0; off >>= 1) {
         n_own += __shfl_xor(n_own, off);
         n_halo += __shfl_xor(n_halo, off);
     }
-    if ((tid & 63) == 0) { s_cnt[0][tid >> 6] = n_own; s_cnt[1][tid >> 6] = n_halo; }
+    if (lane == 0) { s_cnt[0][wv] = n_own; s_cnt[1][wv] = n_halo; }
     __syncthreads();
     if (tid == 0) {
         unsigned a = 0, b = 0;
-        for (int wv = 0; wv < kIntegrateBlock / 64; ++wv) { a += s_cnt[0][wv]; b += s_cnt[1][wv]; }
+        for (int q = 0; q < kIntegrateBlock / 64; ++q) { a += s_cnt[0][q]; b += s_cnt[1][q]; }
         if (a) atomicAdd(&counters[kCntUpdatedOwned], (unsigned long long)a);
         if (b) atomicAdd(&counters[kCntUpdatedHalo], (unsigned long long)b);
     }
@@ -224,19 +285,11 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
     IntegrateTiling tl;
-    int target = 1024 / m; if (target < 1) target = 1;
-    int rpb = 1;
-    for (int d = 1; d <= target; ++d) if (m % d == 0) rpb = d;
-    tl.rpb = rpb;
-    tl.iters = (rpb * m + kIntegrateBlock - 1) / kIntegrateBlock;
-    tl.tiles_per_layer = m / rpb;
-    tl.n_tiles = (long long)nx * tl.tiles_per_layer;
+    tl.n_rows = (long long)nx * m;
     tl.log2m = -1;
     for (int b = 0; b < 31; ++b) if ((1 << b) == m) tl.log2m = b;
-    long long blocks = tl.n_tiles;
-    const long long cap = 256 * 8;                       // 256 CUs x 8 resident workgroups
-    if (blocks > cap) blocks = cap;
-    blocks = (blocks + 7) / 8 * 8;                       // whole XCD groups
+    tl.clip = (p.K[6] == 0.0 && p.K[7] == 0.0 && p.K[8] > 0.0) ? 1 : 0;
+    const long long blocks = (tl.n_rows + kRowsPerTile - 1) / kRowsPerTile;
     if (p.with_color)
         integrate_kernel<true><<<dim3((unsigned)blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, dw, crgb, pn, counters);
     else
