@@ -9,7 +9,8 @@ LIB     := $(LIBDIR)/libtsdf_hip.so
 
 # -ffp-contract=off and no fast-math are REQUIRED for parity: every multiply-add of the reference is
 # two roundings (its g++ build sets no -O/-march flags, src/CMakeLists.txt:97-98).
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+HIPEXTRA ?=
+HIPFLAGS := $(HIPEXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
             -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wextra -Wno-unused-parameter
 SRCS := $(CSRC)/tsdf_kernels.hip $(CSRC)/tsdf_api.cpp $(CSRC)/rccl_dyn.cpp
 HDRS := $(CSRC)/tsdf_device.h $(CSRC)/host_math.hpp $(CSRC)/rccl_dyn.hpp $(ROOT)include/tsdf.h

@@ -46,6 +46,10 @@ struct tsdf_handle {
     int64_t n_stored = 0;          // voxels in [xs, xe)
     unsigned long long* counters = nullptr;     // device, kNumCounters
     unsigned long long* counters_host = nullptr;  // pinned
+    unsigned* worklist = nullptr;  // integrate work items (row << 6 | chunk)
+    unsigned* work_count = nullptr;
+    int integrate_blocks = 0;      // persistent grid of integrate_kernel
+    double* rowbase = nullptr;     // per-row share of rot_inv * g (3 doubles per row)
 
     // frame
     int32_t fw = 0, fh = 0, ncols = 0, nrows = 0, n_samples = 0;
@@ -413,6 +417,16 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMalloc((void**)&h->counters, kNumCounters * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(h->counters, 0, kNumCounters * sizeof(unsigned long long), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->counters_host, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    CREATE_TRY(hipMalloc((void**)&h->worklist, integrate_worklist_entries(g) * sizeof(unsigned)));
+    CREATE_TRY(hipMalloc((void**)&h->work_count, sizeof(unsigned)));
+    CREATE_TRY(hipMalloc((void**)&h->rowbase, integrate_rowbase_entries(g) * sizeof(double)));
+    {
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
+        const char* env = std::getenv("TSDF_INTEGRATE_BLOCKS_PER_CU");
+        const int per_cu = env ? std::atoi(env) : integrate_blocks_per_cu();
+        h->integrate_blocks = (prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4) + 7) / 8 * 8;   // whole XCD groups
+    }
     CREATE_TRY(hipMalloc((void**)&h->red_dev, kRedWidth * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->red_host, kRedWidth * sizeof(double), hipHostMallocDefault));
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
@@ -436,6 +450,9 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
     if (h->counters) (void)hipFree(h->counters);
+    if (h->worklist) (void)hipFree(h->worklist);
+    if (h->work_count) (void)hipFree(h->work_count);
+    if (h->rowbase) (void)hipFree(h->rowbase);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->dw) (void)hipFree(h->dw);
     if (h->crgb) (void)hipFree(h->crgb);
@@ -537,6 +554,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     p.width = h->fw; p.height = h->fh;
     p.pix_su = h->pix_su; p.pix_sv = h->pix_sv;
     p.with_color = h->cfg.with_color;
+    { const char* dbg = std::getenv("TSDF_DEBUG_INTEGRATE"); p.debug = dbg ? std::atoi(dbg) : 0; }
     unsigned long long before[kNumCounters];
     if (stats) {
         HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof before, hipMemcpyDeviceToHost, h->stream));
@@ -546,7 +564,8 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     EventPair* ep;
     rc = timed_begin(h, 0, &ep);
     if (rc) return rc;
-    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters));
+    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
+                                h->rowbase, h->integrate_blocks));
     rc = timed_end(h, ep);
     if (rc) return rc;
     h->cnt.integrate_calls++;

@@ -41,6 +41,7 @@ struct IntegrateParams {
     int32_t width, height;
     int32_t pix_su, pix_sv;  // record index of pixel (col,row) = col*pix_su + row*pix_sv
     int32_t with_color;
+    int32_t debug;           // 0 in production; bit 0 / bit 1 = timing experiments (see integrate_kernel)
 };
 
 struct TrackParams {
@@ -62,8 +63,14 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
                        int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
                        float4* pn, float4* samples, int32_t ncols, int32_t nrows);
+// worklist: integrate_worklist_entries(g) unsigned; work_count: 1 unsigned; rowbase:
+// integrate_rowbase_entries(g) doubles; n_blocks: persistent grid size (CUs x integrate_blocks_per_cu()).
+size_t integrate_worklist_entries(const Grid& g);
+size_t integrate_rowbase_entries(const Grid& g);
+int integrate_blocks_per_cu();
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
-                            const float4* pn, unsigned long long* counters);
+                            const float4* pn, unsigned long long* counters,
+                            unsigned* worklist, unsigned* work_count, double* rowbase, int n_blocks);
 // partials: nblocks x kRedWidth doubles; red_dev / red_host: kRedWidth doubles each (red_host may be null)
 hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                         double* partials, double* red_dev, double* red_host);

@@ -35,6 +35,13 @@ __device__ __forceinline__ double row3(const double* M, double x, double y, doub
 
 __device__ __forceinline__ bool is_nan(float f) { return f != f; }
 
+// sdf.cpp:294  cosine = fabs(cam_vect.dot(n)) / n.norm(), cam_vect = (0,0,1), in the reference's f64
+// evaluation order (Eigen redux: a0*b0 + (a1*b1 + a2*b2)).
+__device__ __forceinline__ double pixel_cosine(float nx, float ny, float nz) {
+    const double x = (double)nx, y = (double)ny, z = (double)nz;
+    return fabs(0.0 * x + (0.0 * y + 1.0 * z)) / sqrt(x * x + (y * y + z * z));
+}
+
 // ------------------------------------------------------------------------------------------------
 // volume fill: D = width+height+depth, W = 0, Color_W = 0, R = G = B = 0.4f   (sdf.cpp:28-34)
 
@@ -80,7 +87,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
     const int col = pix % width, row = pix / width;
     const long long rec = (long long)col * pix_su + (long long)row * pix_sv;   // row- or column-major records
     pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
-    pn[2 * rec + 1] = make_float4(nx, ny, nz, 0.0f);
+    // sdf.cpp:294: cosine = |cam_vect . n| / |n| depends on the pixel only.  Its f32 rounding rides in the
+    // record: for the common weight w_new == 1 the colour weight (float)(w_new * cosine) is exactly that.
+    pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)pixel_cosine(nx, ny, nz));
     if (col % stride == 0 && row % stride == 0) {
         const int ci = col / stride, rj = row / stride;
         if (ci < ncols && rj < nrows) samples[ci * nrows + rj] = make_float4(px, py, pz, 0.0f);
@@ -97,33 +106,40 @@ hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// TSDF integration.
+// TSDF integration = SDF::update (reference src/sdf.cpp:224-315), in two launches.
 //
 // The reference visits all m^3 voxels and rejects most of them (behind the camera / outside the
-// image / NaN pixel / d > delta).  Rejected voxels cost no HBM traffic, so a kernel that evaluates
-// the full f64 projection for every voxel is ALU-bound on the rejects (round-1 v1: 0.61 ms at 512^3
-// for 9 M updated voxels).  v2 culls per k-ROW first:
+// image / NaN pixel / d > delta); rejected voxels cost no HBM traffic.  Measured on MI355X (round 1):
+// a kernel that walks every voxel is neither ALU- nor HBM-bound but LATENCY-bound -- VALU busy 16 %,
+// waves parked 65 % of their life, ~1 resident wave per SIMD on average -- because the few wavefronts
+// that own in-frustum voxels run long serial chains (pixel gather -> {D,W} read -> write) while the
+// rest of the chip has nothing to do.  So the work is first compacted, then spread evenly:
 //
-//   * a row (fixed i,j; k = 0..m-1) is a straight segment in camera space, pc(k) = Q0 + k Q1, and
-//     each frustum test (z >= 0, u > -1, u < W, v > -1, v < H) is affine in k, so the set of k that
-//     can pass is one interval [klo, khi], obtained from five divisions per ROW instead of two per
-//     VOXEL.  The interval is widened by one voxel each side and every voxel inside it still runs
-//     the reference's exact test, so the cull never changes a result;
-//   * one workgroup = 64 consecutive rows (wave w takes rows 4r+w: 16 rows per wavefront, lanes
-//     0..15 do the row clips); the wave then walks only the 64-voxel chunks that intersect
-//     [klo, khi]: 64 lanes = 64 consecutive k = one 512-byte {D,W} segment, perfectly coalesced;
-//   * one workgroup per tile, not persistent: tiles differ by 50x in work, the hardware dispatcher
-//     is the load balancer.
+//   clip_rows_kernel   one thread per k-row (fixed i,j; k = 0..m-1).  A row is a straight segment in
+//                      camera space, pc(k) = Q0 + k Q1, and every frustum test (z >= 0, u > -1, u < W,
+//                      v > -1, v < H) is affine in k, so the k that can pass form ONE interval, found
+//                      with five divisions per row.  The interval is widened by a voxel per side and
+//                      its 64-voxel chunks are appended to a work list (block scan + one atomic per
+//                      workgroup).  Every listed voxel still runs the reference's exact tests, so the
+//                      cull never changes a result.  The row's share of rot_inv * g (its first two
+//                      terms, identical for all k) is stored once per row.
+//   integrate_kernel   persistent workgroups stride over the list; one item = 64 consecutive k of one
+//                      row = one 512-byte {D,W} segment (+1 KiB colour): perfectly coalesced RMW.
+//                      Row constants arrive through scalar loads (wave-uniform), so the per-voxel f64
+//                      work is 1 multiply + 2 adds per camera coordinate.
 //
 // Algorithmic traffic: 16 B (48 B with colour) per *updated* voxel + the 32-byte pixel records.
 
-constexpr int kRowsPerTile = 64;
-constexpr int kRowsPerWave = kRowsPerTile / (kIntegrateBlock / 64);   // 16
+constexpr int kClipBlock = 256;
+#ifndef TSDF_INTEGRATE_MIN_WAVES
+#define TSDF_INTEGRATE_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
 
 struct IntegrateTiling {
     long long n_rows;    // (xe-xs) * m
     int log2m;           // >= 0 when m is a power of two
     int clip;            // 1 = K has the usual last row (0,0,k22>0): row clipping is valid
+    int k_std;           // 1 = K = [[fx,0,cx],[0,fy,cy],[0,0,1]] exactly: zero terms can be dropped
 };
 
 // interval of k (real-valued) on which a + k*b > 0, intersected into [lo, hi]
@@ -134,133 +150,275 @@ __device__ __forceinline__ void clip_affine(double a, double b, double& lo, doub
     // (b == 0 and a within rounding of 0: leave it to the exact per-voxel test)
 }
 
-template <bool COLOR>
-__global__ __launch_bounds__(kIntegrateBlock) void integrate_kernel(
-    IntegrateParams p, IntegrateTiling tl, float2* __restrict__ dw, float4* __restrict__ crgb,
-    const float4* __restrict__ pn, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
+                                                                unsigned* __restrict__ list,
+                                                                unsigned* __restrict__ count,
+                                                                double* __restrict__ rowbase) {
     const int m = p.g.m;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double ox = p.g.origin[0], oy = p.g.origin[1], oz = p.g.origin[2];
-    const double cw = (double)p.g.cell_w, ch = (double)p.g.cell_h, cd = (double)p.g.cell_d;
-    const float delta = p.g.delta, eps = p.g.epsilon;
-    const long long row0 = (long long)blockIdx.x * kRowsPerTile;
-    unsigned n_own = 0, n_halo = 0;
-
-    // ---- per-row clip: lane r (< 16) owns row row0 + 4 r + wv
-    int klo_v = 1, khi_v = 0;
-    {
-        const long long row = row0 + 4 * lane + wv;
-        if (lane < kRowsPerWave && row < tl.n_rows) {
-            int il, j;
-            if (tl.log2m >= 0) { il = (int)(row >> tl.log2m); j = (int)(row & (m - 1)); }
-            else { il = (int)(row / m); j = (int)(row - (long long)il * m); }
-            klo_v = 0; khi_v = m - 1;
-            if (tl.clip) {
-                const double gx = cw * ((double)(il + p.g.xs) + 0.5) + ox;
-                const double gy = ch * ((double)j + 0.5) + oy;
-                const double gz0 = cd * 0.5 + oz;               // k = 0
-                // pc(k) = Q0 + k Q1
-                double Q0[3], Q1[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    Q0[a] = (p.rot_inv[3 * a] * gx + p.rot_inv[3 * a + 1] * gy) + p.rot_inv[3 * a + 2] * gz0 + p.rot_inv_trans[a];
-                    Q1[a] = p.rot_inv[3 * a + 2] * cd;
-                }
-                // ij = K pc, with K's last row (0,0,k22): ij2 = k22 * pcz has the sign of pcz
-                const double a0 = row3(&p.K[0], Q0[0], Q0[1], Q0[2]), b0 = row3(&p.K[0], Q1[0], Q1[1], Q1[2]);
-                const double a1 = row3(&p.K[3], Q0[0], Q0[1], Q0[2]), b1 = row3(&p.K[3], Q1[0], Q1[1], Q1[2]);
-                const double a2 = p.K[8] * Q0[2], b2 = p.K[8] * Q1[2];
-                double lo = -1.0, hi = (double)m;
-                clip_affine(a2, b2, lo, hi);                                   // pcz > 0 (>= handled by the margin)
-                clip_affine(a0 + a2, b0 + b2, lo, hi);                         // u > -1
-                clip_affine((double)p.width * a2 - a0, (double)p.width * b2 - b0, lo, hi);     // u < W
-                clip_affine(a1 + a2, b1 + b2, lo, hi);                         // v > -1
-                clip_affine((double)p.height * a2 - a1, (double)p.height * b2 - b1, lo, hi);   // v < H
-                if (!(lo <= hi + 1.0e-6)) { klo_v = 1; khi_v = 0; }            // empty (or NaN): nothing can pass
-                else {
-                    // widen by one voxel per side; the exact test below decides inside
-                    const double l2 = floor(lo) - 1.0, h2 = ceil(hi) + 1.0;
-                    klo_v = l2 < 0.0 ? 0 : (l2 > (double)(m - 1) ? m : (int)l2);
-                    khi_v = h2 > (double)(m - 1) ? m - 1 : (h2 < 0.0 ? -1 : (int)h2);
-                }
-            }
-        }
-    }
-
-    // ---- walk the rows of this wave
-    for (int r = 0; r < kRowsPerWave; ++r) {
-        const int klo = __builtin_amdgcn_readlane(klo_v, r);
-        const int khi = __builtin_amdgcn_readlane(khi_v, r);
-        if (klo > khi) continue;                                   // wave-uniform
-        const long long row = row0 + 4 * r + wv;
+    const long long row = (long long)blockIdx.x * kClipBlock + tid;
+    int c0 = 0, n = 0;
+    if (row < tl.n_rows) {
         int il, j;
         if (tl.log2m >= 0) { il = (int)(row >> tl.log2m); j = (int)(row & (m - 1)); }
         else { il = (int)(row / m); j = (int)(row - (long long)il * m); }
-        const int i = il + p.g.xs;
-        const bool owned = (i >= p.g.own_x0 && i < p.g.own_x1);
+        const double cw = (double)p.g.cell_w, ch = (double)p.g.cell_h, cd = (double)p.g.cell_d;
         // get_global_coordinates, sdf.h:153-157: (extent/(float)m) * (i + 0.5) + origin
-        const double gx = cw * ((double)i + 0.5) + ox;
-        const double gy = ch * ((double)j + 0.5) + oy;
-        // first two terms of rot_inv * g (Eigen order: (r0*gx + r1*gy) + r2*gz), shared by the row
-        const double sx = p.rot_inv[0] * gx + p.rot_inv[1] * gy;
-        const double sy = p.rot_inv[3] * gx + p.rot_inv[4] * gy;
-        const double sz = p.rot_inv[6] * gx + p.rot_inv[7] * gy;
-        const long long row_base = row * m;
-
-        for (int k = (klo & ~63) + lane; k <= khi; k += 64) {
-            if (k < klo) continue;
-            const double gz = cd * ((double)k + 0.5) + oz;
-            // project_world_to_camera, camera_tracking.cpp:51-54
-            const double pcx = (sx + p.rot_inv[2] * gz) + p.rot_inv_trans[0];
-            const double pcy = (sy + p.rot_inv[5] * gz) + p.rot_inv_trans[1];
-            const double pcz = (sz + p.rot_inv[8] * gz) + p.rot_inv_trans[2];
-            if (pcz < 0) continue;                                              // sdf.cpp:247-249
-            // project_camera_to_image_plane, camera_tracking.cpp:40-47
-            const double ij0 = row3(&p.K[0], pcx, pcy, pcz);
-            const double ij1 = row3(&p.K[3], pcx, pcy, pcz);
-            const double ij2 = row3(&p.K[6], pcx, pcy, pcz);
-            const double u = ij0 / ij2;
-            const double w = ij1 / ij2;
-            // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
-            // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
-            if (!(u > -1.0 && u < (double)p.width && w > -1.0 && w < (double)p.height)) continue;
-            const int iu = (int)u, iw = (int)w;
-            const long long pix = (long long)iu * p.pix_su + (long long)iw * p.pix_sv;
-            const float4 P = pn[2 * pix + 0];
-            const float4 N = pn[2 * pix + 1];
-            if (is_nan(P.x) || is_nan(P.y) || is_nan(N.x) || is_nan(N.y) || is_nan(N.z)) continue;  // :260
-            // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
-            const double dx = (double)P.x - pcx, dy = (double)P.y - pcy, dz = (double)P.z - pcz;
-            const double nx = (double)N.x, ny = (double)N.y, nz = (double)N.z;
-            const double p2p = dx * nx + (dy * ny + dz * nz);
-            float d_new = (float)p2p;                                           // sdf.cpp:274
-            float w_new = 1.0f;
-            if (d_new >= eps && d_new <= delta) {                               // sdf.cpp:277-279
-                const float a = d_new - eps;
-                w_new = (float)exp((-0.5 * (double)a) * (double)a);
+        const double gx = cw * ((double)(il + p.g.xs) + 0.5) + p.g.origin[0];
+        const double gy = ch * ((double)j + 0.5) + p.g.origin[1];
+        // first two terms of rot_inv * g in Eigen's order ((r0*gx + r1*gy) + r2*gz): the same for every k
+        double S[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) S[a] = p.rot_inv[3 * a] * gx + p.rot_inv[3 * a + 1] * gy;
+        int klo = 0, khi = m - 1;
+        if (tl.clip) {
+            const double gz0 = cd * 0.5 + p.g.origin[2];               // k = 0
+            double Q0[3], Q1[3];                                       // pc(k) = Q0 + k Q1
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                Q0[a] = S[a] + p.rot_inv[3 * a + 2] * gz0 + p.rot_inv_trans[a];
+                Q1[a] = p.rot_inv[3 * a + 2] * cd;
             }
-            if (d_new > delta) continue;                                        // sdf.cpp:280-283
-            if (d_new < -delta) d_new = -delta;                                 // sdf.cpp:285-287
-
-            const long long idx = row_base + k;
-            const float2 old = dw[idx];                                         // {D, W}
-            const float w_sum = old.y + w_new;                                  // sdf.cpp:289-292
-            const float d_out = (old.y * old.x + w_new * d_new) / w_sum;
-            dw[idx] = make_float2(d_out, w_sum);
-            if (owned) ++n_own; else ++n_halo;
-
-            if (COLOR) {                                                        // sdf.cpp:294-304
-                const double cosine = fabs(0.0 * nx + (0.0 * ny + 1.0 * nz)) / sqrt(nx * nx + (ny * ny + nz * nz));
-                const float wc = (float)((double)w_new * cosine);
-                const float4 c = crgb[idx];                                     // {Color_W, R, G, B}
-                const unsigned bits = __float_as_uint(P.w);
-                const float pr = (float)(int)(bits & 255u), pg = (float)(int)((bits >> 8) & 255u),
-                            pb = (float)(int)((bits >> 16) & 255u);
-                const float cw_sum = c.x + wc;
-                crgb[idx] = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
-                                        (c.x * c.w + wc * pb) / cw_sum);
+            // ij = K pc, with K's last row (0,0,k22): ij2 = k22 * pcz has the sign of pcz
+            const double a0 = row3(&p.K[0], Q0[0], Q0[1], Q0[2]), b0 = row3(&p.K[0], Q1[0], Q1[1], Q1[2]);
+            const double a1 = row3(&p.K[3], Q0[0], Q0[1], Q0[2]), b1 = row3(&p.K[3], Q1[0], Q1[1], Q1[2]);
+            const double a2 = p.K[8] * Q0[2], b2 = p.K[8] * Q1[2];
+            double lo = -1.0, hi = (double)m;
+            clip_affine(a2, b2, lo, hi);                                                   // pcz >= 0
+            clip_affine(a0 + a2, b0 + b2, lo, hi);                                         // u > -1
+            clip_affine((double)p.width * a2 - a0, (double)p.width * b2 - b0, lo, hi);     // u < W
+            clip_affine(a1 + a2, b1 + b2, lo, hi);                                         // v > -1
+            clip_affine((double)p.height * a2 - a1, (double)p.height * b2 - b1, lo, hi);   // v < H
+            if (!(lo <= hi + 1.0e-6)) { klo = 1; khi = 0; }            // empty (or NaN): nothing can pass
+            else {
+                const double l2 = floor(lo) - 1.0, h2 = ceil(hi) + 1.0;   // one voxel of slack per side
+                klo = l2 < 0.0 ? 0 : (l2 > (double)(m - 1) ? m : (int)l2);
+                khi = h2 > (double)(m - 1) ? m - 1 : (h2 < 0.0 ? -1 : (int)h2);
             }
         }
+        if (klo <= khi) {
+            c0 = klo >> 6; n = (khi >> 6) - c0 + 1;
+            rowbase[3 * row + 0] = S[0]; rowbase[3 * row + 1] = S[1]; rowbase[3 * row + 2] = S[2];
+        }
+    }
+    // exclusive scan of n over the workgroup: wave scan by shuffles, then the 4 wave totals through LDS
+    int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    __shared__ int s_tot[kClipBlock / 64];
+    __shared__ unsigned s_base;
+    if (lane == 63) s_tot[wv] = incl;
+    __syncthreads();
+    int wave_off = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < kClipBlock / 64; ++q) { if (q < wv) wave_off += s_tot[q]; total += s_tot[q]; }
+    if (tid == 0) s_base = total ? atomicAdd(count, (unsigned)total) : 0u;
+    __syncthreads();
+    unsigned at = s_base + (unsigned)(wave_off + incl - n);
+    const unsigned code = (unsigned)row << 6;
+    for (int q = 0; q < n; ++q) list[at + q] = code | (unsigned)(c0 + q);
+}
+
+// exp(x) for the weight of sdf.cpp:278.  x = -(d-eps)^2/2 lies in [-(delta-eps)^2/2, 0]; for
+// |x| <= 1/16 a degree-10 Taylor polynomial in f64 (fused multiply-adds: this approximates the exact
+// function, it does not mimic reference roundings) has a truncation error below 2e-19, i.e. it is as
+// close to the true value as glibc's / ocml's exp (< 1 ulp of f64) and agrees with them after the
+// reference's f64 -> f32 narrowing except for values within ~1e-16 (relative) of an f32 rounding
+// boundary.  Larger |x| (non-default delta) use the library exp.
+__device__ __forceinline__ double exp_small(double x) {
+    if (x < -0.0625) return exp(x);
+    double r = 1.0 / 3628800.0;
+    r = __builtin_fma(r, x, 1.0 / 362880.0);
+    r = __builtin_fma(r, x, 1.0 / 40320.0);
+    r = __builtin_fma(r, x, 1.0 / 5040.0);
+    r = __builtin_fma(r, x, 1.0 / 720.0);
+    r = __builtin_fma(r, x, 1.0 / 120.0);
+    r = __builtin_fma(r, x, 1.0 / 24.0);
+    r = __builtin_fma(r, x, 1.0 / 6.0);
+    r = __builtin_fma(r, x, 0.5);
+    r = __builtin_fma(r, x, 1.0);
+    r = __builtin_fma(r, x, 1.0);
+    return r;
+}
+
+// Per-item state between the pipeline stages of integrate_kernel.
+struct GatherState {        // stage 1 done: pixel record requested
+    bool live;
+    bool owned;
+    long long idx;          // voxel index inside the stored slab
+    long long pix;          // pixel record index
+    double pcx, pcy, pcz;   // camera-frame voxel centre
+    float4 P, N;            // pixel record (in flight until stage 2 reads it)
+};
+struct UpdateState {        // stage 2 done: volume reads requested
+    bool live;
+    bool owned;
+    long long idx;
+    float d_new, w_new;
+    unsigned rgb;
+    float2 old;             // {D, W}            (in flight until stage 3)
+    float4 col;             // {Color_W, R, G, B} (in flight until stage 3)
+    float wc;               // colour weight (float)(w_new * cosine), sdf.cpp:299
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool COLOR, bool KSTD>
+__global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
+    IntegrateParams p, IntegrateTiling tl, const unsigned* __restrict__ list, const unsigned* __restrict__ count,
+    const double* __restrict__ rowbase, float2* __restrict__ dw, float4* __restrict__ crgb,
+    const float4* __restrict__ pn, unsigned long long* __restrict__ counters) {
+    const int m = p.g.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double oz = p.g.origin[2];
+    const double cd = (double)p.g.cell_d;
+    const float delta = p.g.delta, eps = p.g.epsilon;
+    const unsigned n_items = *count;
+    const unsigned n_waves = gridDim.x * (kIntegrateBlock / 64);
+    // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
+    // list = one x-range of the slab = one band of the image, so the pixel records it gathers stay in
+    // its own L2 instead of every XCD streaming the whole 10 MB image through.
+    const unsigned vblock = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned gwave = vblock * (kIntegrateBlock / 64) + wv;
+    // this wavefront's contiguous share of the work list (items of one row stay together)
+    const unsigned first = (unsigned)(((unsigned long long)n_items * gwave) / n_waves);
+    const unsigned last = (unsigned)(((unsigned long long)n_items * (gwave + 1)) / n_waves);
+    unsigned n_own = 0, n_halo = 0;
+    unsigned code_v = 0;
+    double s0_v = 0.0, s1_v = 0.0, s2_v = 0.0;
+    int cnt = 0;
+
+    // S1(j): geometry of item j of the current block; request its pixel record.  The two record loads are
+    // issued on every path (dead lanes read record 0) so that later waits can be counted, not vmcnt(0).
+    auto stage1 = [&](int j, GatherState& g) {
+        const int jj = j < cnt ? j : 0;
+        const unsigned code = __builtin_amdgcn_readlane(code_v, jj);
+        const long long row = (long long)(code >> 6);
+        const int k = (int)(code & 63u) * 64 + lane;
+        const int il = (tl.log2m >= 0) ? (int)(row >> tl.log2m) : (int)(row / m);
+        const int i = il + p.g.xs;
+        g.owned = (i >= p.g.own_x0 && i < p.g.own_x1);
+        const double sx = readlane_f64(s0_v, jj), sy = readlane_f64(s1_v, jj), sz = readlane_f64(s2_v, jj);
+        g.idx = row * m + (k < m ? k : 0);
+        // get_global_coordinates (sdf.h:153-157) + project_world_to_camera (camera_tracking.cpp:51-54)
+        const double gz = cd * ((double)k + 0.5) + oz;
+        g.pcx = (sx + p.rot_inv[2] * gz) + p.rot_inv_trans[0];
+        g.pcy = (sy + p.rot_inv[5] * gz) + p.rot_inv_trans[1];
+        g.pcz = (sz + p.rot_inv[8] * gz) + p.rot_inv_trans[2];
+        bool ok = (j < cnt) && (k < m) && !(g.pcz < 0);                         // sdf.cpp:247-249
+        // project_camera_to_image_plane, camera_tracking.cpp:40-47.  With K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
+        // the dropped terms are +-0 products: (fx*x + 0*y) + cx*z == fx*x + cx*z and (0*x + 0*y) + 1*z == z
+        // bit for bit (up to the sign of a zero, which no later step can observe).
+        double ij0, ij1, ij2;
+        if (KSTD) {
+            ij0 = p.K[0] * g.pcx + p.K[2] * g.pcz;
+            ij1 = p.K[4] * g.pcy + p.K[5] * g.pcz;
+            ij2 = g.pcz;
+        } else {
+            ij0 = row3(&p.K[0], g.pcx, g.pcy, g.pcz);
+            ij1 = row3(&p.K[3], g.pcx, g.pcy, g.pcz);
+            ij2 = row3(&p.K[6], g.pcx, g.pcy, g.pcz);
+        }
+        const double u = ij0 / ij2;
+        const double w = ij1 / ij2;
+        // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
+        // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
+        ok = ok && (u > -1.0 && u < (double)p.width && w > -1.0 && w < (double)p.height);
+        const int iu = ok ? (int)u : 0, iw = ok ? (int)w : 0;
+        g.pix = (long long)iu * p.pix_su + (long long)iw * p.pix_sv;
+        if (p.debug & 1) g.pix = __shfl(g.pix, 0);          // timing experiment only: one record per wave
+        g.P = pn[2 * g.pix + 0];
+        g.N = pn[2 * g.pix + 1];
+        g.live = ok;
+    };
+    // S2: distance + weight from the pixel record; request {D,W} (+ colour, cosine).  Loads again on every
+    // path; lanes that will not update read the item's first voxel (one shared, cache-resident line).
+    auto stage2 = [&](const GatherState& g, UpdateState& u) {
+        const float4 P = g.P, N = g.N;
+        bool ok = g.live && !(is_nan(P.x) || is_nan(P.y) || is_nan(N.x) || is_nan(N.y) || is_nan(N.z));  // sdf.cpp:260
+        // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
+        const double dx = (double)P.x - g.pcx, dy = (double)P.y - g.pcy, dz = (double)P.z - g.pcz;
+        const double p2p = dx * (double)N.x + (dy * (double)N.y + dz * (double)N.z);
+        float d = (float)p2p;                                                   // sdf.cpp:274
+        ok = ok && !(d > delta);                                                // sdf.cpp:280-283
+        float wn = 1.0f;
+        if (ok && d >= eps && d <= delta) {                                     // sdf.cpp:277-279
+            const float a = d - eps;
+            wn = (float)exp_small((-0.5 * (double)a) * (double)a);
+        }
+        if (d < -delta) d = -delta;                                             // sdf.cpp:285-287
+        if (p.debug & 2) ok = false;                                            // timing experiment only: no volume RMW
+        u.d_new = d; u.w_new = wn; u.rgb = __float_as_uint(P.w);
+        u.owned = g.owned;
+        u.idx = g.idx;
+        const long long ld = ok ? g.idx : 0ll;              // dead lanes share voxel 0's (cache-resident) line
+        u.old = dw[ld];
+        if (COLOR) {
+            u.col = crgb[ld];
+            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  w_new == 1 (every voxel in front of the surface)
+            // makes it the pre-rounded cosine of the record; the exp() band recomputes the f64 product.
+            u.wc = N.w;
+            if (ok && wn != 1.0f) u.wc = (float)((double)wn * pixel_cosine(N.x, N.y, N.z));
+        }
+        u.live = ok;
+    };
+    // S3: running averages and the two stores.
+    auto stage3 = [&](const UpdateState& u) {
+        if (u.live) {
+            const float w_sum = u.old.y + u.w_new;                              // sdf.cpp:289-292
+            const float d_out = (u.old.y * u.old.x + u.w_new * u.d_new) / w_sum;
+            dw[u.idx] = make_float2(d_out, w_sum);
+            if (u.owned) ++n_own; else ++n_halo;
+            if (COLOR) {                                                        // sdf.cpp:294-304
+                const float wc = u.wc;
+                const float pr = (float)(int)(u.rgb & 255u), pg = (float)(int)((u.rgb >> 8) & 255u),
+                            pb = (float)(int)((u.rgb >> 16) & 255u);
+                const float4 c = u.col;
+                const float cw_sum = c.x + wc;
+                crgb[u.idx] = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
+                                          (c.x * c.w + wc * pb) / cw_sum);
+            }
+        }
+    };
+
+    for (unsigned blk = first; blk < last; blk += 64) {
+        cnt = (int)((last - blk) < 64u ? (last - blk) : 64u);
+        // lane l fetches item blk+l and its row constants: one round of memory latency per 64 items;
+        // the stages broadcast them with v_readlane (no further scalar/vector loads per item)
+        code_v = 0; s0_v = s1_v = s2_v = 0.0;
+        if (lane < cnt) {
+            code_v = list[blk + lane];
+            const long long r = (long long)(code_v >> 6);
+            s0_v = rowbase[3 * r + 0]; s1_v = rowbase[3 * r + 1]; s2_v = rowbase[3 * r + 2];
+        }
+        // Wait for them HERE (vmcnt(0) only): otherwise hipcc puts a vmcnt(0) at their first use inside the
+        // pipelined loop, where it would drain the pipeline on every step.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // Three-stage software pipeline over the items of this block, unrolled by two so that the
+        // in-flight registers never have to be copied (a copy would force the wait):
+        //   step j:  S1(j) request pixel record | S2(j-1) request {D,W}/colour | S3(j-2) average + store
+        // every memory round-trip has a whole step of other work to hide behind.
+        GatherState GA, GB;
+        UpdateState UA, UB;
+        GB.live = false; GB.owned = false; GB.idx = 0; GB.pix = 0; GB.pcx = GB.pcy = GB.pcz = 0.0;
+        GB.P = make_float4(0.f, 0.f, 0.f, 0.f); GB.N = GB.P;
+        UA.live = false; UB.live = false;
+        UA.owned = UB.owned = false; UA.idx = UB.idx = 0; UA.d_new = UB.d_new = 0.f; UA.w_new = UB.w_new = 1.f;
+        UA.rgb = UB.rgb = 0u; UA.old = UB.old = make_float2(0.f, 0.f);
+        UA.col = UB.col = make_float4(0.f, 0.f, 0.f, 0.f); UA.wc = UB.wc = 0.f;
+        for (int j = 0; j < cnt + 2; j += 2) {
+            stage1(j, GA);     stage2(GB, UA); stage3(UB);
+            stage1(j + 1, GB); stage2(GA, UB); stage3(UA);
+        }
+        stage3(UB);           // drain (UA was consumed by the last half-step; GB is dead: j+1 >= cnt+1 ... )
     }
 
     // one atomic per counter per workgroup that updated anything: wave shuffle, then LDS across the 4 waves
@@ -269,7 +427,7 @@ __global__ __launch_bounds__(kIntegrateBlock) void integrate_kernel(
         n_own += __shfl_xor(n_own, off);
         n_halo += __shfl_xor(n_halo, off);
     }
-    if (lane == 0) { s_cnt[0][wv] = n_own; s_cnt[1][wv] = n_halo; }
+    if (lane == 0) { s_cnt[0][tid >> 6] = n_own; s_cnt[1][tid >> 6] = n_halo; }
     __syncthreads();
     if (tid == 0) {
         unsigned a = 0, b = 0;
@@ -279,8 +437,21 @@ __global__ __launch_bounds__(kIntegrateBlock) void integrate_kernel(
     }
 }
 
+size_t integrate_worklist_entries(const Grid& g) {
+    return (size_t)(g.xe - g.xs) * g.m * ((g.m + 63) / 64);
+}
+size_t integrate_rowbase_entries(const Grid& g) { return (size_t)(g.xe - g.xs) * g.m * 3; }
+
+int integrate_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true>, kIntegrateBlock, 0) != hipSuccess || n < 1)
+        n = TSDF_INTEGRATE_MIN_WAVES;
+    return n;
+}
+
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
-                            const float4* pn, unsigned long long* counters) {
+                            const float4* pn, unsigned long long* counters,
+                            unsigned* worklist, unsigned* work_count, double* rowbase, int n_blocks) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
@@ -289,11 +460,20 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     tl.log2m = -1;
     for (int b = 0; b < 31; ++b) if ((1 << b) == m) tl.log2m = b;
     tl.clip = (p.K[6] == 0.0 && p.K[7] == 0.0 && p.K[8] > 0.0) ? 1 : 0;
-    const long long blocks = (tl.n_rows + kRowsPerTile - 1) / kRowsPerTile;
-    if (p.with_color)
-        integrate_kernel<true><<<dim3((unsigned)blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, dw, crgb, pn, counters);
-    else
-        integrate_kernel<false><<<dim3((unsigned)blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, dw, crgb, pn, counters);
+    tl.k_std = (p.K[1] == 0.0 && p.K[3] == 0.0 && p.K[6] == 0.0 && p.K[7] == 0.0 && p.K[8] == 1.0) ? 1 : 0;
+    if (p.debug & 4) tl.k_std = 0;
+    if (tl.n_rows >= (1ll << 26)) return hipErrorInvalidValue;       // row index must fit the 26-bit item code
+    hipError_t e = hipMemsetAsync(work_count, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
+    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, worklist, work_count, rowbase);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+#define TSDF_LAUNCH_INTEGRATE(C, KS) \
+    integrate_kernel<C, KS><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, work_count, rowbase, dw, crgb, pn, counters)
+    if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE(true, true); else TSDF_LAUNCH_INTEGRATE(true, false); }
+    else { if (tl.k_std) TSDF_LAUNCH_INTEGRATE(false, true); else TSDF_LAUNCH_INTEGRATE(false, false); }
+#undef TSDF_LAUNCH_INTEGRATE
     return hipGetLastError();
 }
 
