@@ -169,8 +169,10 @@ int tsdf_set_allreduce_hook(tsdf_handle *h, tsdf_allreduce_fn fn, void *ctx);
 int tsdf_allreduce(tsdf_handle *h, double *buf, int32_t n);
 
 /* ---- measurement helpers ------------------------------------------------------------------ */
-/* GPU time measured with HIP events recorded on the handle's own stream around each kernel launch
- * (off by default; tsdf_set_timing(h,1) turns it on), summed since the last reset. */
+/* GPU time measured with HIP events recorded on the handle's own stream around each kernel launch,
+ * summed since the last reset.  Off by default.  tsdf_set_timing(h, mask): bit 0 = integrate + pack
+ * launches (events are read back lazily, no extra synchronisation); bit 1 = every tracker pass (the stop
+ * event of each pass must complete before the host continues, which costs a few microseconds per pass). */
 typedef struct tsdf_timing {
     double  integrate_ms;       /* integrate_kernel only                                              */
     int64_t integrate_launches;

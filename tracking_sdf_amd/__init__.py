@@ -365,8 +365,11 @@ class SDF:
         return a
 
     # -- measurement
-    def set_timing(self, on=True):
-        self._check(lib().tsdf_set_timing(self._h, 1 if on else 0))
+    def set_timing(self, on=True, track=None):
+        """HIP-event timing: integrate/pack launches when ``on``; tracker passes too when ``track``
+        (default: same as ``on``; per-pass events cost a few microseconds each)."""
+        track = on if track is None else track
+        self._check(lib().tsdf_set_timing(self._h, (1 if on else 0) | (2 if track else 0)))
 
     def read_timing(self, reset=False):
         t = Timing()

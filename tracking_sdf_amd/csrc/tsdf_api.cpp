@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -63,9 +64,11 @@ struct tsdf_handle {
     size_t pn_cap = 0, samples_cap = 0;
 
     // tracker reduction buffers
-    double* partials = nullptr; size_t partials_cap = 0;   // blocks x kRedWidth
+    double* partials = nullptr; size_t partials_cap = 0;   // doubles
     double* red_dev = nullptr;     // kRedWidth
-    double* red_host = nullptr;    // pinned, kRedWidth
+    double* red_host = nullptr;    // pinned, kRedWidth doubles + the pass-number word the host polls
+    unsigned long long pass_seq = 0;
+    bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
 
     // comm
     rccl::Comm comm;
@@ -73,7 +76,8 @@ struct tsdf_handle {
     void* hook_ctx = nullptr;
 
     // measurement
-    bool timing = false;
+    bool timing = false;           // events around the integrate / pack launches (asynchronous, drained on read)
+    bool timing_track = false;     // events around every tracker pass (needs a completed stop event per pass)
     std::vector<EventPair> ev_pool;   // pending integrate/pack pairs
     std::vector<int> ev_kind;         // 0 = integrate, 1 = pack
     size_t ev_used = 0;
@@ -140,11 +144,11 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
         HIP_TRY(h, hipMalloc((void**)&h->samples, ns * sizeof(float4)));
         h->samples_cap = ns;
     }
-    const size_t nb = (size_t)track_num_blocks((int32_t)ns);
+    const size_t nb = track_partials_doubles((int32_t)ns);
     if (nb > h->partials_cap) {
         if (h->partials) (void)hipFree(h->partials);
         h->partials = nullptr; h->partials_cap = 0;
-        HIP_TRY(h, hipMalloc((void**)&h->partials, nb * kRedWidth * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void**)&h->partials, nb * sizeof(double)));
         h->partials_cap = nb;
     }
     if (need_staging && npix > h->in_cap) {
@@ -249,21 +253,38 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     TrackParams p;
     fill_track_params(h, p);
     const bool use_rccl = reduce_ranks && h->comm.active();
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
+    const unsigned long long seq = ++h->pass_seq;
+    if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
     HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
-                            use_rccl ? nullptr : h->red_host));
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
+                            use_rccl ? nullptr : h->red_host, seq));
+    if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
+    bool arrived = false;
     if (use_rccl) {
         std::string cerr;
         if (!h->comm.allreduce_sum_f64(h->red_dev, kRedAllreduce, h->stream, &cerr))
             return fail(h, TSDF_E_COMM, "RCCL all-reduce failed: %s", cerr.c_str());
         HIP_TRY(h, hipMemcpyAsync(h->red_host, h->red_dev, kRedWidth * sizeof(double), hipMemcpyDeviceToHost,
                                   h->stream));
+    } else if (h->poll) {
+        // The final kernel publishes the pass number after the row (system-scope release); spinning on it
+        // saves the runtime's completion-signal path.  Bounded: fall back to a real synchronisation.
+        volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(h->red_host + kRedWidth);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+            if ((spins & 1023u) == 1023u &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->timing) {
+    if (!arrived) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->timing_track) {
         float ms = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_track.a, h->ev_track.b));
+        hipError_t te = hipEventElapsedTime(&ms, h->ev_track.a, h->ev_track.b);
+        if (te == hipErrorNotReady) {
+            HIP_TRY(h, hipEventSynchronize(h->ev_track.b));
+            te = hipEventElapsedTime(&ms, h->ev_track.a, h->ev_track.b);
+        }
+        HIP_TRY(h, te);
         h->tm.track_ms += ms;
         h->tm.track_launches++;
     }
@@ -428,7 +449,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
         h->integrate_blocks = (prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4) + 7) / 8 * 8;   // whole XCD groups
     }
     CREATE_TRY(hipMalloc((void**)&h->red_dev, kRedWidth * sizeof(double)));
-    CREATE_TRY(hipHostMalloc((void**)&h->red_host, kRedWidth * sizeof(double), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void**)&h->red_host, (kRedWidth + 2) * sizeof(double), hipHostMallocDefault));
+    std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
+    { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
     CREATE_TRY(hipEventCreate(&h->ev_track.b));
     CREATE_TRY(launch_fill(h->stream, g, h->dw, h->crgb, cfg->width + cfg->height + cfg->depth));   // sdf.cpp:29
@@ -798,7 +821,8 @@ int tsdf_set_timing(tsdf_handle* h, int32_t on) {
     int rc = bind_device(h);
     if (rc) return rc;
     if (!on) { rc = drain_events(h); if (rc) return rc; }
-    h->timing = on != 0;
+    h->timing = (on & 1) != 0;
+    h->timing_track = (on & 2) != 0;
     return TSDF_OK;
 }
 

@@ -71,10 +71,12 @@ int integrate_blocks_per_cu();
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             unsigned* worklist, unsigned* work_count, double* rowbase, int n_blocks);
-// partials: nblocks x kRedWidth doubles; red_dev / red_host: kRedWidth doubles each (red_host may be null)
+// partials: track_partials_doubles(n_samples) doubles; red_dev: kRedWidth doubles; red_host (pinned, may
+// be null): kRedWidth doubles + one 64-bit word that receives `seq` after the row is complete.
 hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                        double* partials, double* red_dev, double* red_host);
+                        double* partials, double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);
+size_t track_partials_doubles(int32_t n_samples);
 hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const double* vox, int32_t n,
                          float* val, int32_t* ok);
 hipError_t launch_split(hipStream_t s, const float2* dw, float* d, float* w, int64_t n);

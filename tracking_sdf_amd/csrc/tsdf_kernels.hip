@@ -541,19 +541,37 @@ hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const d
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tracker: one Gauss-Newton accumulation pass.
+// Tracker: one Gauss-Newton accumulation pass (reference src/camera_tracking.cpp:146-189 +
+// get_partial_derivative :246-363).
 //
-// One thread per sampled pixel, in the reference's visiting order (so a wavefront's ballot is a
-// 64-sample window of that order).  Classification (NaN / out-of-grid / in-grid) needs geometry
-// only; the reference's stale carry-over (an out-of-grid pixel re-adds the previous successful
-// pixel's terms, camera_tracking.cpp:156-159,176-182,261-268) becomes a multiplicity
-//     1 + #{out-of-grid samples between this sample and the next in-grid one, NaN samples skipped}
-// computed from 64-bit ballots held in LDS, with a cooperative look-ahead past the workgroup's end.
-// 13 look-ups x 8 corners of 8-byte {D,W} gathers per owned in-grid sample follow; the 27 unique
-// terms of J J^T / r J (+ counters) are reduced wave-shuffle -> LDS across the 4 waves -> one row of
+// The reference does 13 dependent look-ups per sampled pixel, one after the other.  One thread per
+// sample (round-1 v1) therefore means 13 serial memory round trips per wavefront and only ~535
+// wavefronts for the whole chip: pure latency, 48 us per pass.  v2 spends 16 lanes per sample:
+//
+//   lane q of a 16-lane group   q = 0       centre voxel            -> r            (:269)
+//                               q = 1..6    centre +- v_h e_k       -> J[0..2]      (:273-316)
+//                               q = 7..12   (I +- w_h [e_k]x) rot p -> J[3..5]      (:318-361)
+//   so the 13 look-ups of a sample are ONE memory round trip, the chip holds ~8 wavefronts per SIMD,
+//   and the reference's early exits become an AND over the group (a failed look-up drops the sample
+//   either way, so evaluating the others changes nothing).
+//
+// Stale carry-over (:156-159,176-182,261-268): an out-of-grid pixel re-adds the previous successful
+// pixel's terms, i.e. a successful sample counts 1 + #{out-of-grid samples between it and the next
+// in-grid one, NaN samples skipped} times.  Classification needs geometry only, so every workgroup
+// classifies a 256-sample window starting at its own 16 samples (64-bit ballots = 64 consecutive
+// samples of the reference's column-major visiting order) and reads the run lengths off the masks,
+// looking further ahead cooperatively in the rare case a run outlives the window.
+//
+// Reduction: lane q < 6 of a group forms J[q] J[(q+d)%6] (d = 0..3: all 21 unique products) and
+// r J[q]; the 4 groups of a wavefront are added by shuffles, the 4 wavefronts through LDS, one row of
 // `partials` per workgroup; track_final_kernel adds the rows in a fixed order (bitwise reproducible).
 
 enum { kClsSkip = 0, kClsOog = 1, kClsIn = 2 };
+constexpr int kLanesPerSample = 16;
+constexpr int kSamplesPerBlock = kTrackBlock / kLanesPerSample;   // 16
+// partial-row layout of track_kernel: [5*q + d] (q = 0..5, d = 0..4), then counters
+constexpr int kPartTerms = 30, kPartViol = 31, kPartOk = 32, kPartInOwned = 33, kPartOog = 34, kPartNan = 35,
+              kPartSamples = 36, kPartWidth = 40;
 
 struct SampleGeom {
     double px, py, pz;   // camera-frame point
@@ -562,6 +580,7 @@ struct SampleGeom {
 
 __device__ __forceinline__ int classify(const TrackParams& p, const float4* __restrict__ samples, int n,
                                         SampleGeom& sg) {
+    sg.px = sg.py = sg.pz = 0.0; sg.vx = sg.vy = sg.vz = 0.0;
     if (n >= p.n_samples) return kClsSkip;
     const float4 s = samples[n];
     if (is_nan(s.x) || is_nan(s.y) || is_nan(s.z)) return kClsSkip;          // camera_tracking.cpp:168
@@ -593,30 +612,45 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
                                                              const float4* __restrict__ samples,
                                                              double* __restrict__ partials) {
     constexpr int NW = kTrackBlock / 64;
-    __shared__ unsigned long long s_in[NW], s_oog[NW];     // this workgroup's windows
+    __shared__ unsigned long long s_in[NW], s_oog[NW];     // the 256-sample window of this workgroup
     __shared__ unsigned long long s_in2[NW], s_oog2[NW];   // look-ahead windows
-    __shared__ double s_red[NW][kRedWidth];
+    __shared__ double s_red[NW][8][8];                     // [wave][q][slot]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = blockIdx.x * kTrackBlock + tid;
+    const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's 16 samples
 
-    SampleGeom sg;
-    const int cls = classify(p, samples, n, sg);
-    const unsigned long long b_in = __ballot(cls == kClsIn);
-    const unsigned long long b_oog = __ballot(cls == kClsOog);
-    if (lane == 0) { s_in[wv] = b_in; s_oog[wv] = b_oog; }
+    // ---- phase A: classify the window [base, base+256) -- thread t looks at sample base+t
+    SampleGeom win;
+    const int wcls = classify(p, samples, base + tid, win);
+    {
+        const unsigned long long b_in = __ballot(wcls == kClsIn);
+        const unsigned long long b_oog = __ballot(wcls == kClsOog);
+        if (lane == 0) { s_in[wv] = b_in; s_oog[wv] = b_oog; }
+    }
     __syncthreads();
 
-    // ---- stale-carry multiplicity
+    // ---- phase B: this thread's own sample (group g) and look-up (q)
+    const int g = tid >> 4, q = tid & 15;
+    const int n = base + g;
+    SampleGeom sg;
+    const int cls = classify(p, samples, n, sg);
+
+    // stale-carry multiplicity of sample g: out-of-grid samples between it and the next in-grid one
     unsigned mult = 1;
     if (p.stale_carry) {
-        // out-of-grid samples that follow this workgroup before the next in-grid sample
+        // (wave-uniform) does any of the 16 own samples' run reach past the 256-sample window?
+        const unsigned long long own_in = s_in[0] & 0xFFFFull;
+        bool need_tail = false;
         unsigned tail = 0;
-        bool any_in = false;
-        for (int q = 0; q < NW; ++q) any_in |= (s_in[q] != 0ull);
-        if (any_in) {
+        if (own_in) {
+            // the last own in-grid sample's run reaches the window end iff no in-grid bit follows it
+            const int last_own = 63 - __clzll((long long)own_in);
+            const unsigned long long above = (last_own == 63) ? 0ull : (~0ull << (last_own + 1));
+            need_tail = ((s_in[0] & above) == 0ull) && (s_in[1] | s_in[2] | s_in[3]) == 0ull;
+        }
+        if (need_tail) {
             bool found = false;
-            for (int pos = (blockIdx.x + 1) * kTrackBlock; !found && pos < p.n_samples; pos += kTrackBlock) {
+            for (int pos = base + kTrackBlock; !found && pos < p.n_samples; pos += kTrackBlock) {
                 SampleGeom tmp;
                 const int c2 = classify(p, samples, pos + tid, tmp);
                 const unsigned long long i2 = __ballot(c2 == kClsIn);
@@ -624,8 +658,8 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
                 __syncthreads();                        // previous round's readers are done
                 if (lane == 0) { s_in2[wv] = i2; s_oog2[wv] = o2; }
                 __syncthreads();
-                for (int q = 0; q < NW && !found; ++q) {
-                    const unsigned long long mi = s_in2[q], mo = s_oog2[q];
+                for (int w = 0; w < NW && !found; ++w) {
+                    const unsigned long long mi = s_in2[w], mo = s_oog2[w];
                     if (mi) {
                         const int nxt = __ffsll((long long)mi) - 1;
                         tail += __popcll(mo & ((1ull << nxt) - 1ull));
@@ -637,24 +671,24 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             }
         }
         if (cls == kClsIn) {
-            const unsigned long long above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+            const unsigned long long above = ~0ull << (g + 1);          // g <= 15
             unsigned cnt = 0;
             bool found = false;
-            unsigned long long mi = s_in[wv] & above;
+            unsigned long long mi = s_in[0] & above;
             if (mi) {
                 const int nxt = __ffsll((long long)mi) - 1;
-                cnt = __popcll(s_oog[wv] & above & ((1ull << nxt) - 1ull));
+                cnt = __popcll(s_oog[0] & above & ((1ull << nxt) - 1ull));
                 found = true;
             } else {
-                cnt = __popcll(s_oog[wv] & above);
-                for (int q = wv + 1; q < NW && !found; ++q) {
-                    mi = s_in[q];
+                cnt = __popcll(s_oog[0] & above);
+                for (int w = 1; w < NW && !found; ++w) {
+                    mi = s_in[w];
                     if (mi) {
                         const int nxt = __ffsll((long long)mi) - 1;
-                        cnt += __popcll(s_oog[q] & ((1ull << nxt) - 1ull));
+                        cnt += __popcll(s_oog[w] & ((1ull << nxt) - 1ull));
                         found = true;
                     } else {
-                        cnt += __popcll(s_oog[q]);
+                        cnt += __popcll(s_oog[w]);
                     }
                 }
                 if (!found) cnt += tail;
@@ -663,115 +697,182 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         }
     }
 
-    // ---- data association + numeric Jacobian for owned in-grid samples (camera_tracking.cpp:246-363)
-    double acc[kRedWidth];
-#pragma unroll
-    for (int e = 0; e < kRedWidth; ++e) acc[e] = 0.0;
-    acc[33] = (n < p.n_samples) ? 1.0 : 0.0;
-    acc[32] = (n < p.n_samples && cls == kClsSkip) ? 1.0 : 0.0;
-    acc[31] = (cls == kClsOog) ? 1.0 : 0.0;
-
+    // ---- the look-up of this lane (camera_tracking.cpp:269-361)
     const bool owned = (cls == kClsIn) && (sg.vx >= (double)p.g.own_x0) && (sg.vx < (double)p.g.own_x1);
-    if (owned) {
-        acc[30] = 1.0;
+    float val = 0.0f;
+    unsigned viol = 0;
+    bool ok = false;
+    if (owned && q < 13) {
         Vol V{dw, p.g.m, p.g.xs, p.g.xe};
-        unsigned viol = 0;
-        double J[6];
-        float r0 = 0.0f, fp = 0.0f, fm = 0.0f;
-        bool ok = interp(V, sg.vx, sg.vy, sg.vz, r0, viol);                     // :269
-        // translation columns: +-v_h along each voxel axis                      :273-316
-        if (ok) {
-            const double vh = (double)p.v_h;
-            ok = interp(V, sg.vx + vh, sg.vy, sg.vz, fp, viol) && interp(V, sg.vx - vh, sg.vy, sg.vz, fm, viol);
-            J[0] = (double)((fp - fm) / p.vh2[0]);
-            if (ok) {
-                ok = interp(V, sg.vx, sg.vy + vh, sg.vz, fp, viol) && interp(V, sg.vx, sg.vy - vh, sg.vz, fm, viol);
-                J[1] = (double)((fp - fm) / p.vh2[1]);
-            }
-            if (ok) {
-                ok = interp(V, sg.vx, sg.vy, sg.vz + vh, fp, viol) && interp(V, sg.vx, sg.vy, sg.vz - vh, fm, viol);
-                J[2] = (double)((fp - fm) / p.vh2[2]);
-            }
+        double vx = sg.vx, vy = sg.vy, vz = sg.vz;
+        if (q >= 7) {
+            voxel_of(p, &p.rpm[9 * (q - 7)], sg, vx, vy, vz);        // r1p r1m r2p r2m r3p r3m
+        } else if (q >= 1) {
+            const int a = (q - 1) >> 1;
+            const double step = ((q - 1) & 1) ? -(double)p.v_h : (double)p.v_h;
+            if (a == 0) vx += step; else if (a == 1) vy += step; else vz += step;
         }
-        // rotation columns: (I +- w_h [e_k]x) rot applied to the camera point   :318-361
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (ok) {
-                double ax, ay, az, bx, by, bz;
-                voxel_of(p, &p.rpm[9 * (2 * a + 0)], sg, ax, ay, az);
-                voxel_of(p, &p.rpm[9 * (2 * a + 1)], sg, bx, by, bz);
-                ok = interp(V, ax, ay, az, fp, viol) && interp(V, bx, by, bz, fm, viol);
-                J[3 + a] = (double)((fp - fm) / p.wh2);
-            }
-        }
-        acc[28] = viol ? 1.0 : 0.0;
-        if (ok && !viol) {
-            const double mu = (double)mult;
-            const double r = (double)r0;
-            int e = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[e++] = mu * (J[a] * J[b]);       // :181
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] = mu * (r * J[a]);           // :182
-            acc[27] = mu;
-            acc[29] = 1.0;
-        }
+        ok = interp(V, vx, vy, vz, val, viol);
     }
+    const unsigned long long okmask = __ballot(ok);
+    const bool all_ok = ((okmask >> (16 * (lane >> 4))) & 0x1FFFull) == 0x1FFFull;   // the group's 13 look-ups
+    const unsigned long long violmask = __ballot(viol != 0u);
+    const bool any_viol = ((violmask >> (16 * (lane >> 4))) & 0xFFFFull) != 0ull;
 
-    // ---- reduction: wave butterfly, then LDS across the 4 waves, one row per workgroup
+    // ---- J[q] on lanes 0..5 of the group, from the +/- partners (float quotient widened, :286,331)
+    const int gl = lane & 48;                                   // first lane of this group in the wave
+    const float r0 = __shfl(val, gl);
+    const int qa = q < 6 ? q : 0;
+    const float fp = __shfl(val, gl + 1 + 2 * qa);
+    const float fm = __shfl(val, gl + 2 + 2 * qa);
+    const float h = qa == 0 ? p.vh2[0] : (qa == 1 ? p.vh2[1] : (qa == 2 ? p.vh2[2] : p.wh2));
+    const double Jq = (double)((fp - fm) / h);
+    const double J1 = __shfl(Jq, gl + (qa + 1) % 6);
+    const double J2 = __shfl(Jq, gl + (qa + 2) % 6);
+    const double J3 = __shfl(Jq, gl + (qa + 3) % 6);
+
+    double acc[8];
 #pragma unroll
-    for (int e = 0; e < kRedWidth; ++e) {
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    const bool contributes = all_ok && !any_viol;
+    if (contributes && q < 6) {
+        const double mu = (double)mult;
+        acc[0] = mu * (Jq * Jq);                                // :181  J J^T, products (q, (q+d)%6)
+        acc[1] = mu * (Jq * J1);
+        acc[2] = mu * (Jq * J2);
+        acc[3] = mu * (Jq * J3);                                // (q >= 3 duplicates q-3; dropped by the final kernel)
+        acc[4] = mu * ((double)r0 * Jq);                        // :182  r J
+        if (q == 0) { acc[5] = mu; acc[7] = 1.0; }              // terms added, samples ok
+    }
+    if (q == 0) {
+        if (any_viol) acc[6] = 1.0;
+    }
+    // geometry-only statistics of the 16 own samples, carried by q == 1..4 lanes' slot 5
+    if (q == 1 && owned) acc[5] = 1.0;
+    if (q == 2 && cls == kClsOog) acc[5] = 1.0;
+    if (q == 3 && n < p.n_samples && cls == kClsSkip) acc[5] = 1.0;
+    if (q == 4 && n < p.n_samples) acc[5] = 1.0;
+
+    // ---- reduction over the 4 groups of the wave (xor 16, 32), then the 4 waves through LDS
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
         double v = acc[e];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
         acc[e] = v;
     }
-    if (lane == 0) {
+    if (lane < 8) {
 #pragma unroll
-        for (int e = 0; e < kRedWidth; ++e) s_red[wv][e] = acc[e];
+        for (int e = 0; e < 8; ++e) s_red[wv][lane][e] = acc[e];
     }
     __syncthreads();
-    if (tid < kRedWidth) {
-        double v = s_red[0][tid];
-        for (int q = 1; q < NW; ++q) v += s_red[q][tid];
-        partials[(long long)blockIdx.x * kRedWidth + tid] = v;
+    if (tid < 64) {
+        const int qq = tid >> 3, e = tid & 7;
+        double v = s_red[0][qq][e];
+        for (int w = 1; w < NW; ++w) v += s_red[w][qq][e];
+        // row layout: terms [5*q + d]; counters after them
+        int slot = -1;
+        if (qq < 6 && e < 5) slot = 5 * qq + e;
+        else if (qq == 0 && e == 5) slot = kPartTerms;
+        else if (qq == 0 && e == 6) slot = kPartViol;
+        else if (qq == 0 && e == 7) slot = kPartOk;
+        else if (qq == 1 && e == 5) slot = kPartInOwned;
+        else if (qq == 2 && e == 5) slot = kPartOog;
+        else if (qq == 3 && e == 5) slot = kPartNan;
+        else if (qq == 4 && e == 5) slot = kPartSamples;
+        if (slot >= 0) partials[(long long)blockIdx.x * kPartWidth + slot] = v;
     }
 }
 
-// Fixed-order final sum (kernel boundary = visibility; no atomics, no spin).
-__global__ __launch_bounds__(256) void track_final_kernel(const double* __restrict__ partials, int nblocks,
-                                                           double* __restrict__ red_dev,
-                                                           double* __restrict__ red_host) {
-    constexpr int ROWS = 256 / kRedWidth;            // 7 row groups of 34 columns
-    __shared__ double s[ROWS][kRedWidth];
+// Fixed-order final sum in two levels (kernel boundaries = visibility; no atomics, no spin):
+// track_fold_kernel folds the per-workgroup rows into <= kFoldBlocks rows, track_final_kernel adds those
+// and converts to the result row of tsdf_device.h.  Every sum has a fixed order: bitwise reproducible.
+constexpr int kFoldBlocks = 64;
+
+__device__ __forceinline__ void fold_rows(const double* __restrict__ rows, int first, int last, double* out /*LDS[kPartWidth]*/) {
+    constexpr int RG = 256 / kPartWidth;             // 6 row groups of 40 columns
+    __shared__ double s[RG][kPartWidth];
     const int tid = threadIdx.x;
-    const int col = tid % kRedWidth, rg = tid / kRedWidth;
-    if (rg < ROWS) {
+    const int col = tid % kPartWidth, rg = tid / kPartWidth;
+    if (rg < RG) {
         double v = 0.0;
-        for (int b = rg; b < nblocks; b += ROWS) v += partials[(long long)b * kRedWidth + col];
+        for (int r = first + rg; r < last; r += RG) v += rows[(long long)r * kPartWidth + col];
         s[rg][col] = v;
     }
     __syncthreads();
-    if (tid < kRedWidth) {
+    if (tid < kPartWidth) {
         double v = s[0][tid];
-        for (int q = 1; q < ROWS; ++q) v += s[q][tid];
+        for (int r = 1; r < RG; ++r) v += s[r][tid];
+        out[tid] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void track_fold_kernel(const double* __restrict__ partials, int nrows,
+                                                          double* __restrict__ folded) {
+    __shared__ double tot[kPartWidth];
+    const int per = (nrows + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < nrows ? first + per : nrows;
+    fold_rows(partials, first, last, tot);
+    if (threadIdx.x < kPartWidth) folded[(long long)blockIdx.x * kPartWidth + threadIdx.x] = tot[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void track_final_kernel(const double* __restrict__ folded, int nrows,
+                                                           double* __restrict__ red_dev,
+                                                           double* __restrict__ red_host,
+                                                           unsigned long long seq) {
+    __shared__ double tot[kPartWidth];
+    __shared__ double res[kRedWidth];
+    fold_rows(folded, 0, nrows, tot);
+    const int tid = threadIdx.x;
+    if (tid < kRedWidth) {
+        double v = 0.0;
+        if (tid < 21) {
+            // upper triangle, row-major: (a,b) with a <= b  ->  product slot of q = a or q = b
+            int a = 0, e = tid;
+            while (e >= 6 - a) { e -= 6 - a; ++a; }
+            const int b = a + e, d = b - a;
+            v = (d <= 3) ? tot[5 * a + d] : tot[5 * b + (6 - d)];     // (a,b) = (q,(q+d')%6) with q = b, d' = 6-d
+        } else if (tid < 27) v = tot[5 * (tid - 21) + 4];
+        else if (tid == 27) v = tot[kPartTerms];
+        else if (tid == 28) v = tot[kPartViol];
+        else if (tid == 29) v = tot[kPartOk];
+        else if (tid == 30) v = tot[kPartInOwned];
+        else if (tid == 31) v = tot[kPartOog];
+        else if (tid == 32) v = tot[kPartNan];
+        else if (tid == 33) v = tot[kPartSamples];
         red_dev[tid] = v;
-        if (red_host) red_host[tid] = v;
+        res[tid] = v;
+    }
+    __syncthreads();
+    // Host hand-off without a stream synchronisation: ONE lane writes the row to pinned host memory,
+    // fences at system scope, then publishes the pass number; the host spins on that word.
+    if (red_host && tid == 0) {
+        for (int e = 0; e < kRedWidth; ++e) red_host[e] = res[e];
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(red_host + kRedWidth), seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-int track_num_blocks(int32_t n_samples) { return (n_samples + kTrackBlock - 1) / kTrackBlock; }
+int track_num_blocks(int32_t n_samples) { return (n_samples + kSamplesPerBlock - 1) / kSamplesPerBlock; }
+size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blocks(n_samples) + kFoldBlocks) * kPartWidth; }
 
 hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                        double* partials, double* red_dev, double* red_host) {
+                        double* partials, double* red_dev, double* red_host, unsigned long long seq) {
     const int nb = track_num_blocks(p.n_samples);
     if (nb <= 0) return hipErrorInvalidValue;
     track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    track_final_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, nb, red_dev, red_host);
+    // unwritten counter slots of the rows (37..39) are never read into a result; terms/counters are all written
+    double* folded = partials + (size_t)nb * kPartWidth;
+    const int fb = nb < kFoldBlocks ? nb : kFoldBlocks;
+    track_fold_kernel<<<dim3(fb), dim3(256), 0, s>>>(partials, nb, folded);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    track_final_kernel<<<dim3(1), dim3(256), 0, s>>>(folded, fb, red_dev, red_host, seq);
     return hipGetLastError();
 }
 
