@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-baseline-frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allreduce", choices=["auto", "rccl", "torch"], default="auto")
+    ap.add_argument("--host-frames", action="store_true", help="hand frames over as HOST buffers every step (PCIe-inclusive rate; not the headline value)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--trajectory-out", default=None, help="write the estimated trajectory (TUM format)")
     return ap.parse_args()
 
@@ -137,11 +139,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.dist_backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+            if args.allreduce == "auto":
+                args.allreduce = "torch"          # ranks may share a GPU: RCCL refuses that
 
     def barrier():
         if world > 1:
@@ -162,7 +171,7 @@ def main():
     x0, x1 = ts.slab_range(args.m, world, rank)
     cfg0 = ts.default_config(m=args.m)
     halo = ts.halo_for(cfg0, args.max_range) if world > 1 else 0
-    sdf = ts.SDF(args.m, with_color=not args.no_color, slab=(x0, x1), halo=halo, device=local_rank)
+    sdf = ts.SDF(args.m, with_color=not args.no_color, slab=(x0, x1), halo=halo, device=dev_index)
     trk = ts.CameraTracking(sdf=sdf)
     trk.set_K(seq.K)
 
@@ -175,11 +184,11 @@ def main():
             import ctypes
             buf = ctypes.create_string_buffer(128)
             can = 1 if ts.lib().tsdf_comm_unique_id(buf) == 0 else 0
-            flag = torch.tensor([can], device=dev)
+            flag = torch.tensor([can], device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if bool(flag.item()):
                 # 2) rank 0's id to everyone, collective communicator init, then a self-test sum
-                uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device=dev)
+                uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device=dev if args.dist_backend == "nccl" else "cpu")
                 dist.broadcast(uid, 0)
                 try:
                     sdf.comm_init(world, rank, bytes(uid.cpu().tolist()))
@@ -188,7 +197,7 @@ def main():
                 except Exception as e:      # noqa: BLE001 -- report and fall back to the host hook
                     print(f"[bench] rank {rank}: in-library RCCL failed ({e})", file=sys.stderr)
                     ok = False
-                flag = torch.tensor([1 if ok else 0], device=dev)
+                flag = torch.tensor([1 if ok else 0], device=dev if args.dist_backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = bool(flag.item())
             if ok:
@@ -199,7 +208,7 @@ def main():
             if want == "rccl":
                 raise SystemExit("--allreduce rccl requested but the in-library communicator failed")
             sdf.comm_finalize()
-            scratch = torch.zeros(30, dtype=torch.float64, device=dev)
+            scratch = torch.zeros(30, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
 
             def hook(arr):
                 scratch.copy_(torch.from_numpy(arr))
@@ -211,8 +220,11 @@ def main():
     track_wall = [0.0]
 
     def step(k, timed_stats=None):
-        dx, dn, dc = d_frames[k]
-        sdf.set_frame_device(dx.data_ptr(), dn.data_ptr(), dc.data_ptr(), args.width, args.height)
+        if args.host_frames:
+            sdf.set_frame(*frames[k])
+        else:
+            dx, dn, dc = d_frames[k]
+            sdf.set_frame_device(dx.data_ptr(), dn.data_ptr(), dc.data_ptr(), args.width, args.height)
         tq = time.perf_counter()
         st = trk.estimate_new_position()
         if timed_stats is not None:
@@ -246,7 +258,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     tm = sdf.read_timing()
@@ -270,7 +282,7 @@ def main():
             "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32 volume / f64 geometry+normal equations",
-            "data": "synthetic",
+            "data": "synthetic" + (" (frames handed over as host buffers: PCIe-inclusive)" if args.host_frames else ""),
             "config": {"workload": f"fr1/plant ground-truth camera path at 30 Hz (re-based to the reference's initial "
                                    f"pose), analytic room+sphere+boxes scene, {args.width}x{args.height} depth with "
                                    f"Kinect noise + 2% holes, {args.m}^3 voxels, 6x6x3.5 m volume, "

@@ -168,6 +168,19 @@ int tsdf_set_allreduce_hook(tsdf_handle *h, tsdf_allreduce_fn fn, void *ctx);
 /* Sum-all-reduce n doubles through whichever of the two is configured (identity if neither). */
 int tsdf_allreduce(tsdf_handle *h, double *buf, int32_t n);
 
+/* ---- host-side algebra of the tracker, usable without a handle or a GPU (it runs on the host in the
+ *      product too: 27 doubles per Gauss-Newton pass).  Exposed so that the reference-side caller, the
+ *      CPU test-suite and a multi-process driver can use exactly the code tsdf_track uses.
+ *   tsdf_host_set_pose             set_camera_transformation: rot_inv = inverse(rot), rot_inv_trans = -rot_inv*trans
+ *   tsdf_host_perturbed_rotations  r1p r1m r2p r2m r3p r3m = (I +- w_h [e_k]x) rot          camera_tracking.cpp:92-145
+ *   tsdf_host_gn_step              twist = inverse(A) b; [R|t] = exp(twist); stop rule; rot <- R^T rot,
+ *                                  trans <- trans - R^T t  (in place).  Returns TSDF_E_SINGULAR and leaves the
+ *                                  pose alone if A is singular or the result is not finite.   camera_tracking.cpp:191-239 */
+int tsdf_host_set_pose(const double rot[9], const double trans[3], double rot_inv[9], double rot_inv_trans[3]);
+int tsdf_host_perturbed_rotations(const double rot[9], float w_h, double rpm[54]);
+int tsdf_host_gn_step(double rot[9], double trans[3], const double A[36], const double b[6],
+                      float max_twist_diff, double twist[6], int32_t *stop);
+
 /* ---- measurement helpers ------------------------------------------------------------------ */
 /* GPU time measured with HIP events recorded on the handle's own stream around each kernel launch,
  * summed since the last reset.  Off by default.  tsdf_set_timing(h, mask): bit 0 = integrate + pack

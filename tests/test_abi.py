@@ -1,0 +1,126 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads here (no GPU), exports every symbol that
+include/tsdf.h declares, and fails loudly -- never falls back -- when asked to compute without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import tracking_sdf_amd as ts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tsdf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsdf_[a-z0-9_]+)\s*\(", text)) - {"tsdf_allreduce_fn"})
+
+
+def test_header_symbols_all_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    L = ts.lib()
+    for name in syms:
+        assert hasattr(L, name), f"{name} declared in include/tsdf.h but not exported by libtsdf_hip.so"
+    assert sorted(ts.ABI_SYMBOLS) == syms, "python binding and header disagree"
+    assert L.tsdf_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # tsdf_config: 4+3*4 = 16, origin (8-aligned) 24, then 4*... -> check against a hand computation
+    assert C.sizeof(ts.Config) == 96
+    assert ts.Config.origin.offset == 16 and ts.Config.delta.offset == 40 and ts.Config.device.offset == 88
+    assert C.sizeof(ts.IntegrateStats) == 24 and C.sizeof(ts.AccumStats) == 48
+    assert C.sizeof(ts.TrackStats) == 64 and C.sizeof(ts.Timing) == 48 and C.sizeof(ts.Counters) == 64
+
+
+def test_default_config_is_the_reference_constants():
+    c = ts.default_config()
+    assert (c.m, c.width, c.height, c.depth) == (256, 6.0, 6.0, 3.5)            # sdf_reconstruction.cpp:83-85
+    assert list(c.origin) == [-3.0, -3.0, -0.5]
+    assert c.delta == np.float32(0.3) and c.epsilon == np.float32(0.025)
+    assert (c.gn_max_iter, c.v_h, c.pixel_stride) == (20, 1.0, 3)                # :88, camera_tracking.cpp:162
+    assert c.max_twist_diff == np.float32(0.001) and c.w_h == np.float32(0.01)
+    assert c.stale_carry == 1 and c.with_color == 1
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(ts.TsdfError) as ei:
+        ts.SDF(32)
+    assert ei.value.code in (ts.E_NO_DEVICE, ts.E_HIP)
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_bad_arguments_are_errors_not_crashes():
+    L = ts.lib()
+    h = C.c_void_p()
+    assert L.tsdf_create(None, C.byref(h)) == ts.E_BADARG
+    cfg = ts.default_config(m=1)
+    assert L.tsdf_create(C.byref(cfg), C.byref(h)) == ts.E_BADARG
+    cfg = ts.default_config(m=64)
+    cfg.slab_x0, cfg.slab_x1 = 40, 20
+    assert L.tsdf_create(C.byref(cfg), C.byref(h)) == ts.E_BADARG
+    assert L.tsdf_integrate(None, None) == ts.E_BADARG and L.tsdf_track(None, None) == ts.E_BADARG
+    assert b"bad slab" in L.tsdf_last_error(None)
+    assert L.tsdf_strerror(ts.E_HALO) == b"slab halo too small"
+
+
+def test_slab_ranges_partition_the_axis():
+    for m in (48, 64, 512, 2048):
+        for n in (1, 2, 3, 4, 8):
+            edges = [ts.slab_range(m, n, r) for r in range(n)]
+            assert edges[0][0] == 0 and edges[-1][1] == m
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(n - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ts.TsdfError):
+        ts.slab_range(64, 4, 4)
+
+
+def test_halo_covers_the_rotational_reach():
+    cfg = ts.default_config(m=512)
+    # w_h * range * m/width = 0.01 * 6 m * 85.33 voxel/m = 5.12 -> 6, + ceil(v_h) = 1, + 2 safety
+    assert ts.halo_for(cfg, 6.0) == 9
+    cfg = ts.default_config(m=2048)
+    assert ts.halo_for(cfg, 5.0) == int(np.ceil(0.01 * 5.0 * 2048 / 6.0)) + 1 + 2
+
+
+# ---- the product's host algebra against the oracle's (both restate Eigen; written independently)
+def test_host_pose_algebra_matches_oracle():
+    rng = np.random.default_rng(2)
+    s = orc.SDF(8, 8.0, 8.0, 8.0, (0, 0, 0), 0.3, 0.025)
+    t = orc.CameraTracking(s)
+    for _ in range(20):
+        q, _r = np.linalg.qr(rng.standard_normal((3, 3)))
+        tr = rng.standard_normal(3)
+        t.set_camera_transformation(q, tr)
+        ri, rit = ts.host_set_pose(q, tr)
+        assert np.array_equal(ri, t.rot_inv) and np.array_equal(rit, t.rot_inv_trans)
+        assert np.array_equal(ts.host_perturbed_rotations(q, 0.01), t.perturbed_rotations())
+
+
+def test_host_gn_step_matches_oracle_bit_for_bit():
+    rng = np.random.default_rng(3)
+    s = orc.SDF(8, 8.0, 8.0, 8.0, (0, 0, 0), 0.3, 0.025)
+    t = orc.CameraTracking(s)
+    for k in range(30):
+        J = rng.standard_normal((200, 6))
+        A = J.T @ J
+        b = J.T @ (rng.standard_normal(200) * (1e-3 if k % 2 else 1e-1))
+        rot0, trans0 = t.rot.copy(), t.trans.copy()
+        stop_o, tw_o = t.gn_update(A, b)
+        rot, trans, tw, stop = ts.host_gn_step(rot0, trans0, A, b, 0.001)
+        assert stop == stop_o and np.array_equal(tw, tw_o)
+        assert np.array_equal(rot, t.rot) and np.array_equal(trans, t.trans)
+    with pytest.raises(ts.TsdfError) as ei:
+        ts.host_gn_step(np.eye(3), np.zeros(3), np.zeros((6, 6)), np.ones(6))
+    assert ei.value.code == ts.E_SINGULAR
+    # signed stop rule (camera_tracking.cpp:216-224)
+    assert ts.host_gn_step(np.eye(3), np.zeros(3), np.eye(6), -np.ones(6))[3] is True
+    assert ts.host_gn_step(np.eye(3), np.zeros(3), np.eye(6), np.array([0, 0, 0, 0, 0, 0.002]))[3] is False

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/hotpath_m24.npz: small input/output vectors of the hot path.
+
+The reference ships no tests or golden vectors and cannot be built here (it needs ROS/PCL/Eigen/boost),
+so these vectors come from the CPU oracle (oracle/tsdf_oracle.c, itself pinned by the hand-derived KATs
+of tests/test_oracle_kat.py).  They serve two purposes: they freeze the oracle against regressions
+(CPU test) and they let the GPU parity test check the HIP path against committed data.
+
+Run from the repo root:  python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import oracle as orc                       # noqa: E402
+from tracking_sdf_amd import synth         # noqa: E402
+
+M, W, H = 24, 48, 36
+VOL = dict(width=2.0, height=3.4, depth=2.0, origin=(-1.0, -3.0, 0.0), delta=0.3, epsilon=0.025)
+
+
+def main():
+    seq = synth.Sequence(n_frames=3, width=W, height=H, noise=True, holes=0.04, step=6, seed=7)
+    frames = [seq.frame(k) for k in range(3)]
+    s = orc.SDF(M, VOL["width"], VOL["height"], VOL["depth"], VOL["origin"], VOL["delta"], VOL["epsilon"])
+    t = orc.CameraTracking(s, 20, 0.001, 1.0, 0.01)
+    t.set_K(seq.K)
+    out = {"K": seq.K, "R": seq.R, "t": seq.t, "m": np.int32(M)}
+    n_upd = []
+    for k in range(2):
+        xyz, nrm, rgb = frames[k]
+        out[f"xyz{k}"], out[f"nrm{k}"], out[f"rgb{k}"] = xyz, nrm, rgb
+        t.set_camera_transformation(seq.R[k], seq.t[k])
+        n_upd.append(s.update(t, orc.Cloud(xyz, nrm, rgb), with_color=True, threads=1))
+    out["n_updated"] = np.array(n_upd, dtype=np.int64)
+    for name in ("D", "W", "Color_W", "R", "G", "B"):
+        out["vol_" + name] = getattr(s, name).copy()
+    xyz2 = frames[2][0]
+    out["xyz2"] = xyz2
+    cloud = orc.Cloud(xyz2)
+    # interpolation probes
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-1.5, M + 0.5, size=(512, 3))
+    pts[:64] = np.round(pts[:64])
+    vals, oks = [], []
+    for p in pts:
+        v, ok = s.interpolate_distance(p)
+        vals.append(v)
+        oks.append(ok)
+    out["probe_pts"], out["probe_val"], out["probe_ok"] = pts, np.array(vals, dtype=np.float32), np.array(oks)
+    # one accumulation at the previous pose (what the tracker sees when frame 2 arrives)
+    t.set_camera_transformation(seq.R[1], seq.t[1])
+    for flag in (1, 0):
+        A, b, st = t.accumulate(s, cloud, threads=1, stale_carry=bool(flag))
+        out[f"A_stale{flag}"], out[f"b_stale{flag}"] = A, b
+        out[f"acc_stats_stale{flag}"] = np.array([st[k] for k in ("n_samples", "n_nan", "n_oog", "n_fail", "n_ok", "n_terms")],
+                                                  dtype=np.int64)
+    st = t.estimate_new_position(s, cloud, threads=1, stale_carry=True)
+    out["track_iterations"] = np.int32(st["iterations"])
+    out["track_stopped"] = np.int32(st["stopped"])
+    out["track_rot"], out["track_trans"], out["track_twist"] = t.rot, t.trans, st["last_twist"]
+    dst = os.path.join(ROOT, "tests", "golden", "hotpath_m24.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes;", "updated", n_upd, "iterations", st["iterations"],
+          "terms", out["acc_stats_stale1"][-1], out["acc_stats_stale0"][-1])
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ ABI_SYMBOLS = (
     "tsdf_set_frame_device", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
-    "tsdf_allreduce", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
+    "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
 
 _lib = None
@@ -145,6 +145,9 @@ def lib():
         "tsdf_comm_finalize": (C.c_int, [H]),
         "tsdf_set_allreduce_hook": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
         "tsdf_allreduce": (C.c_int, [H, dp, C.c_int32]),
+        "tsdf_host_set_pose": (C.c_int, [dp, dp, dp, dp]),
+        "tsdf_host_perturbed_rotations": (C.c_int, [dp, C.c_float, dp]),
+        "tsdf_host_gn_step": (C.c_int, [dp, dp, dp, dp, C.c_float, dp, ip]),
         "tsdf_set_timing": (C.c_int, [H, C.c_int32]),
         "tsdf_read_timing": (C.c_int, [H, C.POINTER(Timing), C.c_int32]),
         "tsdf_read_counters": (C.c_int, [H, C.POINTER(Counters), C.c_int32]),
@@ -186,6 +189,33 @@ def halo_for(cfg: Config, max_range: float) -> int:
 
 def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def host_set_pose(rot, trans):
+    """(rot_inv, rot_inv_trans) as CameraTracking::set_camera_transformation computes them (host only)."""
+    r, t, ri, rit = _d(rot, 9), _d(trans, 3), np.zeros(9), np.zeros(3)
+    rc = lib().tsdf_host_set_pose(_dptr(r), _dptr(t), _dptr(ri), _dptr(rit))
+    if rc:
+        raise TsdfError(rc, "tsdf_host_set_pose")
+    return ri.reshape(3, 3), rit
+
+
+def host_perturbed_rotations(rot, w_h):
+    r, out = _d(rot, 9), np.zeros(54)
+    rc = lib().tsdf_host_perturbed_rotations(_dptr(r), float(w_h), _dptr(out))
+    if rc:
+        raise TsdfError(rc, "tsdf_host_perturbed_rotations")
+    return out.reshape(6, 3, 3)
+
+
+def host_gn_step(rot, trans, A, b, max_twist_diff=0.001):
+    """One Gauss-Newton pose update on the host: returns (rot, trans, twist, stop); raises on a singular system."""
+    r, t = _d(rot, 9).copy(), _d(trans, 3).copy()
+    a, bb, tw, stop = _d(A, 36), _d(b, 6), np.zeros(6), C.c_int32(0)
+    rc = lib().tsdf_host_gn_step(_dptr(r), _dptr(t), _dptr(a), _dptr(bb), float(max_twist_diff), _dptr(tw), C.byref(stop))
+    if rc:
+        raise TsdfError(rc, lib().tsdf_strerror(rc).decode())
+    return r.reshape(3, 3), t, tw, bool(stop.value)
 
 
 def _fptr(a):

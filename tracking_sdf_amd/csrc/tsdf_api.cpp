@@ -814,6 +814,40 @@ int tsdf_allreduce(tsdf_handle* h, double* buf, int32_t n) {
     return TSDF_OK;
 }
 
+// ---- host-only algebra ---------------------------------------------------------------------------------
+
+int tsdf_host_set_pose(const double rot[9], const double trans[3], double rot_inv[9], double rot_inv_trans[3]) {
+    if (!rot || !trans || !rot_inv || !rot_inv_trans) return TSDF_E_BADARG;
+    hm::Pose P;
+    hm::set_pose(P, rot, trans);
+    std::memcpy(rot_inv, P.rot_inv, sizeof P.rot_inv);
+    std::memcpy(rot_inv_trans, P.rot_inv_trans, sizeof P.rot_inv_trans);
+    return TSDF_OK;
+}
+
+int tsdf_host_perturbed_rotations(const double rot[9], float w_h, double rpm[54]) {
+    if (!rot || !rpm) return TSDF_E_BADARG;
+    hm::Pose P;
+    std::memcpy(P.rot, rot, sizeof P.rot);
+    hm::perturbed_rotations(P, w_h, rpm);
+    return TSDF_OK;
+}
+
+int tsdf_host_gn_step(double rot[9], double trans[3], const double A[36], const double b[6],
+                      float max_twist_diff, double twist[6], int32_t* stop) {
+    if (!rot || !trans || !A || !b) return TSDF_E_BADARG;
+    hm::Pose P;
+    hm::set_pose(P, rot, trans);
+    double tw[6];
+    bool st = false;
+    if (!hm::gn_step(P, A, b, max_twist_diff, tw, &st)) return TSDF_E_SINGULAR;
+    std::memcpy(rot, P.rot, sizeof P.rot);
+    std::memcpy(trans, P.trans, sizeof P.trans);
+    if (twist) std::memcpy(twist, tw, sizeof tw);
+    if (stop) *stop = st ? 1 : 0;
+    return TSDF_OK;
+}
+
 // ---- measurement -------------------------------------------------------------------------------------
 
 int tsdf_set_timing(tsdf_handle* h, int32_t on) {
