@@ -34,3 +34,9 @@ clean:
 	rm -f $(LIB)
 	$(MAKE) -C $(ROOT)oracle clean
 .PHONY: all oracle asm clean
+
+# C++ example of the drop-in shim (include/sdf_3d_reconstruction/hotpath.hpp): plain g++, links the C ABI only
+shim_demo: $(LIB)
+	@mkdir -p $(ROOT)build
+	g++ -std=c++17 -O2 -Wall -Wextra -o $(ROOT)build/shim_demo $(ROOT)tools/shim_demo.cpp -L$(LIBDIR) -ltsdf_hip -Wl,-rpath,$(LIBDIR)
+.PHONY: shim_demo

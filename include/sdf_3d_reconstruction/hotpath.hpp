@@ -1,0 +1,191 @@
+// hotpath.hpp -- header-only C++ shim that keeps the reference's two hot-path classes, `SDF` and
+// `CameraTracking`, with their method names and argument order, on top of the C ABI of tsdf.h.
+//
+// It is what a maintainer of mees/tracking_sdf would include from sdf_reconstruction.cpp instead of
+// sdf.h / camera_tracking.h to run the per-frame hot path on an MI355X.  Eigen and
+// PCL are not required: matrices are plain row-major arrays (`Mat3`, `Vec3`), clouds are the small
+// `OrganizedCloud` / `NormalCloud` views below.  With -DTSDF_WITH_EIGEN_PCL (and those headers on the
+// include path) overloads taking the reference's exact types are compiled as well.
+//
+// Reference interfaces mirrored (paths relative to the reference's src/):
+//   SDF::SDF(m, width, height, depth, origin, delta, epsilon)           include/sdf_3d_reconstruction/sdf.h:78-79
+//   SDF::update(CameraTracking*, cloud_filtered, normals)               sdf.h:161-163
+//   SDF::interpolate_distance(voxel_coordinates, is_interpolated)       sdf.h:86
+//   SDF::m, m_div_width/height/depth, get_number_of_voxels()            sdf.h:69-72,107
+//   CameraTracking::CameraTracking(max_iter, max_twist_diff, v_h, w_h, sdf)   camera_tracking.cpp:3-4 (definition order)
+//   CameraTracking::estimate_new_position(sdf, point_cloud)             camera_tracking.h:101
+//   CameraTracking::set_camera_transformation(rot, trans)               camera_tracking.h:84
+//   CameraTracking::camera_info_cb -> set_K(K)                          camera_tracking.cpp:22-36
+//   public rot, trans, rot_inv, rot_inv_trans, K, isKFilled             camera_tracking.h:43-59
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../tsdf.h"
+
+namespace tsdf_shim {
+
+using Vec3 = std::array<double, 3>;
+using Mat3 = std::array<double, 9>;   // row-major
+
+// Non-owning views of the two inputs of the hot calls (PCL's organised clouds: at(col,row) = [row*width+col]).
+struct OrganizedCloud {
+    const float* xyz = nullptr;      // height*width*3, NaN = no depth
+    const uint8_t* rgb = nullptr;    // height*width*3 (r,g,b), may be null
+    int32_t width = 0, height = 0;
+};
+struct NormalCloud {
+    const float* normal = nullptr;   // height*width*3, NaN = undefined
+    int32_t width = 0, height = 0;
+};
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+class CameraTracking;
+
+class SDF {
+public:
+    int m;
+    float m_div_height, m_div_width, m_div_depth;
+
+    // standard constructor (sdf.h:78-79); `base` lets the caller override placement / colour / tracker steps
+    SDF(int m_, float width, float height, float depth, const Vec3& sdf_origin, float distance_delta,
+        float distance_epsilon, const tsdf_config* base = nullptr)
+        : m(m_), m_div_height(m_ / height), m_div_width(m_ / width), m_div_depth(m_ / depth) {
+        tsdf_config cfg;
+        if (base) cfg = *base; else tsdf_default_config(&cfg);
+        cfg.m = m_; cfg.width = width; cfg.height = height; cfg.depth = depth;
+        cfg.origin[0] = sdf_origin[0]; cfg.origin[1] = sdf_origin[1]; cfg.origin[2] = sdf_origin[2];
+        cfg.delta = distance_delta; cfg.epsilon = distance_epsilon;
+        const int rc = tsdf_create(&cfg, &h_);
+        if (rc != TSDF_OK) throw Error(rc, std::string("tsdf_create: ") + tsdf_last_error(nullptr));
+    }
+    ~SDF() { tsdf_destroy(h_); }
+    SDF(const SDF&) = delete;
+    SDF& operator=(const SDF&) = delete;
+
+    int get_number_of_voxels() const { return m * m * m; }
+
+    // sdf.h:161-163.  The tracker argument is kept for signature compatibility: pose and intrinsics live
+    // in the same native handle.
+    inline void update(CameraTracking* camera_tracking, const OrganizedCloud& cloud_filtered, const NormalCloud& normals);
+
+    // sdf.h:86
+    float interpolate_distance(const Vec3& voxel_coordinates, bool& is_interpolated) const {
+        float val = 0.f;
+        int32_t ok = 0;
+        check(tsdf_sample(h_, voxel_coordinates.data(), 1, &val, &ok), "tsdf_sample");
+        is_interpolated = ok != 0;
+        return val;
+    }
+
+    // host mirrors of D / W for a mesher (the reference hands raw pointers to MarchingCubesSDF, sdf.cpp:47-49)
+    void download(std::vector<float>& D, std::vector<float>& W) const {
+        tsdf_config c;
+        tsdf_get_config(h_, &c);
+        const size_t n = (size_t)(c.slab_x1 - c.slab_x0) * m * m;
+        D.resize(n); W.resize(n);
+        check(tsdf_download(h_, D.data(), W.data()), "tsdf_download");
+    }
+
+    tsdf_handle* handle() const { return h_; }
+    void check(int rc, const char* what) const {
+        if (rc != TSDF_OK) throw Error(rc, std::string(what) + ": " + tsdf_last_error(h_));
+    }
+
+private:
+    tsdf_handle* h_ = nullptr;
+};
+
+class CameraTracking {
+public:
+    Mat3 rot{}, rot_inv{}, K{};
+    Vec3 trans{}, rot_inv_trans{};
+    bool isKFilled = false;
+
+    // definition order of the reference: (gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf)
+    CameraTracking(int gauss_newton_max_iteration, float maximum_twist_diff, float v_h, float w_h, SDF* sdf)
+        : sdf_(sdf) {
+        tsdf_config c;
+        tsdf_get_config(sdf->handle(), &c);
+        if (c.gn_max_iter != gauss_newton_max_iteration || c.max_twist_diff != maximum_twist_diff || c.v_h != v_h ||
+            c.w_h != w_h)
+            throw Error(TSDF_E_BADARG, "CameraTracking: constants differ from the ones the SDF handle was created with "
+                                       "(pass them through the tsdf_config given to SDF)");
+        sync();
+    }
+
+    void set_K(const Mat3& k) {              // camera_info_cb, camera_tracking.cpp:22-36
+        K = k;
+        sdf_->check(tsdf_set_intrinsics(sdf_->handle(), K.data()), "tsdf_set_intrinsics");
+        isKFilled = true;
+    }
+    void set_camera_transformation(const Mat3& r, const Vec3& t) {   // camera_tracking.cpp:59-65
+        sdf_->check(tsdf_set_camera_transformation(sdf_->handle(), r.data(), t.data()), "tsdf_set_camera_transformation");
+        sync();
+    }
+    // camera_tracking.h:101; on a singular system / no samples the pose is left unchanged and Error is thrown
+    // (the reference silently continues with a NaN pose, camera_tracking.cpp:191)
+    void estimate_new_position(const SDF* sdf, const OrganizedCloud& point_cloud, tsdf_track_stats* stats = nullptr) {
+        sdf->check(tsdf_set_frame(sdf->handle(), point_cloud.xyz, nullptr, point_cloud.rgb, point_cloud.width,
+                                  point_cloud.height), "tsdf_set_frame");
+        const int rc = tsdf_track(sdf->handle(), stats);
+        sync();
+        sdf->check(rc, "tsdf_track");
+    }
+    void sync() {
+        tsdf_get_pose(sdf_->handle(), rot.data(), trans.data(), rot_inv.data(), rot_inv_trans.data());
+    }
+
+private:
+    SDF* sdf_;
+};
+
+inline void SDF::update(CameraTracking* camera_tracking, const OrganizedCloud& cloud_filtered, const NormalCloud& normals) {
+    (void)camera_tracking;
+    check(tsdf_set_frame(h_, cloud_filtered.xyz, normals.normal, cloud_filtered.rgb, cloud_filtered.width,
+                         cloud_filtered.height), "tsdf_set_frame");
+    check(tsdf_integrate(h_, nullptr), "tsdf_integrate");      // reference: exit(0) when K is missing (sdf.cpp:227-230)
+}
+
+}  // namespace tsdf_shim
+
+#ifdef TSDF_WITH_EIGEN_PCL
+// Adapters for the reference's exact argument types.  Compiled only where Eigen and PCL exist (they do
+// not in the build container): they repack PCL's 32-byte AoS points into the planes the C ABI takes.
+#include <Eigen/Core>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+namespace tsdf_shim {
+struct PclFrame {
+    std::vector<float> xyz, nrm;
+    std::vector<uint8_t> rgb;
+    OrganizedCloud cloud;
+    NormalCloud normals;
+    PclFrame(const pcl::PointCloud<pcl::PointXYZRGB>& c, const pcl::PointCloud<pcl::Normal>* n) {
+        const size_t np = (size_t)c.width * c.height;
+        xyz.resize(np * 3); rgb.resize(np * 3);
+        for (size_t i = 0; i < np; ++i) {
+            const auto& p = c.points[i];
+            xyz[3 * i] = p.x; xyz[3 * i + 1] = p.y; xyz[3 * i + 2] = p.z;
+            rgb[3 * i] = p.r; rgb[3 * i + 1] = p.g; rgb[3 * i + 2] = p.b;
+        }
+        cloud = {xyz.data(), rgb.data(), (int32_t)c.width, (int32_t)c.height};
+        if (n) {
+            nrm.resize(np * 3);
+            for (size_t i = 0; i < np; ++i) {
+                nrm[3 * i] = n->points[i].normal_x; nrm[3 * i + 1] = n->points[i].normal_y; nrm[3 * i + 2] = n->points[i].normal_z;
+            }
+            normals = {nrm.data(), (int32_t)c.width, (int32_t)c.height};
+        }
+    }
+};
+}  // namespace tsdf_shim
+#endif

@@ -1,0 +1,64 @@
+"""The C++ shim (include/sdf_3d_reconstruction/hotpath.hpp) driven like the reference's frame loop.
+
+CPU: the demo compiles with plain g++ against the C ABI (no HIP headers, no Eigen/PCL).
+GPU: it runs the reference's sequencing (frame 1 integrate only, then track -> write pose -> integrate,
+sdf_reconstruction.cpp:69-74) and its trajectory file matches the oracle's poses.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def build_demo():
+    subprocess.check_call(["make", "-C", ROOT, "-s", "shim_demo"])
+    return os.path.join(ROOT, "build", "shim_demo")
+
+
+def test_shim_demo_compiles_with_plain_gxx():
+    exe = build_demo()
+    assert os.access(exe, os.X_OK)
+    # header must be self-contained C++17 without HIP / Eigen / PCL
+    src = "#include \"sdf_3d_reconstruction/hotpath.hpp\"\nint main(){ tsdf_config c; tsdf_default_config(&c); return c.m == 256 ? 0 : 1; }\n"
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++", "-"],
+                       input=src, text=True, capture_output=True)
+    assert p.returncode == 0, p.stderr
+
+
+@pytest.mark.gpu
+def test_shim_demo_frame_loop_matches_oracle(tmp_path):
+    import oracle as orc
+    from dump_frames import dump
+    exe = build_demo()
+    frames_bin = str(tmp_path / "frames.bin")
+    traj = str(tmp_path / "trajectory.txt")
+    n, w, h, m = 5, 160, 120, 64
+    seq = dump(frames_bin, n=n, width=w, height=h, step=2)
+    p = subprocess.run([exe, frames_bin, str(m), traj], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = np.loadtxt(traj)
+    assert got.shape == (n - 1, 8)
+    # the same loop on the oracle
+    oo = orc.SDF(m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025)
+    ot = orc.CameraTracking(oo)
+    ot.set_K(seq.K)
+    want = []
+    for k in range(n):
+        xyz, nrm, rgb = seq.frame(k)
+        cloud = orc.Cloud(xyz, nrm, rgb)
+        if k > 0:
+            ot.estimate_new_position(oo, cloud, threads=1, stale_carry=True)
+            want.append(ot.trans.copy())
+        oo.update(ot, cloud)
+    want = np.array(want)
+    assert np.allclose(got[:, 0], seq.stamps[1:], atol=1e-4)
+    assert np.max(np.abs(got[:, 1:4] - want)) <= 5.1e-5          # file has 4 decimals
+    final = [float(x) for x in p.stdout.strip().split("=")[1].split()]
+    assert np.max(np.abs(np.array(final) - want[-1])) < 1e-6
+    # the quaternion columns come from a det = -1 matrix (camera_tracking.cpp:7): only finiteness is meaningful
+    assert np.all(np.isfinite(got[:, 4:8]))
