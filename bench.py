@@ -305,6 +305,14 @@ def main():
                                "avg_pass_wall_ms": 1e3 * track_wall[0] / max(1, cn["track_iterations"]),
                                "achieved_GBs_on_832B_per_sample": 832.0 * cn["track_in_grid"] / max(1e-9, track_wall[0]) / 1e9},
         }
+        # HBM traffic of the integrate launch from the committed rocprofv3 --pmc passes (bench.py cannot collect
+        # PMC counters itself); only meaningful for the default workload
+        pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
+        if os.path.exists(pmc) and args.m == 512 and (args.width, args.height) == (640, 480) and not args.no_color \
+                and world == 1:
+            with open(pmc) as f:
+                out["roofline"]["traffic"] = json.load(f)["integrate_launch_traffic_bytes"]
+            out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
         if args.trajectory_out:
             with open(args.trajectory_out, "w") as f:
                 for k in range(1, len(est)):
