@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--max-range", type=float, default=6.0, help="metres; sizes the slab halo")
     ap.add_argument("--cpu-baseline-frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allreduce", choices=["auto", "rccl", "torch"], default="auto")
+    ap.add_argument("--allreduce", choices=["auto", "rccl", "shm", "torch"], default="auto",
+                    help="auto = in-library RCCL, else torch hook; shm = shared-memory fan-in (one node)")
     ap.add_argument("--host-frames", action="store_true", help="hand frames over as HOST buffers every step (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--trajectory-out", default=None, help="write the estimated trajectory (TUM format)")
@@ -204,6 +205,13 @@ def main():
                 allreduce_kind = "rccl-in-library"
             elif rank == 0:
                 print("[bench] in-library RCCL unavailable; using the torch.distributed hook", file=sys.stderr)
+        if want == "shm":
+            names = [f"/tsdf_{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}"]
+            dist.broadcast_object_list(names, 0)
+            sdf.comm_init_shm(world, rank, names[0])
+            dist.barrier()
+            ok = True
+            allreduce_kind = "shared-memory fan-in"
         if not ok:
             if want == "rccl":
                 raise SystemExit("--allreduce rccl requested but the in-library communicator failed")

@@ -162,6 +162,11 @@ int32_t tsdf_halo_for(const tsdf_config *cfg, float max_range);
  * (torch.distributed / MPI / a file), every rank calls tsdf_comm_init. */
 int tsdf_comm_unique_id(void *id128);
 int tsdf_comm_init(tsdf_handle *h, int32_t nranks, int32_t rank, const void *id128);
+/* Alternative for ranks on ONE node: every rank's final kernel writes its 34-double row + pass number into
+ * its slot of a POSIX shared-memory segment (`name`, created on first use; pinned with hipHostRegister), and
+ * every rank's host sums the slots in rank order.  No GPU collective, no stream synchronisation, bitwise
+ * deterministic; costs one PCIe write per pass.  `name` must be unique per job (e.g. contain the master port). */
+int tsdf_comm_init_shm(tsdf_handle *h, int32_t nranks, int32_t rank, const char *name);
 int tsdf_comm_finalize(tsdf_handle *h);                          /* drop the RCCL communicator (hook, if any, takes over) */
 /* Alternative: let the host do the 28-double sum (e.g. torch.distributed); fn = NULL removes it. */
 int tsdf_set_allreduce_hook(tsdf_handle *h, tsdf_allreduce_fn fn, void *ctx);
@@ -204,6 +209,7 @@ typedef struct tsdf_counters {
     int64_t track_iterations;   /* Gauss-Newton passes                                                 */
     int64_t track_in_grid;      /* owned in-grid samples over all passes (each does <= 13 look-ups)    */
     int64_t track_terms;
+    int64_t integrate_items;    /* 64-voxel work items the row clip produced (each is one 512-byte {D,W} segment) */
 } tsdf_counters;
 int tsdf_set_timing(tsdf_handle *h, int32_t on);
 int tsdf_read_timing(tsdf_handle *h, tsdf_timing *out, int32_t reset);

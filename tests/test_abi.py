@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ts.Config) == 96
     assert ts.Config.origin.offset == 16 and ts.Config.delta.offset == 40 and ts.Config.device.offset == 88
     assert C.sizeof(ts.IntegrateStats) == 24 and C.sizeof(ts.AccumStats) == 48
-    assert C.sizeof(ts.TrackStats) == 64 and C.sizeof(ts.Timing) == 48 and C.sizeof(ts.Counters) == 64
+    assert C.sizeof(ts.TrackStats) == 64 and C.sizeof(ts.Timing) == 48 and C.sizeof(ts.Counters) == 72
 
 
 def test_default_config_is_the_reference_constants():

@@ -1,0 +1,66 @@
+"""Two ranks (two processes) on the one GPU of the test box: x-slab sharding end to end through bench.py.
+
+RCCL refuses two ranks on one device, so the exchange step runs through the shared-memory fan-in and
+through the torch.distributed (gloo) hook; the in-library RCCL path is exercised with a 1-rank communicator.
+The sharded runs must reproduce the single-rank trajectory.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--m", "128", "--width", "320", "--height", "240", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+          "--frame-step", "3"]
+
+
+def run_bench(extra, nproc, traj, port):
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + COMMON + ["--trajectory-out", traj] + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+               "--gpus", str(nproc), "--dist-backend", "gloo", "--trajectory-out", traj] + COMMON + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line), np.loadtxt(traj)
+
+
+@pytest.mark.parametrize("mode,nproc", [("shm", 2), ("torch", 2), ("shm", 3)])
+def test_sharded_bench_reproduces_single_rank_trajectory(tmp_path, mode, nproc):
+    j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
+    jn, tn = run_bench(["--allreduce", mode], nproc, str(tmp_path / "tn.txt"), 29600 + nproc + (7 if mode == "shm" else 0))
+    assert jn["n_gpus"] == nproc and jn["config"]["halo"] > 0
+    assert ("shared-memory" in jn["config"]["allreduce"]) == (mode == "shm")
+    assert t1.shape == tn.shape and np.array_equal(t1, tn)          # 4-decimal TUM lines, identical
+    assert abs(jn["ate_rmse_m"] - j1["ate_rmse_m"]) < 1e-9
+    assert jn["gn_iterations_per_frame"] == j1["gn_iterations_per_frame"]
+
+
+def test_rccl_path_in_tracker_with_one_rank():
+    import ctypes
+    import tracking_sdf_amd as ts
+    from tracking_sdf_amd import synth
+    seq = synth.Sequence(n_frames=3, width=160, height=120, noise=True, step=3)
+    poses = []
+    for use_comm in (False, True):
+        s = ts.SDF(64)
+        t = ts.CameraTracking(sdf=s)
+        t.set_K(seq.K)
+        if use_comm:
+            buf = ctypes.create_string_buffer(128)
+            assert ts.lib().tsdf_comm_unique_id(buf) == 0
+            s.comm_init(1, 0, buf.raw)
+        for k in range(3):
+            xyz, nrm, rgb = seq.frame(k)
+            if k > 0:
+                t.estimate_new_position(s, xyz)
+            s.update(t, xyz, nrm, rgb)
+        poses.append((t.rot.copy(), t.trans.copy()))
+        s.close()
+    assert np.array_equal(poses[0][0], poses[1][0]) and np.array_equal(poses[0][1], poses[1][1])

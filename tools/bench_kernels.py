@@ -63,7 +63,8 @@ def main():
     upd = cn["n_updated"] / tm["integrate_launches"]
     out = {"m": args.m, "integrate_ms": ms, "updated_per_launch": upd,
            "integrate_GBs": (bpv * upd + args.width * args.height * 32) / (ms * 1e-3) / 1e9,
-           "pack_ms": tm["pack_ms"] / max(1, tm["pack_launches"])}
+           "pack_ms": tm["pack_ms"] / max(1, tm["pack_launches"]),
+           "items_per_launch": cn["integrate_items"] / tm["integrate_launches"]}
     # tracker passes at a perturbed pose (not applied: accumulate only)
     k = args.frames - 1
     trk.set_camera_transformation(seq.R[k], seq.t[k] + np.array([0.01, -0.01, 0.005]))

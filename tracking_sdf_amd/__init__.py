@@ -64,7 +64,7 @@ class Timing(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("n_updated", C.c_int64), ("n_updated_halo", C.c_int64), ("n_voxels_swept", C.c_int64),
                 ("integrate_calls", C.c_int64), ("track_calls", C.c_int64), ("track_iterations", C.c_int64),
-                ("track_in_grid", C.c_int64), ("track_terms", C.c_int64)]
+                ("track_in_grid", C.c_int64), ("track_terms", C.c_int64), ("integrate_items", C.c_int64)]
 
 
 def _struct_dict(s):
@@ -83,7 +83,7 @@ ABI_SYMBOLS = (
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_set_frame_device", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset",
-    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
+    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
 
@@ -142,6 +142,7 @@ def lib():
         "tsdf_halo_for": (C.c_int32, [C.POINTER(Config), C.c_float]),
         "tsdf_comm_unique_id": (C.c_int, [C.c_void_p]),
         "tsdf_comm_init": (C.c_int, [H, C.c_int32, C.c_int32, C.c_void_p]),
+        "tsdf_comm_init_shm": (C.c_int, [H, C.c_int32, C.c_int32, C.c_char_p]),
         "tsdf_comm_finalize": (C.c_int, [H]),
         "tsdf_set_allreduce_hook": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
         "tsdf_allreduce": (C.c_int, [H, dp, C.c_int32]),
@@ -369,6 +370,9 @@ class SDF:
     def comm_init(self, nranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(lib().tsdf_comm_init(self._h, nranks, rank, buf))
+
+    def comm_init_shm(self, nranks, rank, name: str):
+        self._check(lib().tsdf_comm_init_shm(self._h, nranks, rank, name.encode()))
 
     def comm_finalize(self):
         self._check(lib().tsdf_comm_finalize(self._h))

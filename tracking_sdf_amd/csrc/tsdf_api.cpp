@@ -6,6 +6,11 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -74,6 +79,15 @@ struct tsdf_handle {
     rccl::Comm comm;
     tsdf_allreduce_fn hook = nullptr;
     void* hook_ctx = nullptr;
+    // shared-memory fan-in (ranks of one node): nranks x 2 slots (double-buffered by pass parity)
+    struct Shm {
+        int nranks = 0, rank = 0;
+        char* base = nullptr;        // host mapping
+        char* dev_base = nullptr;    // device-visible alias (hipHostRegister)
+        size_t bytes = 0;
+        std::string name;
+        bool active() const { return base != nullptr; }
+    } shm;
 
     // measurement
     bool timing = false;           // events around the integrate / pack launches (asynchronous, drained on read)
@@ -247,33 +261,72 @@ void fill_track_params(const tsdf_handle* h, TrackParams& p) {
     p.stale_carry = h->cfg.stale_carry;
 }
 
+constexpr size_t kShmSlot = 512;   // bytes per (rank, parity) slot: 34 doubles + the pass-number word, padded
+
+void shm_close(tsdf_handle* h) {
+    if (!h->shm.active()) return;
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipHostUnregister(h->shm.base);
+    munmap(h->shm.base, h->shm.bytes);
+    if (h->shm.rank == 0) shm_unlink(h->shm.name.c_str());
+    h->shm.base = h->shm.dev_base = nullptr;
+    h->shm.nranks = 0;
+}
+
 // Launch one accumulation pass and wait for its kRedWidth-double result row in h->red_host.
 // reduce_ranks: sum the leading kRedAllreduce entries over ranks (RCCL on the device buffer, or hook).
 int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     TrackParams p;
     fill_track_params(h, p);
     const bool use_rccl = reduce_ranks && h->comm.active();
+    const bool use_shm = reduce_ranks && !use_rccl && h->shm.active();
     const unsigned long long seq = ++h->pass_seq;
+    double* host_row = h->red_host;          // where the final kernel publishes this rank's row
+    if (use_shm)
+        host_row = reinterpret_cast<double*>(h->shm.dev_base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot);
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
     HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
-                            use_rccl ? nullptr : h->red_host, seq));
+                            use_rccl ? nullptr : host_row, seq));
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
-    bool arrived = false;
     if (use_rccl) {
         std::string cerr;
         if (!h->comm.allreduce_sum_f64(h->red_dev, kRedAllreduce, h->stream, &cerr))
             return fail(h, TSDF_E_COMM, "RCCL all-reduce failed: %s", cerr.c_str());
-        HIP_TRY(h, hipMemcpyAsync(h->red_host, h->red_dev, kRedWidth * sizeof(double), hipMemcpyDeviceToHost,
-                                  h->stream));
+        if (h->poll) HIP_TRY(h, launch_track_publish(h->stream, h->red_dev, h->red_host, seq));
+        else HIP_TRY(h, hipMemcpyAsync(h->red_host, h->red_dev, kRedWidth * sizeof(double), hipMemcpyDeviceToHost,
+                                       h->stream));
+    }
+    bool arrived = false;
+    if (use_shm) {
+        // fan-in: wait for every rank's row of THIS pass (slots are double-buffered by pass parity: a rank can
+        // only overwrite its pass-s slot when publishing pass s+2, which needs everybody's pass s+1 row, which
+        // nobody publishes before having read all pass-s rows), then add them in rank order.
+        double sum[kRedAllreduce];
+        for (int e = 0; e < kRedAllreduce; ++e) sum[e] = 0.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < h->shm.nranks; ++r) {
+            const char* slot = h->shm.base + ((size_t)r * 2 + (seq & 1ull)) * kShmSlot;
+            const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(slot + kRedWidth * sizeof(double));
+            for (unsigned spins = 0;; ++spins) {
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+                    return fail(h, TSDF_E_COMM, "shared-memory fan-in: rank %d did not publish pass %llu within 20 s", r, seq);
+            }
+            const double* row = reinterpret_cast<const double*>(slot);
+            for (int e = 0; e < kRedAllreduce; ++e) sum[e] += row[e];
+            if (r == h->shm.rank) std::memcpy(h->red_host, row, kRedWidth * sizeof(double));
+        }
+        std::memcpy(h->red_host, sum, sizeof sum);
+        arrived = true;
     } else if (h->poll) {
-        // The final kernel publishes the pass number after the row (system-scope release); spinning on it
-        // saves the runtime's completion-signal path.  Bounded: fall back to a real synchronisation.
+        // The final (or publish) kernel releases the pass number after the row (system scope); spinning on
+        // it saves the runtime's completion-signal path.  Bounded: fall back to a real synchronisation.
         volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(h->red_host + kRedWidth);
         const auto t0 = std::chrono::steady_clock::now();
+        const auto limit = std::chrono::milliseconds(use_rccl ? 2000 : 5);
         for (unsigned spins = 0;; ++spins) {
             if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
-            if ((spins & 1023u) == 1023u &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > limit) break;
         }
     }
     if (!arrived) HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -291,7 +344,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     h->cnt.track_iterations++;
     h->cnt.track_in_grid += (int64_t)h->red_host[30];
     h->cnt.track_terms += (int64_t)h->red_host[27];
-    if (reduce_ranks && !use_rccl && h->hook) {
+    if (reduce_ranks && !use_rccl && !use_shm && h->hook) {
         if (h->hook(h->red_host, kRedAllreduce, h->hook_ctx) != 0)
             return fail(h, TSDF_E_COMM, "all-reduce hook reported failure");
     }
@@ -466,6 +519,7 @@ void tsdf_destroy(tsdf_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->comm.destroy();
+    shm_close(h);
     free_frame(h);
     if (h->pn) (void)hipFree(h->pn);
     if (h->samples) (void)hipFree(h->samples);
@@ -781,11 +835,37 @@ int tsdf_comm_init(tsdf_handle* h, int32_t nranks, int32_t rank, const void* id1
     return TSDF_OK;
 }
 
+int tsdf_comm_init_shm(tsdf_handle* h, int32_t nranks, int32_t rank, const char* name) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!name || nranks <= 0 || rank < 0 || rank >= nranks) return fail(h, TSDF_E_BADARG, "tsdf_comm_init_shm: bad argument");
+    shm_close(h);
+    const size_t bytes = (size_t)nranks * 2 * kShmSlot;
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) return fail(h, TSDF_E_COMM, "shm_open(%s) failed", name);
+    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return fail(h, TSDF_E_COMM, "ftruncate(%s) failed", name); }
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(h, TSDF_E_COMM, "mmap(%s) failed", name);
+    hipError_t e = hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    void* dptr = nullptr;
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, m, 0);
+    if (e != hipSuccess) {
+        munmap(m, bytes);
+        return fail(h, TSDF_E_HIP, "hipHostRegister of the shared segment failed: %s", hipGetErrorString(e));
+    }
+    h->shm.nranks = nranks; h->shm.rank = rank; h->shm.base = (char*)m; h->shm.dev_base = (char*)dptr;
+    h->shm.bytes = bytes; h->shm.name = name;
+    h->pass_seq = 0;               // every rank counts passes from the same origin
+    return TSDF_OK;
+}
+
 int tsdf_comm_finalize(tsdf_handle* h) {
     int rc = check_ready(h, false);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->comm.destroy();
+    shm_close(h);
     return TSDF_OK;
 }
 
@@ -877,6 +957,7 @@ int tsdf_read_counters(tsdf_handle* h, tsdf_counters* out, int32_t reset) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->cnt.n_updated = (int64_t)(h->counters_host[kCntUpdatedOwned] - h->cnt_base[kCntUpdatedOwned]);
     h->cnt.n_updated_halo = (int64_t)(h->counters_host[kCntUpdatedHalo] - h->cnt_base[kCntUpdatedHalo]);
+    h->cnt.integrate_items = (int64_t)(h->counters_host[kCntItems] - h->cnt_base[kCntItems]);
     if (out) *out = h->cnt;
     if (reset) {
         for (int i = 0; i < kNumCounters; ++i) h->cnt_base[i] = h->counters_host[i];

@@ -57,7 +57,7 @@ struct TrackParams {
 };
 
 // cumulative device counters (unsigned long long each)
-enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntSwept = 2, kNumCounters = 4 };
+enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntItems = 2, kNumCounters = 4 };
 
 hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0);
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
@@ -75,6 +75,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
 // be null): kRedWidth doubles + one 64-bit word that receives `seq` after the row is complete.
 hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                         double* partials, double* red_dev, double* red_host, unsigned long long seq);
+hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);
 size_t track_partials_doubles(int32_t n_samples);
 hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const double* vox, int32_t n,

@@ -153,7 +153,8 @@ __device__ __forceinline__ void clip_affine(double a, double b, double& lo, doub
 __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
                                                                 unsigned* __restrict__ list,
                                                                 unsigned* __restrict__ count,
-                                                                double* __restrict__ rowbase) {
+                                                                double* __restrict__ rowbase,
+                                                                unsigned long long* __restrict__ counters) {
     const int m = p.g.m;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
@@ -215,7 +216,10 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
     int wave_off = 0, total = 0;
 #pragma unroll
     for (int q = 0; q < kClipBlock / 64; ++q) { if (q < wv) wave_off += s_tot[q]; total += s_tot[q]; }
-    if (tid == 0) s_base = total ? atomicAdd(count, (unsigned)total) : 0u;
+    if (tid == 0) {
+        s_base = total ? atomicAdd(count, (unsigned)total) : 0u;
+        if (total) atomicAdd(&counters[kCntItems], (unsigned long long)total);
+    }
     __syncthreads();
     unsigned at = s_base + (unsigned)(wave_off + incl - n);
     const unsigned code = (unsigned)row << 6;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         u.d_new = d; u.w_new = wn; u.rgb = __float_as_uint(P.w);
         u.owned = g.owned;
         u.idx = g.idx;
-        const long long ld = ok ? g.idx : 0ll;              // dead lanes share voxel 0's (cache-resident) line
+        const long long ld = (ok && !(p.debug & 16)) ? g.idx : 0ll;   // dead lanes share voxel 0's (cache-resident) line
         u.old = dw[ld];
         if (COLOR) {
             u.col = crgb[ld];
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         if (u.live) {
             const float w_sum = u.old.y + u.w_new;                              // sdf.cpp:289-292
             const float d_out = (u.old.y * u.old.x + u.w_new * u.d_new) / w_sum;
-            dw[u.idx] = make_float2(d_out, w_sum);
+            if (!(p.debug & 8)) dw[u.idx] = make_float2(d_out, w_sum);      // (debug bit 3: timing experiment, no stores)
             if (u.owned) ++n_own; else ++n_halo;
             if (COLOR) {                                                        // sdf.cpp:294-304
                 const float wc = u.wc;
@@ -383,8 +387,10 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
                             pb = (float)(int)((u.rgb >> 16) & 255u);
                 const float4 c = u.col;
                 const float cw_sum = c.x + wc;
-                crgb[u.idx] = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
-                                          (c.x * c.w + wc * pb) / cw_sum);
+                const float4 cout = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
+                                                (c.x * c.w + wc * pb) / cw_sum);
+                if (!(p.debug & 8)) crgb[u.idx] = cout;
+                else if (cout.x == -12345.0f) crgb[u.idx] = cout;   // keep the arithmetic alive in the experiment
             }
         }
     };
@@ -466,7 +472,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     hipError_t e = hipMemsetAsync(work_count, 0, sizeof(unsigned), s);
     if (e != hipSuccess) return e;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
-    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, worklist, work_count, rowbase);
+    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, worklist, work_count, rowbase, counters);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 #define TSDF_LAUNCH_INTEGRATE(C, KS) \
@@ -854,6 +860,24 @@ __global__ __launch_bounds__(256) void track_final_kernel(const double* __restri
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(red_host + kRedWidth), seq, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// After an in-stream all-reduce (RCCL) of red_dev: hand the reduced row to the host the same way
+// track_final_kernel does (pinned memory + system-scope release of the pass number), so the host can
+// poll instead of waiting for a stream synchronisation.
+__global__ __launch_bounds__(64) void track_publish_kernel(const double* __restrict__ red_dev,
+                                                            double* __restrict__ red_host, unsigned long long seq) {
+    if (threadIdx.x == 0) {
+        for (int e = 0; e < kRedWidth; ++e) red_host[e] = red_dev[e];
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(red_host + kRedWidth), seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq) {
+    track_publish_kernel<<<dim3(1), dim3(64), 0, s>>>(red_dev, red_host, seq);
+    return hipGetLastError();
 }
 
 int track_num_blocks(int32_t n_samples) { return (n_samples + kSamplesPerBlock - 1) / kSamplesPerBlock; }
