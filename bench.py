@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--m", type=int, default=512, help="voxels per axis (BASELINE metric: 512)")
+    ap.add_argument("--voxels", dest="m", type=int, default=512, help="voxels per axis m (BASELINE metric: 512)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-color", action="store_true", help="drop the colour lanes (sdf.cpp:294-304)")
@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--cpu-baseline-frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allreduce", choices=["auto", "rccl", "shm", "torch"], default="auto",
-                    help="auto = in-library RCCL, else torch hook; shm = shared-memory fan-in (one node)")
+                    help="auto = self-test and time in-library RCCL and the shared-memory fan-in, keep the faster (torch hook if both fail)")
     ap.add_argument("--host-frames", action="store_true", help="hand frames over as HOST buffers every step (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--trajectory-out", default=None, help="write the estimated trajectory (TUM format)")
@@ -177,46 +177,74 @@ def main():
     trk.set_K(seq.K)
 
     allreduce_kind = "none"
+    exchange_us = {}
     if world > 1:
-        want = args.allreduce
-        ok = False
-        if want in ("auto", "rccl"):
-            # 1) local check on every rank that RCCL can be bound at all (no collective yet)
+        cpu_or_dev = dev if args.dist_backend == "nccl" else "cpu"
+
+        def all_agree(flag):
+            t = torch.tensor([1 if flag else 0], device=cpu_or_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        def probe(n=40):
+            """Self-test + time of one exchange step (sum of 30 doubles over the ranks), microseconds."""
+            got = sdf.allreduce(np.full(30, float(rank + 1)))
+            good = bool(np.all(got == world * (world + 1) / 2))
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                sdf.allreduce(np.ones(30))
+            return good, 1e6 * (time.perf_counter() - t0) / n
+
+        def init_rccl():
             import ctypes
             buf = ctypes.create_string_buffer(128)
-            can = 1 if ts.lib().tsdf_comm_unique_id(buf) == 0 else 0
-            flag = torch.tensor([can], device=dev if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if bool(flag.item()):
-                # 2) rank 0's id to everyone, collective communicator init, then a self-test sum
-                uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device=dev if args.dist_backend == "nccl" else "cpu")
-                dist.broadcast(uid, 0)
-                try:
-                    sdf.comm_init(world, rank, bytes(uid.cpu().tolist()))
-                    probe = sdf.allreduce(np.full(30, float(rank + 1)))
-                    ok = bool(np.all(probe == world * (world + 1) / 2))
-                except Exception as e:      # noqa: BLE001 -- report and fall back to the host hook
-                    print(f"[bench] rank {rank}: in-library RCCL failed ({e})", file=sys.stderr)
-                    ok = False
-                flag = torch.tensor([1 if ok else 0], device=dev if args.dist_backend == "nccl" else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = bool(flag.item())
-            if ok:
-                allreduce_kind = "rccl-in-library"
-            elif rank == 0:
-                print("[bench] in-library RCCL unavailable; using the torch.distributed hook", file=sys.stderr)
-        if want == "shm":
+            if not all_agree(ts.lib().tsdf_comm_unique_id(buf) == 0):      # can every rank bind librccl at all?
+                return False
+            uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device=cpu_or_dev)
+            dist.broadcast(uid, 0)
+            try:
+                sdf.comm_init(world, rank, bytes(uid.cpu().tolist()))
+                good = True
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] rank {rank}: in-library RCCL failed ({e})", file=sys.stderr)
+                good = False
+            return all_agree(good)
+
+        def init_shm():
             names = [f"/tsdf_{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}"]
             dist.broadcast_object_list(names, 0)
-            sdf.comm_init_shm(world, rank, names[0])
-            dist.barrier()
-            ok = True
-            allreduce_kind = "shared-memory fan-in"
-        if not ok:
-            if want == "rccl":
-                raise SystemExit("--allreduce rccl requested but the in-library communicator failed")
+            try:
+                sdf.comm_init_shm(world, rank, names[0])
+                good = True
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] rank {rank}: shared-memory fan-in failed ({e})", file=sys.stderr)
+                good = False
+            return all_agree(good)
+
+        want = args.allreduce
+        candidates = {"auto": ["rccl", "shm"], "rccl": ["rccl"], "shm": ["shm"], "torch": []}[want]
+        if args.dist_backend != "nccl" and "rccl" in candidates:
+            candidates.remove("rccl")          # ranks may share a GPU under gloo: RCCL refuses that
+        for mode in candidates:
+            if (init_rccl() if mode == "rccl" else init_shm()):
+                good, us = probe()
+                if all_agree(good):
+                    exchange_us[mode] = us
             sdf.comm_finalize()
-            scratch = torch.zeros(30, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.barrier()
+        # every rank must take the same decision: use rank 0's timings
+        choice = [min(exchange_us, key=exchange_us.get) if exchange_us else "torch"]
+        dist.broadcast_object_list(choice, 0)
+        if choice[0] == "rccl" and init_rccl():
+            allreduce_kind = "rccl-in-library"
+        elif choice[0] == "shm" and init_shm():
+            allreduce_kind = "shared-memory fan-in"
+        else:
+            if want in ("rccl", "shm"):
+                raise SystemExit(f"--allreduce {want} requested but it failed its self-test")
+            sdf.comm_finalize()
+            scratch = torch.zeros(30, dtype=torch.float64, device=cpu_or_dev)
 
             def hook(arr):
                 scratch.copy_(torch.from_numpy(arr))
@@ -224,6 +252,7 @@ def main():
                 arr[:] = scratch.cpu().numpy()
             sdf.set_allreduce_hook(hook)
             allreduce_kind = "torch.distributed-hook"
+        dist.barrier()
 
     track_wall = [0.0]
 
@@ -297,7 +326,7 @@ def main():
                                    f"colour lanes {'off' if args.no_color else 'on'}; TUM fr1/plant images are not "
                                    f"available on the box",
                        "m": args.m, "image": [args.width, args.height], "parallelism": f"x-slab x{world}",
-                       "halo": halo, "allreduce": allreduce_kind},
+                       "halo": halo, "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us},
             "ate_rmse_m": ate, "abs_trajectory_rmse_m": raw,
             "gn_iterations_per_frame": float(np.mean(iters)),
             "stage_ms_per_frame": {"track_wall": 1e3 * track_wall[0] / args.steps,

@@ -14,7 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--m", "128", "--width", "320", "--height", "240", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+COMMON = ["--voxels", "128", "--width", "320", "--height", "240", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
           "--frame-step", "3"]
 
 
@@ -31,12 +31,12 @@ def run_bench(extra, nproc, traj, port):
     return json.loads(line), np.loadtxt(traj)
 
 
-@pytest.mark.parametrize("mode,nproc", [("shm", 2), ("torch", 2), ("shm", 3)])
+@pytest.mark.parametrize("mode,nproc", [("shm", 2), ("torch", 2), ("shm", 3), ("auto", 2)])
 def test_sharded_bench_reproduces_single_rank_trajectory(tmp_path, mode, nproc):
     j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
-    jn, tn = run_bench(["--allreduce", mode], nproc, str(tmp_path / "tn.txt"), 29600 + nproc + (7 if mode == "shm" else 0))
+    jn, tn = run_bench(["--allreduce", mode], nproc, str(tmp_path / "tn.txt"), 29600 + nproc + {"shm": 7, "torch": 0, "auto": 13}[mode])
     assert jn["n_gpus"] == nproc and jn["config"]["halo"] > 0
-    assert ("shared-memory" in jn["config"]["allreduce"]) == (mode == "shm")
+    assert ("shared-memory" in jn["config"]["allreduce"]) == (mode in ("shm", "auto"))   # gloo plumbing: RCCL not a candidate
     assert t1.shape == tn.shape and np.array_equal(t1, tn)          # 4-decimal TUM lines, identical
     assert abs(jn["ate_rmse_m"] - j1["ate_rmse_m"]) < 1e-9
     assert jn["gn_iterations_per_frame"] == j1["gn_iterations_per_frame"]

@@ -273,6 +273,31 @@ void shm_close(tsdf_handle* h) {
     h->shm.nranks = 0;
 }
 
+// Shared-memory fan-in: wait for every rank's row of pass `seq`, add the leading `n` entries in rank order
+// into h->red_host (the remaining entries are this rank's own).  Slots are double-buffered by pass parity: a
+// rank can only overwrite its pass-s slot when publishing pass s+2, which needs everybody's pass s+1 row,
+// which nobody publishes before having read all pass-s rows.
+int shm_fan_in(tsdf_handle* h, unsigned long long seq, int n) {
+    double sum[kRedWidth];
+    for (int e = 0; e < kRedWidth; ++e) sum[e] = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < h->shm.nranks; ++r) {
+        const char* slot = h->shm.base + ((size_t)r * 2 + (seq & 1ull)) * kShmSlot;
+        const volatile unsigned long long* word =
+            reinterpret_cast<const volatile unsigned long long*>(slot + kRedWidth * sizeof(double));
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+                return fail(h, TSDF_E_COMM, "shared-memory fan-in: rank %d did not publish pass %llu within 20 s", r, seq);
+        }
+        const double* row = reinterpret_cast<const double*>(slot);
+        for (int e = 0; e < n; ++e) sum[e] += row[e];
+        if (r == h->shm.rank) std::memcpy(h->red_host, row, kRedWidth * sizeof(double));
+    }
+    std::memcpy(h->red_host, sum, (size_t)n * sizeof(double));
+    return TSDF_OK;
+}
+
 // Launch one accumulation pass and wait for its kRedWidth-double result row in h->red_host.
 // reduce_ranks: sum the leading kRedAllreduce entries over ranks (RCCL on the device buffer, or hook).
 int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
@@ -298,25 +323,8 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     }
     bool arrived = false;
     if (use_shm) {
-        // fan-in: wait for every rank's row of THIS pass (slots are double-buffered by pass parity: a rank can
-        // only overwrite its pass-s slot when publishing pass s+2, which needs everybody's pass s+1 row, which
-        // nobody publishes before having read all pass-s rows), then add them in rank order.
-        double sum[kRedAllreduce];
-        for (int e = 0; e < kRedAllreduce; ++e) sum[e] = 0.0;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int r = 0; r < h->shm.nranks; ++r) {
-            const char* slot = h->shm.base + ((size_t)r * 2 + (seq & 1ull)) * kShmSlot;
-            const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(slot + kRedWidth * sizeof(double));
-            for (unsigned spins = 0;; ++spins) {
-                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
-                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
-                    return fail(h, TSDF_E_COMM, "shared-memory fan-in: rank %d did not publish pass %llu within 20 s", r, seq);
-            }
-            const double* row = reinterpret_cast<const double*>(slot);
-            for (int e = 0; e < kRedAllreduce; ++e) sum[e] += row[e];
-            if (r == h->shm.rank) std::memcpy(h->red_host, row, kRedWidth * sizeof(double));
-        }
-        std::memcpy(h->red_host, sum, sizeof sum);
+        int rc2 = shm_fan_in(h, seq, kRedAllreduce);
+        if (rc2) return rc2;
         arrived = true;
     } else if (h->poll) {
         // The final (or publish) kernel releases the pass number after the row (system scope); spinning on
@@ -886,6 +894,17 @@ int tsdf_allreduce(tsdf_handle* h, double* buf, int32_t n) {
         if (!h->comm.allreduce_sum_f64(h->red_dev, n, h->stream, &err)) return fail(h, TSDF_E_COMM, "RCCL all-reduce failed: %s", err.c_str());
         HIP_TRY(h, hipMemcpyAsync(buf, h->red_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return TSDF_OK;
+    }
+    if (h->shm.active()) {
+        const unsigned long long seq = ++h->pass_seq;
+        double* slot = reinterpret_cast<double*>(h->shm.dev_base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot);
+        HIP_TRY(h, hipMemsetAsync(h->red_dev, 0, kRedWidth * sizeof(double), h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->red_dev, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, launch_track_publish(h->stream, h->red_dev, slot, seq));
+        int rc2 = shm_fan_in(h, seq, n);
+        if (rc2) return rc2;
+        std::memcpy(buf, h->red_host, (size_t)n * sizeof(double));
         return TSDF_OK;
     }
     if (h->hook) {
