@@ -150,8 +150,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend="gloo")
-            if args.allreduce == "auto":
-                args.allreduce = "torch"          # ranks may share a GPU: RCCL refuses that
 
     def barrier():
         if world > 1:
