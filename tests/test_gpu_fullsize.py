@@ -1,0 +1,133 @@
+"""Full-size (BASELINE.json) configurations checked through size-independent properties -- the oracle would
+take minutes per frame here, so nothing in this file calls it.
+
+Properties of SDF::update (sdf.cpp:289-292) that hold bit-exactly in float arithmetic:
+  * integrating the SAME frame at the SAME pose twice doubles W exactly and leaves D unchanged
+    ((W d + w d')/(W + w) with identical terms is exact: x + x and 2x/2 never round);
+  * the set of updated voxels is a function of pose and image only (counter identical both times);
+  * a slab of the volume integrates to the same bits as the same layers of the whole volume.
+Properties of the tracker: A is symmetric positive semi-definite, its term count equals the OK samples when
+no sample is out of grid, and tracking a frame against the volume it was just fused into at the true pose
+converges to (nearly) zero motion.
+"""
+import numpy as np
+import pytest
+
+from tracking_sdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def seq_frames(n, w=640, h=480, **kw):
+    seq = synth.Sequence(n_frames=n, width=w, height=h, noise=True, holes=0.02, **kw)
+    return seq, [seq.frame(k) for k in range(n)]
+
+
+@pytest.mark.parametrize("m,color", [(512, True), (256, True)])
+def test_double_integration_doubles_w_exactly(m, color):
+    import tracking_sdf_amd as ts
+    seq, fr = seq_frames(2, step=5)
+    s = ts.SDF(m, with_color=color)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    xyz, nrm, rgb = fr[0]
+    st1 = s.update(t, xyz, nrm, rgb)
+    D1, W1 = s.download()
+    st2 = s.update(t, xyz, nrm, rgb)
+    D2, W2 = s.download()
+    assert st1["n_updated"] == st2["n_updated"] and st1["n_voxels"] == m ** 3
+    frac = st1["n_updated"] / m ** 3
+    assert 0.03 < frac < 0.2                       # the frustum of a 640x480 camera inside the 6x6x3.5 m volume
+    upd = W1 > 0
+    assert int(upd.sum()) == st1["n_updated"]
+    assert np.array_equal(W2[upd], 2 * W1[upd]) and np.array_equal(D2[upd], D1[upd])
+    assert np.all(W2[~upd] == 0) and np.all(D2[~upd] == np.float32(15.5))
+    assert np.all(np.abs(D1[upd]) <= np.float32(0.3))          # truncation: -delta clamp, d > delta skipped
+    if color:
+        cw, r, g, b = s.download_color()
+        assert np.all(cw[~upd] == 0) and np.all(r[~upd] == np.float32(0.4))
+        assert np.all((r[upd] >= 0) & (r[upd] <= 255))
+    # second frame at its own pose: counters move, nothing becomes NaN
+    t.set_camera_transformation(seq.R[1], seq.t[1])
+    st3 = s.update(t, *fr[1])
+    D3, W3 = s.download()
+    assert st3["n_updated"] > 0 and not np.isnan(D3).any() and np.all(W3 >= W2)
+    s.close()
+
+
+def test_tracker_properties_at_512():
+    import tracking_sdf_amd as ts
+    m = 512
+    seq, fr = seq_frames(3, step=3)
+    s = ts.SDF(m, with_color=False)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    for k in range(2):
+        t.set_camera_transformation(seq.R[k], seq.t[k])
+        s.update(t, fr[k][0], fr[k][1])
+    # accumulate at the true pose of frame 1
+    s.set_frame(fr[1][0])
+    A, b, st = t.accumulate()
+    assert st["n_samples"] == 214 * 160 and st["n_oog"] == 0 and st["n_terms"] == st["n_ok"] > 25000
+    assert np.array_equal(A, A.T) and np.all(np.linalg.eigvalsh(A) > -1e-6 * np.abs(A).max())
+    # repeated passes are bitwise reproducible (fixed-order reduction, no float atomics)
+    A2, b2, _ = t.accumulate()
+    assert np.array_equal(A, A2) and np.array_equal(b, b2)
+    # tracking frame 1 from its true pose stays put (sub-centimetre), frame 2 from pose 1 moves toward pose 2
+    st = t.estimate_new_position(s, fr[1][0])
+    assert np.linalg.norm(t.trans - seq.t[1]) < 0.01
+    err_before = np.linalg.norm(seq.t[1] - seq.t[2])
+    t.set_camera_transformation(seq.R[1], seq.t[1])
+    st = t.estimate_new_position(s, fr[2][0])
+    assert 1 <= st["iterations"] <= 20
+    assert np.linalg.norm(t.trans - seq.t[2]) < 0.5 * err_before
+    s.close()
+
+
+def test_slab_of_512_matches_whole_volume_layers():
+    import tracking_sdf_amd as ts
+    m = 512
+    seq, fr = seq_frames(1)
+    whole = ts.SDF(m, with_color=False)
+    tw = ts.CameraTracking(sdf=whole)
+    tw.set_K(seq.K)
+    whole.update(tw, fr[0][0], fr[0][1])
+    Dw, Ww = whole.download()
+    whole.close()
+    x0, x1 = ts.slab_range(m, 8, 3)
+    halo = ts.halo_for(ts.default_config(m=m), 6.0)
+    slab = ts.SDF(m, with_color=False, slab=(x0, x1), halo=halo)
+    tsl = ts.CameraTracking(sdf=slab)
+    tsl.set_K(seq.K)
+    st = slab.update(tsl, fr[0][0], fr[0][1])
+    Ds, Ws = slab.download()
+    sl = slice(x0 * m * m, x1 * m * m)
+    assert np.array_equal(Ds, Dw[sl]) and np.array_equal(Ws, Ww[sl])
+    assert st["n_voxels"] == (x1 - x0 + 2 * halo) * m * m and st["n_updated_halo"] > 0
+    slab.close()
+
+
+def test_config5_shapes_1280x960_at_1024():
+    """Config 5's image size against a 1024^3 volume (8 GiB of D/W on one GPU, no colour lanes): counters and
+    samples only -- the volume never leaves the device."""
+    import tracking_sdf_amd as ts
+    m = 1024
+    seq, fr = seq_frames(2, w=1280, h=960, step=3)
+    s = ts.SDF(m, with_color=False)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    st1 = s.update(t, fr[0][0], fr[0][1])
+    st2 = s.update(t, fr[0][0], fr[0][1])
+    assert st1["n_updated"] == st2["n_updated"] and 0.03 < st1["n_updated"] / m ** 3 < 0.2
+    # sample the SDF at the voxel positions of some valid pixels: |value| must be below one truncation distance
+    xyz = fr[0][0]
+    pts = xyz[::97, ::89].reshape(-1, 3)
+    pts = pts[np.isfinite(pts[:, 0])]
+    world = pts.astype(np.float64) @ seq.R[0].T + seq.t[0]
+    vox = (world - np.array([-3.0, -3.0, -0.5])) * (m / np.array([6.0, 6.0, 3.5])) - 0.5
+    val, ok = s.interpolate_distance(vox)
+    assert ok.mean() > 0.95 and np.all(np.abs(val[ok]) < 0.05)         # surface points sit near the zero crossing
+    s.set_frame(fr[1][0])
+    A, b, st = t.accumulate()
+    assert st["n_samples"] == 427 * 320 and st["n_ok"] > 100000 and np.array_equal(A, A.T)
+    s.close()
