@@ -151,6 +151,13 @@ int tsdf_upload_color(tsdf_handle *h, const float *Color_W, const float *R, cons
  * uploads D/W for the halo layers too (arrays cover [max(0,x0-halo), min(m,x1+halo)) ). */
 int tsdf_upload_with_halo(tsdf_handle *h, const float *D, const float *W);
 int tsdf_reset(tsdf_handle *h);                                   /* back to the constructor state */
+/* Volume checkpoint (the reference keeps the volume only in RAM, sdf.cpp:52-54).
+ * File = 72-byte little-endian header {"TSDFVOL1", int32 m, x0, x1, has_color, float width, height, depth,
+ * delta, epsilon, int32 pad, double origin[3]} followed by the owned slab's D, W (and Color_W, R, G, B) float arrays in
+ * reference index order.  tsdf_load checks the header against the handle (same m, slab, colour) and also
+ * restores nothing but the voxel state: pose and intrinsics stay with the caller. */
+int tsdf_save(tsdf_handle *h, const char *path);
+int tsdf_load(tsdf_handle *h, const char *path);
 
 /* ---- multi-GPU (one process per GPU; the volume is sharded in x-slabs) ------------------- */
 /* Owned range of `rank` out of `nranks` for an m-voxel axis (balanced contiguous slabs). */

@@ -9,6 +9,8 @@ Tolerances (stated per SURVEY.md section 8c):
   pose, one GN call    <= 1e-9
   pose, 10 free frames <= 1e-5 m
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -406,3 +408,33 @@ def test_integrate_general_intrinsics_disable_row_clip():
     st = go.update(gt, xyz, nrm, rgb)
     assert st["n_updated"] == n_or
     assert_volume_equal(go, oo, m)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """tsdf_save / tsdf_load: the volume survives a process-independent file, bit for bit."""
+    import tracking_sdf_amd as ts
+    m = 32
+    seq, fr = frames(2)
+    go, gt = make_gpu(m, seq.K)
+    go.update(gt, *fr[0])
+    path = str(tmp_path / "vol.tsdf")
+    go.save(path)
+    D, W = go.download()
+    col = go.download_color()
+    assert os.path.getsize(path) == 72 + 6 * 4 * m ** 3
+    go2, gt2 = make_gpu(m, seq.K)
+    go2.load(path)
+    D2, W2 = go2.download()
+    assert np.array_equal(D, D2) and np.array_equal(W, W2)
+    for a, b in zip(col, go2.download_color()):
+        assert np.array_equal(a, b)
+    # resuming from the checkpoint continues exactly like the original
+    gt.set_camera_transformation(seq.R[1], seq.t[1]); gt2.set_camera_transformation(seq.R[1], seq.t[1])
+    go.update(gt, *fr[1]); go2.update(gt2, *fr[1])
+    assert all(np.array_equal(a, b) for a, b in zip(go.download(), go2.download()))
+    # mismatching handle is refused
+    go3 = ts.SDF(m, with_color=False)
+    with pytest.raises(ts.TsdfError):
+        go3.load(path)
+    with pytest.raises(ts.TsdfError):
+        go2.load(str(tmp_path / "missing.tsdf"))

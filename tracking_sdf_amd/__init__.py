@@ -82,7 +82,7 @@ ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_set_frame_device", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
-    "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset",
+    "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
@@ -138,6 +138,8 @@ def lib():
         "tsdf_upload_color": (C.c_int, [H, fp, fp, fp, fp]),
         "tsdf_upload_with_halo": (C.c_int, [H, fp, fp]),
         "tsdf_reset": (C.c_int, [H]),
+        "tsdf_save": (C.c_int, [H, C.c_char_p]),
+        "tsdf_load": (C.c_int, [H, C.c_char_p]),
         "tsdf_slab_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, ip, ip]),
         "tsdf_halo_for": (C.c_int32, [C.POINTER(Config), C.c_float]),
         "tsdf_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -365,6 +367,13 @@ class SDF:
 
     def reset(self):
         self._check(lib().tsdf_reset(self._h))
+
+    def save(self, path):
+        """Write the owned slab's D, W (and colour) as a TSDFVOL1 checkpoint."""
+        self._check(lib().tsdf_save(self._h, str(path).encode()))
+
+    def load(self, path):
+        self._check(lib().tsdf_load(self._h, str(path).encode()))
 
     # -- multi-GPU plumbing
     def comm_init(self, nranks, rank, unique_id: bytes):

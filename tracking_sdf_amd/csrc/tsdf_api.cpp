@@ -825,6 +825,77 @@ int tsdf_upload_color(tsdf_handle* h, const float* Color_W, const float* R, cons
     return volume_io(h, false, true, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
 }
 
+// ---- checkpoint ----------------------------------------------------------------------------------------
+
+namespace {
+struct VolHeader {
+    char magic[8];
+    int32_t m, x0, x1, has_color;
+    float width, height, depth, delta, epsilon;
+    int32_t pad;
+    double origin[3];
+};
+static_assert(sizeof(VolHeader) == 72, "checkpoint header layout");
+}  // namespace
+
+int tsdf_save(tsdf_handle* h, const char* path) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!path) return fail(h, TSDF_E_BADARG, "tsdf_save: null path");
+    const size_t n = (size_t)(h->grid.own_x1 - h->grid.own_x0) * h->grid.m * h->grid.m;
+    const int planes = h->crgb ? 6 : 2;
+    std::vector<float> buf;
+    try { buf.resize(n * planes); } catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_save: out of host memory"); }
+    rc = tsdf_download(h, buf.data(), buf.data() + n);
+    if (rc) return rc;
+    if (h->crgb) {
+        rc = tsdf_download_color(h, buf.data() + 2 * n, buf.data() + 3 * n, buf.data() + 4 * n, buf.data() + 5 * n);
+        if (rc) return rc;
+    }
+    VolHeader hd;
+    std::memset(&hd, 0, sizeof hd);
+    std::memcpy(hd.magic, "TSDFVOL1", 8);
+    hd.m = h->grid.m; hd.x0 = h->grid.own_x0; hd.x1 = h->grid.own_x1; hd.has_color = h->crgb ? 1 : 0;
+    hd.width = h->cfg.width; hd.height = h->cfg.height; hd.depth = h->cfg.depth;
+    hd.delta = h->cfg.delta; hd.epsilon = h->cfg.epsilon;
+    std::memcpy(hd.origin, h->cfg.origin, sizeof hd.origin);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(h, TSDF_E_BADARG, "tsdf_save: cannot open %s", path);
+    const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(buf.data(), sizeof(float), buf.size(), f) == buf.size();
+    std::fclose(f);
+    if (!ok) return fail(h, TSDF_E_BADARG, "tsdf_save: short write to %s", path);
+    return TSDF_OK;
+}
+
+int tsdf_load(tsdf_handle* h, const char* path) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!path) return fail(h, TSDF_E_BADARG, "tsdf_load: null path");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(h, TSDF_E_BADARG, "tsdf_load: cannot open %s", path);
+    VolHeader hd;
+    if (std::fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, "TSDFVOL1", 8) != 0) {
+        std::fclose(f);
+        return fail(h, TSDF_E_BADARG, "tsdf_load: %s is not a TSDFVOL1 file", path);
+    }
+    if (hd.m != h->grid.m || hd.x0 != h->grid.own_x0 || hd.x1 != h->grid.own_x1 || (hd.has_color != 0) != (h->crgb != nullptr)) {
+        std::fclose(f);
+        return fail(h, TSDF_E_BADARG, "tsdf_load: file holds m=%d slab [%d,%d) colour=%d, handle has m=%d slab [%d,%d) colour=%d",
+                    hd.m, hd.x0, hd.x1, hd.has_color, h->grid.m, h->grid.own_x0, h->grid.own_x1, h->crgb ? 1 : 0);
+    }
+    const size_t n = (size_t)(h->grid.own_x1 - h->grid.own_x0) * h->grid.m * h->grid.m;
+    const int planes = h->crgb ? 6 : 2;
+    std::vector<float> buf;
+    try { buf.resize(n * planes); } catch (...) { std::fclose(f); return fail(h, TSDF_E_NOMEM, "tsdf_load: out of host memory"); }
+    const bool ok = std::fread(buf.data(), sizeof(float), buf.size(), f) == buf.size();
+    std::fclose(f);
+    if (!ok) return fail(h, TSDF_E_BADARG, "tsdf_load: %s is truncated", path);
+    rc = tsdf_upload(h, buf.data(), buf.data() + n);
+    if (rc) return rc;
+    if (h->crgb) rc = tsdf_upload_color(h, buf.data() + 2 * n, buf.data() + 3 * n, buf.data() + 4 * n, buf.data() + 5 * n);
+    return rc;
+}
+
 // ---- multi-GPU ---------------------------------------------------------------------------------------
 
 int tsdf_comm_unique_id(void* id128) {
