@@ -56,6 +56,7 @@ struct tsdf_handle {
     unsigned* work_count = nullptr;
     int integrate_blocks = 0;      // persistent grid of integrate_kernel
     double* rowbase = nullptr;     // per-row share of rot_inv * g (3 doubles per row)
+    int integrate_debug = 0;       // timing experiments; only honoured by builds with -DTSDF_INTEGRATE_DEBUG=1
 
     // frame
     int32_t fw = 0, fh = 0, ncols = 0, nrows = 0, n_samples = 0;
@@ -505,6 +506,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
+        { const char* dbg = std::getenv("TSDF_DEBUG_INTEGRATE"); h->integrate_debug = dbg ? std::atoi(dbg) : 0; }
         const char* env = std::getenv("TSDF_INTEGRATE_BLOCKS_PER_CU");
         const int per_cu = env ? std::atoi(env) : integrate_blocks_per_cu();
         h->integrate_blocks = (prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4) + 7) / 8 * 8;   // whole XCD groups
@@ -639,7 +641,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     p.width = h->fw; p.height = h->fh;
     p.pix_su = h->pix_su; p.pix_sv = h->pix_sv;
     p.with_color = h->cfg.with_color;
-    { const char* dbg = std::getenv("TSDF_DEBUG_INTEGRATE"); p.debug = dbg ? std::atoi(dbg) : 0; }
+    p.debug = h->integrate_debug;
     unsigned long long before[kNumCounters];
     if (stats) {
         HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof before, hipMemcpyDeviceToHost, h->stream));

@@ -227,13 +227,13 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
 }
 
 // exp(x) for the weight of sdf.cpp:278.  x = -(d-eps)^2/2 lies in [-(delta-eps)^2/2, 0]; for
-// |x| <= 1/16 a degree-10 Taylor polynomial in f64 (fused multiply-adds: this approximates the exact
+// |x| <= 1/16 (decided on the host from delta - epsilon: template flag EXPPOLY) a degree-10 Taylor polynomial in f64 (fused multiply-adds: this approximates the exact
 // function, it does not mimic reference roundings) has a truncation error below 2e-19, i.e. it is as
 // close to the true value as glibc's / ocml's exp (< 1 ulp of f64) and agrees with them after the
 // reference's f64 -> f32 narrowing except for values within ~1e-16 (relative) of an f32 rounding
-// boundary.  Larger |x| (non-default delta) use the library exp.
-__device__ __forceinline__ double exp_small(double x) {
-    if (x < -0.0625) return exp(x);
+// boundary.  Larger |x| (non-default delta) use the library exp.  The polynomial is branch-free, which keeps
+// the pipeline step of integrate_kernel one basic block.
+__device__ __forceinline__ double exp_taylor10(double x) {
     double r = 1.0 / 3628800.0;
     r = __builtin_fma(r, x, 1.0 / 362880.0);
     r = __builtin_fma(r, x, 1.0 / 40320.0);
@@ -274,7 +274,11 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
-template <bool COLOR, bool KSTD>
+#ifndef TSDF_INTEGRATE_DEBUG
+#define TSDF_INTEGRATE_DEBUG 0      // 1 compiles the p.debug timing experiments in (uniform branches split the step)
+#endif
+
+template <bool COLOR, bool KSTD, bool EXPPOLY>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, const unsigned* __restrict__ list, const unsigned* __restrict__ count,
     const double* __restrict__ rowbase, float2* __restrict__ dw, float4* __restrict__ crgb,
@@ -300,98 +304,114 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     double s0_v = 0.0, s1_v = 0.0, s2_v = 0.0;
     int cnt = 0;
 
-    // S1(j): geometry of item j of the current block; request its pixel record.  The two record loads are
-    // issued on every path (dead lanes read record 0) so that later waits can be counted, not vmcnt(0).
-    auto stage1 = [&](int j, GatherState& g) {
-        const int jj = j < cnt ? j : 0;
-        const unsigned code = __builtin_amdgcn_readlane(code_v, jj);
-        const long long row = (long long)(code >> 6);
-        const int k = (int)(code & 63u) * 64 + lane;
-        const int il = (tl.log2m >= 0) ? (int)(row >> tl.log2m) : (int)(row / m);
-        const int i = il + p.g.xs;
-        g.owned = (i >= p.g.own_x0 && i < p.g.own_x1);
-        const double sx = readlane_f64(s0_v, jj), sy = readlane_f64(s1_v, jj), sz = readlane_f64(s2_v, jj);
-        g.idx = row * m + (k < m ? k : 0);
-        // get_global_coordinates (sdf.h:153-157) + project_world_to_camera (camera_tracking.cpp:51-54)
-        const double gz = cd * ((double)k + 0.5) + oz;
-        g.pcx = (sx + p.rot_inv[2] * gz) + p.rot_inv_trans[0];
-        g.pcy = (sy + p.rot_inv[5] * gz) + p.rot_inv_trans[1];
-        g.pcz = (sz + p.rot_inv[8] * gz) + p.rot_inv_trans[2];
-        bool ok = (j < cnt) && (k < m) && !(g.pcz < 0);                         // sdf.cpp:247-249
-        // project_camera_to_image_plane, camera_tracking.cpp:40-47.  With K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
-        // the dropped terms are +-0 products: (fx*x + 0*y) + cx*z == fx*x + cx*z and (0*x + 0*y) + 1*z == z
-        // bit for bit (up to the sign of a zero, which no later step can observe).
-        double ij0, ij1, ij2;
-        if (KSTD) {
-            ij0 = p.K[0] * g.pcx + p.K[2] * g.pcz;
-            ij1 = p.K[4] * g.pcy + p.K[5] * g.pcz;
-            ij2 = g.pcz;
-        } else {
-            ij0 = row3(&p.K[0], g.pcx, g.pcy, g.pcz);
-            ij1 = row3(&p.K[3], g.pcx, g.pcy, g.pcz);
-            ij2 = row3(&p.K[6], g.pcx, g.pcy, g.pcz);
-        }
-        const double u = ij0 / ij2;
-        const double w = ij1 / ij2;
-        // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
-        // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
-        ok = ok && (u > -1.0 && u < (double)p.width && w > -1.0 && w < (double)p.height);
-        const int iu = ok ? (int)u : 0, iw = ok ? (int)w : 0;
-        g.pix = (long long)iu * p.pix_su + (long long)iw * p.pix_sv;
-        if (p.debug & 1) g.pix = __shfl(g.pix, 0);          // timing experiment only: one record per wave
-        g.P = pn[2 * g.pix + 0];
-        g.N = pn[2 * g.pix + 1];
-        g.live = ok;
-    };
-    // S2: distance + weight from the pixel record; request {D,W} (+ colour, cosine).  Loads again on every
-    // path; lanes that will not update read the item's first voxel (one shared, cache-resident line).
-    auto stage2 = [&](const GatherState& g, UpdateState& u) {
-        const float4 P = g.P, N = g.N;
-        bool ok = g.live && !(is_nan(P.x) || is_nan(P.y) || is_nan(N.x) || is_nan(N.y) || is_nan(N.z));  // sdf.cpp:260
-        // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
-        const double dx = (double)P.x - g.pcx, dy = (double)P.y - g.pcy, dz = (double)P.z - g.pcz;
-        const double p2p = dx * (double)N.x + (dy * (double)N.y + dz * (double)N.z);
-        float d = (float)p2p;                                                   // sdf.cpp:274
-        ok = ok && !(d > delta);                                                // sdf.cpp:280-283
-        float wn = 1.0f;
-        if (ok && d >= eps && d <= delta) {                                     // sdf.cpp:277-279
-            const float a = d - eps;
-            wn = (float)exp_small((-0.5 * (double)a) * (double)a);
-        }
-        if (d < -delta) d = -delta;                                             // sdf.cpp:285-287
-        if (p.debug & 2) ok = false;                                            // timing experiment only: no volume RMW
-        u.d_new = d; u.w_new = wn; u.rgb = __float_as_uint(P.w);
-        u.owned = g.owned;
-        u.idx = g.idx;
-        const long long ld = (ok && !(p.debug & 16)) ? g.idx : 0ll;   // dead lanes share voxel 0's (cache-resident) line
-        u.old = dw[ld];
-        if (COLOR) {
-            u.col = crgb[ld];
-            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  w_new == 1 (every voxel in front of the surface)
-            // makes it the pre-rounded cosine of the record; the exp() band recomputes the f64 product.
-            u.wc = N.w;
-            if (ok && wn != 1.0f) u.wc = (float)((double)wn * pixel_cosine(N.x, N.y, N.z));
-        }
-        u.live = ok;
-    };
-    // S3: running averages and the two stores.
-    auto stage3 = [&](const UpdateState& u) {
-        if (u.live) {
-            const float w_sum = u.old.y + u.w_new;                              // sdf.cpp:289-292
-            const float d_out = (u.old.y * u.old.x + u.w_new * u.d_new) / w_sum;
-            if (!(p.debug & 8)) dw[u.idx] = make_float2(d_out, w_sum);      // (debug bit 3: timing experiment, no stores)
-            if (u.owned) ++n_own; else ++n_halo;
-            if (COLOR) {                                                        // sdf.cpp:294-304
-                const float wc = u.wc;
-                const float pr = (float)(int)(u.rgb & 255u), pg = (float)(int)((u.rgb >> 8) & 255u),
-                            pb = (float)(int)((u.rgb >> 16) & 255u);
-                const float4 c = u.col;
-                const float cw_sum = c.x + wc;
-                const float4 cout = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
-                                                (c.x * c.w + wc * pb) / cw_sum);
-                if (!(p.debug & 8)) crgb[u.idx] = cout;
-                else if (cout.x == -12345.0f) crgb[u.idx] = cout;   // keep the arithmetic alive in the experiment
+    // One pipeline step = S1(j) | S3(j-2) | S2(j-1), written so that everything except the rare f64 cosine
+    // and the two predicated stores is straight-line code: the three stages are independent instruction
+    // streams and the scheduler can interleave them (f64 chains are latency-bound on their own; at 4 waves
+    // per SIMD the VALU otherwise idles half the time).  Loads are issued on every path (dead lanes read a
+    // cache-resident line) so hipcc emits counted s_waitcnt vmcnt(N), never vmcnt(0), inside the loop.
+    auto step = [&](int j, GatherState& g /*out: item j*/, const GatherState& gin /*item j-1, record arrived*/,
+                    UpdateState& u /*out: item j-1*/, const UpdateState& uin /*item j-2, volume data arrived*/) {
+        // ---------------- S1(j): geometry, request the pixel record
+        {
+            const int jj = j < cnt ? j : 0;
+            const unsigned code = __builtin_amdgcn_readlane(code_v, jj);
+            const long long row = (long long)(code >> 6);
+            const int k = (int)(code & 63u) * 64 + lane;
+            const int il = (tl.log2m >= 0) ? (int)(row >> tl.log2m) : (int)(row / m);
+            const int i = il + p.g.xs;
+            g.owned = (i >= p.g.own_x0 && i < p.g.own_x1);
+            const double sx = readlane_f64(s0_v, jj), sy = readlane_f64(s1_v, jj), sz = readlane_f64(s2_v, jj);
+            g.idx = row * m + (k < m ? k : 0);
+            // get_global_coordinates (sdf.h:153-157) + project_world_to_camera (camera_tracking.cpp:51-54)
+            const double gz = cd * ((double)k + 0.5) + oz;
+            g.pcx = (sx + p.rot_inv[2] * gz) + p.rot_inv_trans[0];
+            g.pcy = (sy + p.rot_inv[5] * gz) + p.rot_inv_trans[1];
+            g.pcz = (sz + p.rot_inv[8] * gz) + p.rot_inv_trans[2];
+            bool ok = (j < cnt) && (k < m) && !(g.pcz < 0);                     // sdf.cpp:247-249
+            // project_camera_to_image_plane, camera_tracking.cpp:40-47.  With K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
+            // the dropped terms are +-0 products: (fx*x + 0*y) + cx*z == fx*x + cx*z and (0*x + 0*y) + 1*z == z
+            // bit for bit (up to the sign of a zero, which no later step can observe).
+            double ij0, ij1, ij2;
+            if (KSTD) {
+                ij0 = p.K[0] * g.pcx + p.K[2] * g.pcz;
+                ij1 = p.K[4] * g.pcy + p.K[5] * g.pcz;
+                ij2 = g.pcz;
+            } else {
+                ij0 = row3(&p.K[0], g.pcx, g.pcy, g.pcz);
+                ij1 = row3(&p.K[3], g.pcx, g.pcy, g.pcz);
+                ij2 = row3(&p.K[6], g.pcx, g.pcy, g.pcz);
             }
+            const double uu = ij0 / ij2;
+            const double ww = ij1 / ij2;
+            // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
+            // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
+            ok = ok && (uu > -1.0 && uu < (double)p.width && ww > -1.0 && ww < (double)p.height);
+            const int iu = ok ? (int)uu : 0, iw = ok ? (int)ww : 0;
+            g.pix = (long long)iu * p.pix_su + (long long)iw * p.pix_sv;
+#if TSDF_INTEGRATE_DEBUG
+            if (p.debug & 1) g.pix = __shfl(g.pix, 0);      // timing experiment only: one record per wave
+#endif
+            g.P = pn[2 * g.pix + 0];
+            g.N = pn[2 * g.pix + 1];
+            g.live = ok;
+        }
+        // ---------------- S3(j-2): running averages (unconditional arithmetic, predicated stores below)
+        const float w_sum = uin.old.y + uin.w_new;                              // sdf.cpp:289-292
+        const float d_out = (uin.old.y * uin.old.x + uin.w_new * uin.d_new) / w_sum;
+        float4 c_out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (COLOR) {                                                            // sdf.cpp:294-304
+            const float wc = uin.wc;
+            const float pr = (float)(int)(uin.rgb & 255u), pg = (float)(int)((uin.rgb >> 8) & 255u),
+                        pb = (float)(int)((uin.rgb >> 16) & 255u);
+            const float4 c = uin.col;
+            const float cw_sum = c.x + wc;
+            c_out = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
+                                (c.x * c.w + wc * pb) / cw_sum);
+        }
+        n_own += (uin.live && uin.owned) ? 1u : 0u;
+        n_halo += (uin.live && !uin.owned) ? 1u : 0u;
+        // ---------------- S2(j-1): distance + weight from the pixel record; request {D,W} (+ colour)
+        bool need_cos;
+        {
+            const float4 P = gin.P, N = gin.N;
+            bool ok = gin.live && !(is_nan(P.x) || is_nan(P.y) || is_nan(N.x) || is_nan(N.y) || is_nan(N.z));  // sdf.cpp:260
+            // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
+            const double dx = (double)P.x - gin.pcx, dy = (double)P.y - gin.pcy, dz = (double)P.z - gin.pcz;
+            const double p2p = dx * (double)N.x + (dy * (double)N.y + dz * (double)N.z);
+            float d = (float)p2p;                                               // sdf.cpp:274
+            ok = ok && !(d > delta);                                            // sdf.cpp:280-283
+            const bool band = ok && d >= eps && d <= delta;                     // sdf.cpp:277-279
+            const float a = d - eps;
+            const double xarg = (-0.5 * (double)a) * (double)a;
+            float wn = 1.0f;
+            if (EXPPOLY) {
+                wn = band ? (float)exp_taylor10(band ? xarg : 0.0) : 1.0f;
+            } else {
+                if (band) wn = (float)exp(xarg);
+            }
+            if (d < -delta) d = -delta;                                         // sdf.cpp:285-287
+#if TSDF_INTEGRATE_DEBUG
+            if (p.debug & 2) ok = false;                                        // timing experiment only: no volume RMW
+#endif
+            u.d_new = d; u.w_new = wn; u.rgb = __float_as_uint(P.w);
+            u.owned = gin.owned;
+            u.idx = gin.idx;
+            u.live = ok;
+            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  w_new == 1 (every voxel in front of the surface)
+            // makes it the pre-rounded cosine of the record; the exp() band recomputes the f64 product (rare path).
+            u.wc = N.w;
+            need_cos = COLOR && ok && wn != 1.0f;
+        }
+        if (need_cos) u.wc = (float)((double)u.w_new * pixel_cosine(gin.N.x, gin.N.y, gin.N.z));
+        // ---------------- memory: volume reads of item j-1, stores of item j-2
+        {
+            const long long ld = u.live ? u.idx : 0ll;          // dead lanes share voxel 0's (cache-resident) line
+            u.old = dw[ld];
+            if (COLOR) u.col = crgb[ld];
+        }
+        if (uin.live) {
+            dw[uin.idx] = make_float2(d_out, w_sum);
+            if (COLOR) crgb[uin.idx] = c_out;
         }
     };
 
@@ -410,21 +430,20 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         __builtin_amdgcn_s_waitcnt(0x0F70);
         // Three-stage software pipeline over the items of this block, unrolled by two so that the
         // in-flight registers never have to be copied (a copy would force the wait):
-        //   step j:  S1(j) request pixel record | S2(j-1) request {D,W}/colour | S3(j-2) average + store
-        // every memory round-trip has a whole step of other work to hide behind.
+        //   step j:  S1(j) request pixel record | S3(j-2) average + store | S2(j-1) request {D,W}/colour
         GatherState GA, GB;
         UpdateState UA, UB;
-        GB.live = false; GB.owned = false; GB.idx = 0; GB.pix = 0; GB.pcx = GB.pcy = GB.pcz = 0.0;
-        GB.P = make_float4(0.f, 0.f, 0.f, 0.f); GB.N = GB.P;
-        UA.live = false; UB.live = false;
-        UA.owned = UB.owned = false; UA.idx = UB.idx = 0; UA.d_new = UB.d_new = 0.f; UA.w_new = UB.w_new = 1.f;
-        UA.rgb = UB.rgb = 0u; UA.old = UB.old = make_float2(0.f, 0.f);
-        UA.col = UB.col = make_float4(0.f, 0.f, 0.f, 0.f); UA.wc = UB.wc = 0.f;
+        GA.live = GB.live = false; GA.owned = GB.owned = false; GA.idx = GB.idx = 0; GA.pix = GB.pix = 0;
+        GA.pcx = GA.pcy = GA.pcz = GB.pcx = GB.pcy = GB.pcz = 0.0;
+        GA.P = GB.P = make_float4(0.f, 0.f, 0.f, 0.f); GA.N = GB.N = GA.P;
+        UA.live = UB.live = false; UA.owned = UB.owned = false; UA.idx = UB.idx = 0;
+        UA.d_new = UB.d_new = 0.f; UA.w_new = UB.w_new = 1.f; UA.wc = UB.wc = 0.f; UA.rgb = UB.rgb = 0u;
+        UA.old = UB.old = make_float2(0.f, 1.f); UA.col = UB.col = make_float4(1.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < cnt + 2; j += 2) {
-            stage1(j, GA);     stage2(GB, UA); stage3(UB);
-            stage1(j + 1, GB); stage2(GA, UB); stage3(UA);
+            step(j, GA, GB, UA, UB);          // S1(j)->GA   S2(j-1): GB->UA   S3(j-2): UB
+            step(j + 1, GB, GA, UB, UA);      // S1(j+1)->GB S2(j):   GA->UB   S3(j-1): UA
         }
-        stage3(UB);           // drain (UA was consumed by the last half-step; GB is dead: j+1 >= cnt+1 ... )
+        // (steps run up to j >= cnt+1, so S3 has retired item cnt-1 inside the loop: nothing to drain)
     }
 
     // one atomic per counter per workgroup that updated anything: wave shuffle, then LDS across the 4 waves
@@ -450,7 +469,7 @@ size_t integrate_rowbase_entries(const Grid& g) { return (size_t)(g.xe - g.xs) *
 
 int integrate_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true>, kIntegrateBlock, 0) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true, true>, kIntegrateBlock, 0) != hipSuccess || n < 1)
         n = TSDF_INTEGRATE_MIN_WAVES;
     return n;
 }
@@ -475,10 +494,15 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, worklist, work_count, rowbase, counters);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-#define TSDF_LAUNCH_INTEGRATE(C, KS) \
-    integrate_kernel<C, KS><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, work_count, rowbase, dw, crgb, pn, counters)
-    if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE(true, true); else TSDF_LAUNCH_INTEGRATE(true, false); }
-    else { if (tl.k_std) TSDF_LAUNCH_INTEGRATE(false, true); else TSDF_LAUNCH_INTEGRATE(false, false); }
+    // weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 1/16
+    const double span = (double)p.g.delta - (double)p.g.epsilon;
+    const bool exp_poly = span >= 0.0 && 0.5 * span * span <= 0.0625;
+#define TSDF_LAUNCH_INTEGRATE(C, KS, EP) \
+    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, work_count, rowbase, dw, crgb, pn, counters)
+#define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE(C, KS, true); else TSDF_LAUNCH_INTEGRATE(C, KS, false); } while (0)
+    if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
+    else { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(false, true); else TSDF_LAUNCH_INTEGRATE2(false, false); }
+#undef TSDF_LAUNCH_INTEGRATE2
 #undef TSDF_LAUNCH_INTEGRATE
     return hipGetLastError();
 }
