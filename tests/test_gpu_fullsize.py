@@ -131,3 +131,35 @@ def test_config5_shapes_1280x960_at_1024():
     A, b, st = t.accumulate()
     assert st["n_samples"] == 427 * 320 and st["n_ok"] > 100000 and np.array_equal(A, A.T)
     s.close()
+
+
+def test_config5_2048_cubed_on_one_gpu():
+    """BASELINE config 5 is 2048^3 over 8 GPUs; one MI355X (288 GB) holds the 64 GiB of {D,W} by itself, which
+    exercises 64-bit voxel indexing (the reference's int voxel count wraps at m >= 1291, sdf.cpp:9) and the
+    4 M-row work list.  Counters and device-side samples only."""
+    import tracking_sdf_amd as ts
+    m = 2048
+    seq, fr = seq_frames(2, w=1280, h=960, step=3)
+    s = ts.SDF(m, with_color=False)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    st1 = s.update(t, fr[0][0], fr[0][1])
+    st2 = s.update(t, fr[0][0], fr[0][1])
+    assert st1["n_voxels"] == m ** 3 and st1["n_updated"] == st2["n_updated"]
+    assert 0.03 < st1["n_updated"] / m ** 3 < 0.2
+    xyz = fr[0][0]
+    pts = xyz[::97, ::89].reshape(-1, 3)
+    pts = pts[np.isfinite(pts[:, 0])]
+    world = pts.astype(np.float64) @ seq.R[0].T + seq.t[0]
+    vox = (world - np.array([-3.0, -3.0, -0.5])) * (m / np.array([6.0, 6.0, 3.5])) - 0.5
+    val, ok = s.interpolate_distance(vox)
+    assert ok.mean() > 0.95 and np.all(np.abs(val[ok]) < 0.05)
+    # voxels at the far corner of the volume (linear index > 2^31) keep their constructor value
+    far = np.array([[m - 1.0, m - 1.0, m - 1.0], [m - 2.0, m - 1.0, 5.0]])
+    val, ok = s.interpolate_distance(far)
+    assert not ok.any()
+    s.set_frame(fr[1][0])
+    t.set_camera_transformation(seq.R[1], seq.t[1])
+    A, b, st = t.accumulate()
+    assert st["n_ok"] > 100000 and np.array_equal(A, A.T)
+    s.close()
