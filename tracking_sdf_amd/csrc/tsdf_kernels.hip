@@ -274,6 +274,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+#ifndef TSDF_INTEGRATE_NT
+#define TSDF_INTEGRATE_NT 1          // non-temporal colour loads/stores (colour is streamed once and never re-read by the tracker)
+#endif
 #ifndef TSDF_INTEGRATE_DEBUG
 #define TSDF_INTEGRATE_DEBUG 0      // 1 compiles the p.debug timing experiments in (uniform branches split the step)
 #endif
@@ -406,12 +409,28 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         // ---------------- memory: volume reads of item j-1, stores of item j-2
         {
             const long long ld = u.live ? u.idx : 0ll;          // dead lanes share voxel 0's (cache-resident) line
-            u.old = dw[ld];
+            u.old = dw[ld];                                     // {D,W}: the tracker re-reads these lines -> keep them cached
+#if TSDF_INTEGRATE_NT
+            if (COLOR) {   // colour is streamed once per frame and never read by the tracker: non-temporal
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                const nt_f4 c4 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(&crgb[ld]));
+                u.col = make_float4(c4.x, c4.y, c4.z, c4.w);
+            }
+#else
             if (COLOR) u.col = crgb[ld];
+#endif
         }
         if (uin.live) {
             dw[uin.idx] = make_float2(d_out, w_sum);
+#if TSDF_INTEGRATE_NT
+            if (COLOR) {
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                nt_f4 c4; c4.x = c_out.x; c4.y = c_out.y; c4.z = c_out.z; c4.w = c_out.w;
+                __builtin_nontemporal_store(c4, reinterpret_cast<nt_f4*>(&crgb[uin.idx]));
+            }
+#else
             if (COLOR) crgb[uin.idx] = c_out;
+#endif
         }
     };
 
