@@ -306,6 +306,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     unsigned code_v = 0;
     double s0_v = 0.0, s1_v = 0.0, s2_v = 0.0;
     int cnt = 0;
+    __shared__ float4 s_pieces[kIntegrateBlock / 64][128];   // wave-private un-shuffle buffer of the paired gather
 
     // One pipeline step = S1(j) | S3(j-2) | S2(j-1), written so that everything except the rare f64 cosine
     // and the two predicated stores is straight-line code: the three stages are independent instruction
@@ -354,8 +355,17 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 #if TSDF_INTEGRATE_DEBUG
             if (p.debug & 1) g.pix = __shfl(g.pix, 0);      // timing experiment only: one record per wave
 #endif
-            g.P = pn[2 * g.pix + 0];
-            g.N = pn[2 * g.pix + 1];
+            // Pixel-record gather, paired: the vector L1 looks every distinct 128-byte line up once per
+            // INSTRUCTION, and the two 16-byte halves of a 32-byte record are two instructions.  Instead, the first
+            // load fetches both halves of the records of lanes 0..31 (lane l: record of lane l/2, half l%2), the
+            // second those of lanes 32..63: each line is looked up once per item instead of twice (the L1 was the
+            // measured bottleneck: TCP busy ~90 %, 70 % of its look-ups were this gather).  S2 un-shuffles
+            // the pieces through a wave-private LDS buffer.
+            const int rec = (int)g.pix;
+            const int recA = __shfl(rec, lane >> 1);
+            const int recB = __shfl(rec, 32 + (lane >> 1));
+            g.P = pn[2 * (long long)recA + (lane & 1)];      // piece for LDS slot lane
+            g.N = pn[2 * (long long)recB + (lane & 1)];      // piece for LDS slot 64 + lane
             g.live = ok;
         }
         // ---------------- S3(j-2): running averages (unconditional arithmetic, predicated stores below)
@@ -375,8 +385,22 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         n_halo += (uin.live && !uin.owned) ? 1u : 0u;
         // ---------------- S2(j-1): distance + weight from the pixel record; request {D,W} (+ colour)
         bool need_cos;
+        float4 Nrec;
         {
-            const float4 P = gin.P, N = gin.N;
+            float4* stage = s_pieces[wv];
+            stage[lane] = gin.P;
+            stage[64 + lane] = gin.N;
+            // other LANES read what this lane wrote: the compiler's memory model is per thread, so without a
+            // wavefront-scope fence it may (and did) hoist the reads above the second write.  No instruction is
+            // emitted: LDS operations of one wave execute in order.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 P = stage[2 * lane + 0];             // own record: {Px,Py,Pz,rgb}
+            const float4 N = stage[2 * lane + 1];             //             {Nx,Ny,Nz,(float)cosine}
+            Nrec = N;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads above stay before the next step's writes
+            __builtin_amdgcn_wave_barrier();
             bool ok = gin.live && !(is_nan(P.x) || is_nan(P.y) || is_nan(N.x) || is_nan(N.y) || is_nan(N.z));  // sdf.cpp:260
             // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
             const double dx = (double)P.x - gin.pcx, dy = (double)P.y - gin.pcy, dz = (double)P.z - gin.pcz;
@@ -405,7 +429,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             u.wc = N.w;
             need_cos = COLOR && ok && wn != 1.0f;
         }
-        if (need_cos) u.wc = (float)((double)u.w_new * pixel_cosine(gin.N.x, gin.N.y, gin.N.z));
+        if (need_cos) u.wc = (float)((double)u.w_new * pixel_cosine(Nrec.x, Nrec.y, Nrec.z));
         // ---------------- memory: volume reads of item j-1, stores of item j-2
         {
             const long long ld = u.live ? u.idx : 0ll;          // dead lanes share voxel 0's (cache-resident) line
