@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--allreduce", choices=["auto", "rccl", "shm", "torch"], default="auto",
                     help="auto = self-test and time in-library RCCL and the shared-memory fan-in, keep the faster (torch hook if both fail)")
     ap.add_argument("--host-frames", action="store_true", help="hand frames over as HOST buffers every step (PCIe-inclusive rate; not the headline value)")
+    ap.add_argument("--depth-input", action="store_true", help="hand over raw uint16 depth + rgb as HOST buffers; back-projection, bilateral filter and normals run on the GPU (tsdf_set_depth_frame); PCIe-inclusive, not the headline value")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--trajectory-out", default=None, help="write the estimated trajectory (TUM format)")
     return ap.parse_args()
@@ -164,6 +165,8 @@ def main():
     frames = [seq.frame(k) for k in range(n_frames)]
     d_frames = [(torch.from_numpy(x).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev))
                 for x, n, c in frames]
+    depth16 = [np.where(np.isnan(x[..., 2]), 0, np.round(x[..., 2] * 5000.0)).astype(np.uint16) for x, _, _ in frames] \
+        if args.depth_input else None
     torch.cuda.synchronize()
 
     # ---- volume: x-slab of this rank (+ halo), colour lanes as in the reference
@@ -255,7 +258,9 @@ def main():
     track_wall = [0.0]
 
     def step(k, timed_stats=None):
-        if args.host_frames:
+        if args.depth_input:
+            sdf.set_depth_frame(depth16[k], frames[k][2])
+        elif args.host_frames:
             sdf.set_frame(*frames[k])
         else:
             dx, dn, dc = d_frames[k]
@@ -268,8 +273,11 @@ def main():
         sdf.update(want_stats=False)
 
     # frame 0: integrate only at the reference's initial pose (sdf_reconstruction.cpp:69-74)
-    dx, dn, dc = d_frames[0]
-    sdf.set_frame_device(dx.data_ptr(), dn.data_ptr(), dc.data_ptr(), args.width, args.height)
+    if args.depth_input:
+        sdf.set_depth_frame(depth16[0], frames[0][2])
+    else:
+        dx, dn, dc = d_frames[0]
+        sdf.set_frame_device(dx.data_ptr(), dn.data_ptr(), dc.data_ptr(), args.width, args.height)
     sdf.update(want_stats=False)
     est = [trk.trans.copy()]
     for k in range(1, 1 + args.warmup):
@@ -317,7 +325,8 @@ def main():
             "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32 volume / f64 geometry+normal equations",
-            "data": "synthetic" + (" (frames handed over as host buffers: PCIe-inclusive)" if args.host_frames else ""),
+            "data": "synthetic" + (" (frames handed over as host buffers: PCIe-inclusive)" if args.host_frames else "")
+                    + (" (raw uint16 depth + rgb handed over as host buffers, pre-processed on the GPU: PCIe-inclusive)" if args.depth_input else ""),
             "config": {"workload": f"fr1/plant ground-truth camera path at 30 Hz (re-based to the reference's initial "
                                    f"pose), analytic room+sphere+boxes scene, {args.width}x{args.height} depth with "
                                    f"Kinect noise + 2% holes, {args.m}^3 voxels, 6x6x3.5 m volume, "

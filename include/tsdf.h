@@ -129,6 +129,27 @@ int tsdf_set_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uin
 int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb,
                           int32_t width, int32_t height);
 
+/* ---- optional: depth pre-processing on the GPU.  Replaces, for callers that have a raw
+ * depth image instead of PCL clouds, the host-side steps of sdf_reconstruction.cpp:29-49 (cloud conversion,
+ * pcl::FastBilateralFilter, pcl::IntegralImageNormalEstimation).  PCL is not available here, so this is the
+ * repository's own stand-in (specified in csrc/preproc_kernels.hip and tests/preproc_ref.py), NOT a bit-level
+ * reimplementation of PCL: parity with PCL is unpinned.  The result becomes the current frame exactly as if
+ * tsdf_set_frame had been called with the produced xyz / normals / rgb. */
+typedef struct tsdf_preproc_params {
+    float   depth_scale;        /* metres per unit of a uint16 depth image (TUM: 1/5000); 0 = invalid pixel     */
+    float   sigma_s;            /* bilateral spatial sigma, pixels (PCL default 15)                               */
+    float   sigma_r;            /* bilateral range sigma, metres   (PCL default 0.05)                             */
+    int32_t radius;             /* bilateral window radius, pixels; 0 = no filtering; <= 32 (default 2*sigma_s capped) */
+    int32_t normal_radius;      /* gradient averaging radius, pixels (reference smoothing size 10 -> 5); 1..8      */
+    float   max_depth_change;   /* depth-discontinuity factor (reference 0.02)                                    */
+} tsdf_preproc_params;
+void tsdf_default_preproc(tsdf_preproc_params *p);
+/* depth16 (uint16) or depthf (float metres, <= 0 / NaN invalid): exactly one non-null; host pointers; rgb may be null */
+int tsdf_set_depth_frame(tsdf_handle *h, const uint16_t *depth16, const float *depthf, const uint8_t *rgb,
+                         int32_t width, int32_t height, const tsdf_preproc_params *params);
+/* copy the current pre-processed frame back (any pointer may be null): xyz, normals as float[h*w*3] */
+int tsdf_get_preprocessed(tsdf_handle *h, float *xyz, float *nrm);
+
 /* ---- the hot path ------------------------------------------------------------------------- */
 int tsdf_integrate(tsdf_handle *h, tsdf_integrate_stats *stats);  /* SDF::update at the current pose */
 int tsdf_track(tsdf_handle *h, tsdf_track_stats *stats);          /* estimate_new_position: updates the pose */

@@ -1,0 +1,95 @@
+"""GPU depth pre-processing (tsdf_set_depth_frame) against its NumPy statement (tests/preproc_ref.py).
+Tolerances: z within 2e-6 relative (expf differs in the last bits between ocml and NumPy), x,y bit-exact,
+normals within 2e-4 (angle) where both are defined, identical NaN masks away from ties."""
+import numpy as np
+import pytest
+
+import preproc_ref as ref
+from tracking_sdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def depth_image(w, h, k=0, to_u16=True):
+    seq = synth.Sequence(n_frames=k + 1, width=w, height=h, noise=True, holes=0.03, step=5)
+    xyz, nrm, rgb = seq.frame(k)
+    z = xyz[..., 2]
+    if to_u16:
+        d = np.where(np.isnan(z), 0, np.round(z * 5000.0)).astype(np.uint16)
+    else:
+        d = np.where(np.isnan(z), 0.0, z).astype(np.float32)
+    return seq, d, rgb
+
+
+@pytest.mark.parametrize("w,h,params", [
+    (96, 72, dict(radius=4, sigma_s=2.0, sigma_r=0.03, normal_radius=2)),
+    (160, 120, dict(radius=9, sigma_s=4.5, sigma_r=0.05, normal_radius=5)),
+    (64, 48, dict()),                                   # PCL-like defaults: sigma_s 15, radius 30
+    (80, 60, dict(radius=0, normal_radius=1)),          # no filtering
+])
+def test_preprocessing_matches_numpy_statement(w, h, params):
+    import tracking_sdf_amd as ts
+    seq, d16, rgb = depth_image(w, h)
+    s = ts.SDF(32)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    s.set_depth_frame(d16, rgb, **params)
+    xyz, nrm = s.get_preprocessed()
+    want_xyz, want_n = ref.preprocess(d16, seq.K, **params)
+    assert np.array_equal(np.isnan(xyz[..., 2]), np.isnan(want_xyz[..., 2]))
+    ok = ~np.isnan(want_xyz[..., 2])
+    assert np.array_equal(xyz[..., :2][ok], want_xyz[..., :2][ok])                 # raw back-projection: exact
+    assert np.max(np.abs(xyz[..., 2][ok] - want_xyz[..., 2][ok]) / want_xyz[..., 2][ok]) < 2e-6
+    both = ~np.isnan(nrm[..., 0]) & ~np.isnan(want_n[..., 0])
+    assert (np.isnan(nrm[..., 0]) != np.isnan(want_n[..., 0])).mean() < 2e-3        # discontinuity-test ties only
+    assert both.mean() > 0.5
+    cosang = np.sum(nrm[both] * want_n[both], axis=-1)
+    assert np.min(cosang) > 1.0 - 2e-6 or np.mean(cosang < 1.0 - 2e-8) < 1e-2
+    assert np.allclose(np.linalg.norm(nrm[both], axis=-1), 1.0, atol=1e-5)
+    assert np.all(np.sum(nrm[both] * xyz[both], axis=-1) <= 0)                      # facing the camera
+    s.close()
+
+
+def test_float_depth_input_and_pipeline_runs_from_depth_only():
+    """Depth-only input drives the whole hot path: integrate, then track the next frame."""
+    import tracking_sdf_amd as ts
+    w, h, m = 160, 120, 64
+    seq = synth.Sequence(n_frames=3, width=w, height=h, noise=True, holes=0.02, step=3)
+    s = ts.SDF(m)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    params = dict(radius=6, sigma_s=3.0, sigma_r=0.05, normal_radius=3)
+    for k in range(3):
+        xyz, nrm, rgb = seq.frame(k)
+        z = np.where(np.isnan(xyz[..., 2]), 0.0, xyz[..., 2]).astype(np.float32)
+        s.set_depth_frame(z, rgb, **params)
+        if k > 0:
+            st = t.estimate_new_position()
+            assert 1 <= st["iterations"] <= 20
+        st = s.update()
+        assert st["n_updated"] > 1000
+    assert np.linalg.norm(t.trans - seq.t[2]) < 0.08           # follows the true path (voxel = 9 cm here)
+    # the smoothed normals agree with the analytic ones of the synthetic scene on the big planes
+    xyz_p, nrm_p = s.get_preprocessed()
+    ana = seq.frame(2)[1]
+    both = ~np.isnan(nrm_p[..., 0]) & ~np.isnan(ana[..., 0])
+    cosang = np.sum(nrm_p[both] * ana[both], axis=-1)
+    assert np.median(cosang) > 0.99
+    s.close()
+
+
+def test_preproc_argument_checks():
+    import tracking_sdf_amd as ts
+    s = ts.SDF(32)
+    d = np.zeros((48, 64), dtype=np.uint16)
+    with pytest.raises(ts.TsdfError) as ei:
+        s.set_depth_frame(d)                               # intrinsics missing
+    assert ei.value.code == ts.E_NO_INTRINSICS
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(synth.default_intrinsics(64, 48))
+    with pytest.raises(ts.TsdfError):
+        s.set_depth_frame(d, radius=40)
+    s.set_depth_frame(d, radius=2)                         # all-invalid depth: fine, everything NaN
+    xyz, nrm = s.get_preprocessed()
+    assert np.isnan(xyz).all() and np.isnan(nrm).all()
+    s.close()

@@ -41,6 +41,12 @@ class Config(C.Structure):
                 ("slab_x0", C.c_int32), ("slab_x1", C.c_int32), ("halo", C.c_int32), ("device", C.c_int32)]
 
 
+class PreprocParams(C.Structure):
+    """struct tsdf_preproc_params"""
+    _fields_ = [("depth_scale", C.c_float), ("sigma_s", C.c_float), ("sigma_r", C.c_float), ("radius", C.c_int32),
+                ("normal_radius", C.c_int32), ("max_depth_change", C.c_float)]
+
+
 class IntegrateStats(C.Structure):
     _fields_ = [("n_updated", C.c_int64), ("n_updated_halo", C.c_int64), ("n_voxels", C.c_int64)]
 
@@ -81,7 +87,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p
 ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
-    "tsdf_set_frame_device", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
+    "tsdf_set_frame_device", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
@@ -127,6 +133,9 @@ def lib():
         "tsdf_get_pose": (C.c_int, [H, dp, dp, dp, dp]),
         "tsdf_set_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
         "tsdf_set_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+        "tsdf_default_preproc": (None, [C.POINTER(PreprocParams)]),
+        "tsdf_set_depth_frame": (C.c_int, [H, C.POINTER(C.c_uint16), fp, u8p, C.c_int32, C.c_int32, C.POINTER(PreprocParams)]),
+        "tsdf_get_preprocessed": (C.c_int, [H, fp, fp]),
         "tsdf_integrate": (C.c_int, [H, C.POINTER(IntegrateStats)]),
         "tsdf_track": (C.c_int, [H, C.POINTER(TrackStats)]),
         "tsdf_accumulate": (C.c_int, [H, dp, dp, C.POINTER(AccumStats)]),
@@ -305,6 +314,39 @@ class SDF:
             assert rgb.shape == xyz.shape
             cptr = rgb.ctypes.data_as(C.POINTER(C.c_uint8))
         self._check(lib().tsdf_set_frame(self._h, _fptr(xyz), nptr, cptr, w, h))
+
+    def set_depth_frame(self, depth, rgb=None, **params):
+        """Raw depth image (uint16 with depth_scale, or float32 metres) -> GPU back-projection + bilateral filter +
+        normals -> current frame.  Keyword overrides: depth_scale, sigma_s, sigma_r, radius, normal_radius,
+        max_depth_change.  Needs the intrinsics (CameraTracking.set_K) first."""
+        pp = PreprocParams()
+        lib().tsdf_default_preproc(C.byref(pp))
+        for k, v in params.items():
+            if not hasattr(pp, k):
+                raise AttributeError(f"tsdf_preproc_params has no field {k}")
+            setattr(pp, k, v)
+        depth = np.ascontiguousarray(depth)
+        h, w = depth.shape
+        d16 = df = None
+        if depth.dtype == np.uint16:
+            d16 = depth.ctypes.data_as(C.POINTER(C.c_uint16))
+        else:
+            depth = np.ascontiguousarray(depth, dtype=np.float32)
+            df = _fptr(depth)
+        cptr = None
+        if rgb is not None:
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            assert rgb.shape == (h, w, 3)
+            cptr = rgb.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(lib().tsdf_set_depth_frame(self._h, d16, df, cptr, w, h, C.byref(pp)))
+        self._frame_shape = (h, w)
+
+    def get_preprocessed(self):
+        h, w = self._frame_shape
+        xyz = np.empty((h, w, 3), dtype=np.float32)
+        nrm = np.empty((h, w, 3), dtype=np.float32)
+        self._check(lib().tsdf_get_preprocessed(self._h, _fptr(xyz), _fptr(nrm)))
+        return xyz, nrm
 
     def set_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
         """Borrow device pointers (ints, e.g. torch.Tensor.data_ptr()) of images already in HBM."""

@@ -65,6 +65,8 @@ struct tsdf_handle {
     float* in_xyz = nullptr; float* in_nrm = nullptr; uint8_t* in_rgb = nullptr;   // device staging (owned)
     float* pin_xyz = nullptr; float* pin_nrm = nullptr; uint8_t* pin_rgb = nullptr;  // pinned host staging
     size_t in_cap = 0;             // pixels the staging buffers hold
+    float* pre_z = nullptr; float* pre_zf = nullptr; void* pre_depth = nullptr; void* pin_depth = nullptr;   // pre-processing scratch
+    size_t pre_cap = 0;
     float4* pn = nullptr;          // 2 x float4 per pixel
     float4* samples = nullptr;
     size_t pn_cap = 0, samples_cap = 0;
@@ -128,6 +130,14 @@ int fail(tsdf_handle* h, int code, const char* fmt, ...) {
 int bind_device(tsdf_handle* h) {
     HIP_TRY(h, hipSetDevice(h->device));
     return TSDF_OK;
+}
+
+void free_preproc(tsdf_handle* h) {
+    if (h->pre_z) (void)hipFree(h->pre_z);
+    if (h->pre_zf) (void)hipFree(h->pre_zf);
+    if (h->pre_depth) (void)hipFree(h->pre_depth);
+    if (h->pin_depth) (void)hipHostFree(h->pin_depth);
+    h->pre_z = h->pre_zf = nullptr; h->pre_depth = h->pin_depth = nullptr; h->pre_cap = 0;
 }
 
 void free_frame(tsdf_handle* h) {
@@ -531,6 +541,7 @@ void tsdf_destroy(tsdf_handle* h) {
     h->comm.destroy();
     shm_close(h);
     free_frame(h);
+    free_preproc(h);
     if (h->pn) (void)hipFree(h->pn);
     if (h->samples) (void)hipFree(h->samples);
     if (h->partials) (void)hipFree(h->partials);
@@ -622,6 +633,67 @@ int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm
     rc = ensure_frame_buffers(h, width, height, false);
     if (rc) return rc;
     return run_pack(h, d_xyz, d_nrm, d_rgb);
+}
+
+// ---- depth pre-processing (optional stage in front of the hot path) -------------------------------------------
+
+void tsdf_default_preproc(tsdf_preproc_params* p) {
+    if (!p) return;
+    p->depth_scale = 1.0f / 5000.0f;
+    p->sigma_s = 15.0f;
+    p->sigma_r = 0.05f;
+    p->radius = 30;
+    p->normal_radius = 5;
+    p->max_depth_change = 0.02f;
+}
+
+int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
+                         int32_t width, int32_t height, const tsdf_preproc_params* params) {
+    if (!h || (!depth16 == !depthf) || width <= 0 || height <= 0)
+        return h ? fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: exactly one of depth16 / depthf, positive size") : TSDF_E_BADARG;
+    if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "tsdf_set_depth_frame needs the intrinsics for the back-projection");
+    tsdf_preproc_params pp;
+    if (params) pp = *params; else tsdf_default_preproc(&pp);
+    if (pp.radius < 0 || pp.radius > 32 || pp.normal_radius < 1 || pp.normal_radius > 8 || !(pp.sigma_s > 0) || !(pp.sigma_r > 0))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: bad parameters (radius %d, normal_radius %d)", pp.radius, pp.normal_radius);
+    int rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    if (npix > h->pre_cap) {
+        free_preproc(h);
+        HIP_TRY(h, hipMalloc((void**)&h->pre_z, npix * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->pre_zf, npix * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->pre_depth, npix * sizeof(float)));
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_depth, npix * sizeof(float), hipHostMallocDefault));
+        h->pre_cap = npix;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));           // pinned staging may still feed the previous frame
+    const size_t dbytes = npix * (depth16 ? sizeof(uint16_t) : sizeof(float));
+    std::memcpy(h->pin_depth, depth16 ? (const void*)depth16 : (const void*)depthf, dbytes);
+    HIP_TRY(h, hipMemcpyAsync(h->pre_depth, h->pin_depth, dbytes, hipMemcpyHostToDevice, h->stream));
+    if (rgb) {
+        std::memcpy(h->pin_rgb, rgb, npix * 3);
+        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->stream));
+    }
+    const float Kf[4] = {(float)h->K[0], (float)h->K[4], (float)h->K[2], (float)h->K[5]};
+    HIP_TRY(h, launch_preproc(h->stream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
+                              depth16 ? nullptr : (const float*)h->pre_depth, pp.depth_scale, width, height, Kf,
+                              pp.radius, pp.sigma_s, pp.sigma_r, pp.normal_radius, pp.max_depth_change,
+                              h->pre_z, h->pre_zf, h->in_xyz, h->in_nrm));
+    return run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr);
+}
+
+int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!h->in_xyz || h->in_cap < (size_t)h->fw * h->fh) return fail(h, TSDF_E_NO_FRAME, "no pre-processed frame held");
+    const size_t bytes = (size_t)h->fw * h->fh * 3 * sizeof(float);
+    if (xyz) HIP_TRY(h, hipMemcpyAsync(xyz, h->in_xyz, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(nrm, h->in_nrm, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TSDF_OK;
 }
 
 // ---- hot path ----------------------------------------------------------------------------------------

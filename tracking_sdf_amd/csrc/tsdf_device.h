@@ -78,6 +78,9 @@ hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, c
 hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);
 size_t track_partials_doubles(int32_t n_samples);
+hipError_t launch_preproc(hipStream_t s, const uint16_t* d16, const float* dflt, float scale, int w, int h,
+                          const float* K /*fx fy cx cy*/, int R, float sigma_s, float sigma_r, int nr, float max_change,
+                          float* z, float* zf, float* xyz, float* nrm);
 hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const double* vox, int32_t n,
                          float* val, int32_t* ok);
 hipError_t launch_split(hipStream_t s, const float2* dw, float* d, float* w, int64_t n);
