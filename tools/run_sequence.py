@@ -6,9 +6,10 @@ whole sequence on the HIP path, writing ./trajectory.txt in the reference's form
   --ground-truth-poses: the reference's _useGroundTruth switch (:51-66): no tracking, fuse at the given poses
 
 Input: the synthetic fr1/plant stream (default; no TUM images exist on the box), or --tum DIR with a TUM
-RGB-D directory (depth.txt + depth/*.png, 16-bit, /5000 m): depth is back-projected with --fx/--fy/--cx/--cy
-and normals come from a plain cross-product stand-in (the reference uses PCL's bilateral filter + integral
-image normals, which are not available here: parity of that pre-processing is UNPINNED).
+RGB-D directory (depth.txt + depth/*.png, 16-bit, /5000 m): the raw depth image goes to tsdf_set_depth_frame,
+i.e. back-projection (--fx/--fy/--cx/--cy), bilateral filter and normals run on the GPU (the reference uses
+PCL's bilateral filter + integral image normals, which are not available here: parity of that pre-processing
+is UNPINNED).
 """
 import argparse
 import json
@@ -48,7 +49,8 @@ def quat_from_rot(R):
     return q
 
 
-def tum_frames(root, fx, fy, cx, cy, limit):
+def tum_frames(root, limit):
+    """Yields (stamp, depth uint16 image) of a TUM RGB-D directory."""
     from PIL import Image
     items = []
     with open(os.path.join(root, "depth.txt")) as f:
@@ -60,21 +62,7 @@ def tum_frames(root, fx, fy, cx, cy, limit):
     if limit:
         items = items[:limit]
     for stamp, name in items:
-        z = np.asarray(Image.open(os.path.join(root, name)), dtype=np.float32) / 5000.0
-        h, w = z.shape
-        z = np.where(z > 0, z, np.nan).astype(np.float32)
-        u, v = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
-        xyz = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1).astype(np.float32)
-        dx = np.full_like(xyz, np.nan)
-        dy = np.full_like(xyz, np.nan)
-        dx[:, 1:-1] = xyz[:, 2:] - xyz[:, :-2]
-        dy[1:-1, :] = xyz[2:, :] - xyz[:-2, :]
-        n = np.cross(dx, dy)
-        n /= np.linalg.norm(n, axis=-1, keepdims=True)
-        flip = (n * xyz).sum(-1) > 0
-        n = np.where(flip[..., None], -n, n).astype(np.float32)
-        rgb = np.full(xyz.shape, 128, dtype=np.uint8)
-        yield stamp, xyz, n, rgb
+        yield stamp, np.asarray(Image.open(os.path.join(root, name))).astype(np.uint16)
 
 
 def main():
@@ -97,12 +85,12 @@ def main():
 
     import tracking_sdf_amd as ts
     from tracking_sdf_amd import synth
-    sdf = ts.SDF(a.m)
+    sdf = ts.SDF(a.m, with_color=not a.tum)        # TUM depth-only input carries no registered colour here
     trk = ts.CameraTracking(sdf=sdf)
     gt_R = gt_t = None
     if a.tum:
         K = np.array([[a.fx, 0, a.cx], [0, a.fy, a.cy], [0, 0, 1.0]])
-        stream = tum_frames(a.tum, a.fx, a.fy, a.cx, a.cy, a.frames)
+        stream = ((st_, d16, None, None) for st_, d16 in tum_frames(a.tum, a.frames))
     else:
         seq = synth.Sequence(n_frames=a.frames, width=a.width, height=a.height, noise=not a.no_noise,
                              holes=0.0 if a.no_noise else 0.02)
@@ -115,6 +103,9 @@ def main():
     t_hot = 0.0
     for frame_num, (stamp, xyz, nrm, rgb) in enumerate(stream, start=1):
         t0 = time.perf_counter()
+        if a.tum:
+            sdf.set_depth_frame(xyz, None)                      # `xyz` holds the uint16 depth image here
+            xyz = None
         if a.ground_truth_poses and gt_R is not None:
             trk.set_camera_transformation(gt_R[frame_num - 1], gt_t[frame_num - 1])
         elif frame_num > 1:
@@ -127,7 +118,10 @@ def main():
             q = quat_from_rot(trk.rot)
             with open(a.out, "a") as f:
                 f.write("%.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f\n" % (stamp, *trk.trans, *q))
-        sdf.update(trk, xyz, nrm, rgb, want_stats=False)
+        if a.tum:
+            sdf.update(want_stats=False)
+        else:
+            sdf.update(trk, xyz, nrm, rgb, want_stats=False)
         sdf.synchronize()
         t_hot += time.perf_counter() - t0
         n += 1

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float* __restrict_
                 const float zq = rowp[dx];
                 if (nan_f(zq)) continue;
                 const float dz = zq - zc;
-                const float wgt = expf(-((float)(dx * dx + dy * dy) * inv2ss) - (dz * dz) * inv2sr);
+                // __expf = v_exp_f32(x * log2 e): ~1e-6 relative, 5x cheaper than ocml's expf; 3721 taps per pixel
+                const float wgt = __expf(-((float)(dx * dx + dy * dy) * inv2ss) - (dz * dz) * inv2sr);
                 num += wgt * zq;
                 den += wgt;
             }
