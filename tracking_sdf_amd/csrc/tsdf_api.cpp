@@ -76,6 +76,9 @@ struct tsdf_handle {
     double* red_dev = nullptr;     // kRedWidth
     double* red_host = nullptr;    // pinned, kRedWidth doubles + the pass-number word the host polls
     unsigned long long pass_seq = 0;
+    double* fold_host = nullptr;   // pinned: kFoldBlocks slots of kFoldSlotDoubles (single-rank host fold)
+    bool host_fold = true;         // single rank: folded rows go to the host (TSDF_HOST_FOLD=0 keeps the device final kernel; +1 %)
+    unsigned integrate_launches = 0;
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
 
     // comm
@@ -320,9 +323,11 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     double* host_row = h->red_host;          // where the final kernel publishes this rank's row
     if (use_shm)
         host_row = reinterpret_cast<double*>(h->shm.dev_base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot);
+    // single rank + polling: the folded rows come to the host directly (one dependent launch fewer)
+    const bool host_fold = h->host_fold && !use_rccl && !use_shm && h->poll && !h->timing_track;
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
     HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
-                            use_rccl ? nullptr : host_row, seq));
+                            use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, seq));
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
     if (use_rccl) {
         std::string cerr;
@@ -333,7 +338,38 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
                                        h->stream));
     }
     bool arrived = false;
-    if (use_shm) {
+    if (host_fold) {
+        const int fb = track_fold_blocks(h->n_samples);
+        double tot[kPartWidth];
+        for (int e = 0; e < kPartWidth; ++e) tot[e] = 0.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool all = true;
+        for (int b = 0; b < fb && all; ++b) {
+            const double* slot = h->fold_host + (size_t)b * kFoldSlotDoubles;
+            const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(slot + kPartWidth);
+            for (unsigned spins = 0;; ++spins) {
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { all = false; break; }
+            }
+        }
+        if (!all) HIP_TRY(h, hipStreamSynchronize(h->stream));   // a row did not show up in time: synchronise for real
+        // the summation order of the device-side final kernel (6 interleaved row groups, then the groups), so
+        // that every exchange mode produces the same bits
+        constexpr int RG = 256 / kPartWidth;
+        for (int e = 0; e < kPartWidth; ++e) {
+            double sg[RG];
+            for (int g = 0; g < RG; ++g) {
+                double v = 0.0;
+                for (int b = g; b < fb; b += RG) v += h->fold_host[(size_t)b * kFoldSlotDoubles + e];
+                sg[g] = v;
+            }
+            double v = sg[0];
+            for (int g = 1; g < RG; ++g) v += sg[g];
+            tot[e] = v;
+        }
+        track_unpack_row(tot, h->red_host);
+        arrived = true;
+    } else if (use_shm) {
         int rc2 = shm_fan_in(h, seq, kRedAllreduce);
         if (rc2) return rc2;
         arrived = true;
@@ -511,7 +547,10 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMemsetAsync(h->counters, 0, kNumCounters * sizeof(unsigned long long), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->counters_host, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
     CREATE_TRY(hipMalloc((void**)&h->worklist, integrate_worklist_entries(g) * sizeof(unsigned)));
-    CREATE_TRY(hipMalloc((void**)&h->work_count, sizeof(unsigned)));
+    CREATE_TRY(hipMalloc((void**)&h->work_count, 2 * sizeof(unsigned)));
+    CREATE_TRY(hipMemsetAsync(h->work_count, 0, 2 * sizeof(unsigned), h->stream));
+    CREATE_TRY(hipHostMalloc((void**)&h->fold_host, (size_t)kFoldBlocks * kFoldSlotDoubles * sizeof(double), hipHostMallocDefault));
+    std::memset(h->fold_host, 0, (size_t)kFoldBlocks * kFoldSlotDoubles * sizeof(double));
     CREATE_TRY(hipMalloc((void**)&h->rowbase, integrate_rowbase_entries(g) * sizeof(double)));
     {
         hipDeviceProp_t prop;
@@ -525,6 +564,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipHostMalloc((void**)&h->red_host, (kRedWidth + 2) * sizeof(double), hipHostMallocDefault));
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
     { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
+    { const char* ev = std::getenv("TSDF_HOST_FOLD"); h->host_fold = !(ev && std::atoi(ev) == 0); }
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
     CREATE_TRY(hipEventCreate(&h->ev_track.b));
     CREATE_TRY(launch_fill(h->stream, g, h->dw, h->crgb, cfg->width + cfg->height + cfg->depth));   // sdf.cpp:29
@@ -547,6 +587,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
+    if (h->fold_host) (void)hipHostFree(h->fold_host);
     if (h->counters) (void)hipFree(h->counters);
     if (h->worklist) (void)hipFree(h->worklist);
     if (h->work_count) (void)hipFree(h->work_count);
@@ -724,7 +765,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     rc = timed_begin(h, 0, &ep);
     if (rc) return rc;
     HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                                h->rowbase, h->integrate_blocks));
+                                h->rowbase, h->integrate_blocks, h->integrate_launches++));
     rc = timed_end(h, ep);
     if (rc) return rc;
     h->cnt.integrate_calls++;

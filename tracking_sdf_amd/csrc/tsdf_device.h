@@ -17,6 +17,26 @@ namespace tsdf {
 //   [31]     out-of-grid samples   [32] NaN samples   [33] sampled pixels
 constexpr int kRedWidth = 34;
 constexpr int kRedAllreduce = 30;   // the leading part that is summed over ranks
+// partial-row layout of track_kernel / track_fold_kernel: [5*q + d] (q = 0..5, d = 0..4) = J[q]*J[(q+d)%6] for
+// d <= 3 and r*J[q] for d = 4, then counters
+constexpr int kPartTerms = 30, kPartViol = 31, kPartOk = 32, kPartInOwned = 33, kPartOog = 34, kPartNan = 35,
+              kPartSamples = 36, kPartWidth = 40;
+constexpr int kFoldBlocks = 64;          // rows left after track_fold_kernel
+constexpr int kFoldSlotDoubles = 48;     // pinned host slot per folded row: 40 values + pass-number word + pad
+
+// partial row (kPartWidth) -> result row (kRedWidth); shared by track_final_kernel's logic and the host fold
+inline void track_unpack_row(const double* tot, double* red) {
+    int e = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            const int d = b - a;
+            red[e++] = (d <= 3) ? tot[5 * a + d] : tot[5 * b + (6 - d)];
+        }
+    for (int a = 0; a < 6; ++a) red[21 + a] = tot[5 * a + 4];
+    red[27] = tot[kPartTerms]; red[28] = tot[kPartViol]; red[29] = tot[kPartOk]; red[30] = tot[kPartInOwned];
+    red[31] = tot[kPartOog]; red[32] = tot[kPartNan]; red[33] = tot[kPartSamples];
+}
+
 constexpr int kTrackBlock = 256;    // threads per tracker workgroup (4 wavefronts)
 constexpr int kIntegrateBlock = 256;
 
@@ -70,11 +90,16 @@ size_t integrate_rowbase_entries(const Grid& g);
 int integrate_blocks_per_cu();
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            unsigned* worklist, unsigned* work_count, double* rowbase, int n_blocks);
+                            unsigned* worklist, unsigned* work_count /*two counters*/, double* rowbase, int n_blocks,
+                            unsigned launch_parity);
 // partials: track_partials_doubles(n_samples) doubles; red_dev: kRedWidth doubles; red_host (pinned, may
 // be null): kRedWidth doubles + one 64-bit word that receives `seq` after the row is complete.
+// fold_host (pinned, kFoldBlocks x kFoldSlotDoubles doubles, may be null): when given, the folded rows go to
+// the host and the final kernel is skipped (single-rank mode; the host adds the rows).
 hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                        double* partials, double* red_dev, double* red_host, unsigned long long seq);
+                        double* partials, double* red_dev, double* red_host, double* fold_host,
+                        unsigned long long seq);
+int track_fold_blocks(int32_t n_samples);
 hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);
 size_t track_partials_doubles(int32_t n_samples);

@@ -153,11 +153,13 @@ __device__ __forceinline__ void clip_affine(double a, double b, double& lo, doub
 __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
                                                                 unsigned* __restrict__ list,
                                                                 unsigned* __restrict__ count,
+                                                                unsigned* __restrict__ next_count,
                                                                 double* __restrict__ rowbase,
                                                                 unsigned long long* __restrict__ counters) {
     const int m = p.g.m;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
+    if (blockIdx.x == 0 && tid == 0) *next_count = 0u;
     int c0 = 0, n = 0;
     if (row < tl.n_rows) {
         int il, j;
@@ -519,7 +521,8 @@ int integrate_blocks_per_cu() {
 
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            unsigned* worklist, unsigned* work_count, double* rowbase, int n_blocks) {
+                            unsigned* worklist, unsigned* work_count, double* rowbase, int n_blocks,
+                            unsigned launch_parity) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
@@ -531,17 +534,20 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     tl.k_std = (p.K[1] == 0.0 && p.K[3] == 0.0 && p.K[6] == 0.0 && p.K[7] == 0.0 && p.K[8] == 1.0) ? 1 : 0;
     if (p.debug & 4) tl.k_std = 0;
     if (tl.n_rows >= (1ll << 26)) return hipErrorInvalidValue;       // row index must fit the 26-bit item code
-    hipError_t e = hipMemsetAsync(work_count, 0, sizeof(unsigned), s);
-    if (e != hipSuccess) return e;
+    // two work counters used alternately: this launch's clip kernel re-zeroes the one the NEXT launch will use
+    // (nobody touches it during this launch), which saves a memset node per frame
+    unsigned* const cur = work_count + (launch_parity & 1);
+    unsigned* const nxt = work_count + ((launch_parity + 1) & 1);
+    hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
-    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, worklist, work_count, rowbase, counters);
+    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, worklist, cur, nxt, rowbase, counters);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 1/16
     const double span = (double)p.g.delta - (double)p.g.epsilon;
     const bool exp_poly = span >= 0.0 && 0.5 * span * span <= 0.0625;
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP) \
-    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, work_count, rowbase, dw, crgb, pn, counters)
+    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, cur, rowbase, dw, crgb, pn, counters)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE(C, KS, true); else TSDF_LAUNCH_INTEGRATE(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
     else { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(false, true); else TSDF_LAUNCH_INTEGRATE2(false, false); }
@@ -642,9 +648,6 @@ hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const d
 enum { kClsSkip = 0, kClsOog = 1, kClsIn = 2 };
 constexpr int kLanesPerSample = 16;
 constexpr int kSamplesPerBlock = kTrackBlock / kLanesPerSample;   // 16
-// partial-row layout of track_kernel: [5*q + d] (q = 0..5, d = 0..4), then counters
-constexpr int kPartTerms = 30, kPartViol = 31, kPartOk = 32, kPartInOwned = 33, kPartOog = 34, kPartNan = 35,
-              kPartSamples = 36, kPartWidth = 40;
 
 struct SampleGeom {
     double px, py, pz;   // camera-frame point
@@ -860,7 +863,6 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
 // Fixed-order final sum in two levels (kernel boundaries = visibility; no atomics, no spin):
 // track_fold_kernel folds the per-workgroup rows into <= kFoldBlocks rows, track_final_kernel adds those
 // and converts to the result row of tsdf_device.h.  Every sum has a fixed order: bitwise reproducible.
-constexpr int kFoldBlocks = 64;
 
 __device__ __forceinline__ void fold_rows(const double* __restrict__ rows, int first, int last, double* out /*LDS[kPartWidth]*/) {
     constexpr int RG = 256 / kPartWidth;             // 6 row groups of 40 columns
@@ -882,13 +884,28 @@ __device__ __forceinline__ void fold_rows(const double* __restrict__ rows, int f
 }
 
 __global__ __launch_bounds__(256) void track_fold_kernel(const double* __restrict__ partials, int nrows,
-                                                          double* __restrict__ folded) {
+                                                          double* __restrict__ folded,
+                                                          double* __restrict__ host_rows, unsigned long long seq) {
     __shared__ double tot[kPartWidth];
     const int per = (nrows + gridDim.x - 1) / gridDim.x;
     const int first = blockIdx.x * per;
     const int last = first + per < nrows ? first + per : nrows;
     fold_rows(partials, first, last, tot);
-    if (threadIdx.x < kPartWidth) folded[(long long)blockIdx.x * kPartWidth + threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x < 64) {                                   // one wave
+        if (host_rows) {
+            // single-rank hand-off: the <= 64 folded rows go straight to pinned host memory (one coalesced
+            // 320-byte store), a system-scope fence, then the pass number; the host adds the rows in block
+            // order -- the device-side final kernel (one more dependent launch, ~5 us) is not needed.
+            double* slot = host_rows + (size_t)blockIdx.x * kFoldSlotDoubles;
+            if (threadIdx.x < kPartWidth) slot[threadIdx.x] = tot[threadIdx.x];
+            __threadfence_system();
+            if (threadIdx.x == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + kPartWidth), seq, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (threadIdx.x < kPartWidth) {
+            folded[(long long)blockIdx.x * kPartWidth + threadIdx.x] = tot[threadIdx.x];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void track_final_kernel(const double* __restrict__ folded, int nrows,
@@ -950,8 +967,14 @@ hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* re
 int track_num_blocks(int32_t n_samples) { return (n_samples + kSamplesPerBlock - 1) / kSamplesPerBlock; }
 size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blocks(n_samples) + kFoldBlocks) * kPartWidth; }
 
+int track_fold_blocks(int32_t n_samples) {
+    const int nb = track_num_blocks(n_samples);
+    return nb < kFoldBlocks ? nb : kFoldBlocks;
+}
+
 hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                        double* partials, double* red_dev, double* red_host, unsigned long long seq) {
+                        double* partials, double* red_dev, double* red_host, double* fold_host,
+                        unsigned long long seq) {
     const int nb = track_num_blocks(p.n_samples);
     if (nb <= 0) return hipErrorInvalidValue;
     track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials);
@@ -959,10 +982,10 @@ hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, c
     if (e != hipSuccess) return e;
     // unwritten counter slots of the rows (37..39) are never read into a result; terms/counters are all written
     double* folded = partials + (size_t)nb * kPartWidth;
-    const int fb = nb < kFoldBlocks ? nb : kFoldBlocks;
-    track_fold_kernel<<<dim3(fb), dim3(256), 0, s>>>(partials, nb, folded);
+    const int fb = track_fold_blocks(p.n_samples);
+    track_fold_kernel<<<dim3(fb), dim3(256), 0, s>>>(partials, nb, folded, fold_host, seq);
     e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || fold_host) return e;
     track_final_kernel<<<dim3(1), dim3(256), 0, s>>>(folded, fb, red_dev, red_host, seq);
     return hipGetLastError();
 }
