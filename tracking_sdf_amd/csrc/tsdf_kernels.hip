@@ -1,11 +1,13 @@
 // tsdf_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the tracking_sdf hot path.
 //
-//   integrate_kernel   SDF::update                          (reference src/sdf.cpp:224-315)
+//   clip_rows_kernel   per k-row frustum interval -> compact list of 64-voxel work items
+//   integrate_kernel   SDF::update over that list          (reference src/sdf.cpp:224-315)
 //   track_kernel       one Gauss-Newton accumulation pass    (reference src/camera_tracking.cpp:146-189,
 //                      + get_partial_derivative :246-363, SDF::interpolate_distance sdf.cpp:127-163)
-//   track_final_kernel fixed-order sum of the per-workgroup partial normal equations
+//   track_fold_kernel / track_final_kernel   fixed-order sum of the per-workgroup partial normal equations
 //   pack_kernel        per-frame image packing (xyz|nrm|rgb planes -> 32-byte pixel records + the
 //                      tracker's column-major stride-3 sample list, camera_tracking.cpp:162-163)
+//   sample_kernel, fill_kernel, split/merge kernels: interpolate_distance batches, constructor fill, host mirrors
 //
 // Numerics: every operation that decides a result (f64 geometry, f32 interpolation and running
 // averages, (int) truncations) is the reference's operation in the reference's order, so this file
