@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libtsdf_oracle.so")
+_LIB_PATH = os.environ.get("TSDF_ORACLE_LIB") or os.path.join(_HERE, "libtsdf_oracle.so")   # override: sanitizer build
 
 
 def build(force: bool = False) -> str:
@@ -22,6 +22,8 @@ def build(force: bool = False) -> str:
     hdr = os.path.join(_HERE, "tsdf_oracle.h")
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if os.environ.get("TSDF_ORACLE_LIB"):
+        return _LIB_PATH
     if force or stale:
         if not os.path.exists(src):
             raise RuntimeError("oracle sources missing and no prebuilt libtsdf_oracle.so")
