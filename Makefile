@@ -40,3 +40,9 @@ shim_demo: $(LIB)
 	@mkdir -p $(ROOT)build
 	g++ -std=c++17 -O2 -Wall -Wextra -o $(ROOT)build/shim_demo $(ROOT)tools/shim_demo.cpp -L$(LIBDIR) -ltsdf_hip -Wl,-rpath,$(LIBDIR)
 .PHONY: shim_demo
+
+# C++ offline host for TUM RGB-D directories (depth PNGs -> GPU pre-processing -> track -> integrate); needs zlib
+sdf_offline: $(LIB)
+	@mkdir -p $(ROOT)build
+	g++ -std=c++17 -O2 -Wall -Wextra -o $(ROOT)build/sdf_offline $(ROOT)tools/sdf_offline.cpp -L$(LIBDIR) -ltsdf_hip -lz -Wl,-rpath,$(LIBDIR)
+.PHONY: sdf_offline

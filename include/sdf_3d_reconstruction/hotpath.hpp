@@ -86,6 +86,15 @@ public:
         return val;
     }
 
+    // Raw depth image instead of PCL clouds: back-projection, bilateral filter and normals on the GPU
+    // (tsdf_set_depth_frame; stand-in for the PCL calls of sdf_reconstruction.cpp:37-49).  The frame stays
+    // current: follow with CameraTracking::estimate_new_position(sdf) and SDF::update(tracker).
+    void set_depth_frame(const uint16_t* depth16, const uint8_t* rgb, int32_t width, int32_t height,
+                         const tsdf_preproc_params* params = nullptr) {
+        check(tsdf_set_depth_frame(h_, depth16, nullptr, rgb, width, height, params), "tsdf_set_depth_frame");
+    }
+    inline void update(CameraTracking* camera_tracking);   // integrate the current frame
+
     // host mirrors of D / W for a mesher (the reference hands raw pointers to MarchingCubesSDF, sdf.cpp:47-49)
     void download(std::vector<float>& D, std::vector<float>& W) const {
         tsdf_config c;
@@ -140,6 +149,12 @@ public:
         sync();
         sdf->check(rc, "tsdf_track");
     }
+    // same, against the frame that is already current (after SDF::set_depth_frame)
+    void estimate_new_position(const SDF* sdf, tsdf_track_stats* stats = nullptr) {
+        const int rc = tsdf_track(sdf->handle(), stats);
+        sync();
+        sdf->check(rc, "tsdf_track");
+    }
     void sync() {
         tsdf_get_pose(sdf_->handle(), rot.data(), trans.data(), rot_inv.data(), rot_inv_trans.data());
     }
@@ -153,6 +168,11 @@ inline void SDF::update(CameraTracking* camera_tracking, const OrganizedCloud& c
     check(tsdf_set_frame(h_, cloud_filtered.xyz, normals.normal, cloud_filtered.rgb, cloud_filtered.width,
                          cloud_filtered.height), "tsdf_set_frame");
     check(tsdf_integrate(h_, nullptr), "tsdf_integrate");      // reference: exit(0) when K is missing (sdf.cpp:227-230)
+}
+
+inline void SDF::update(CameraTracking* camera_tracking) {
+    (void)camera_tracking;
+    check(tsdf_integrate(h_, nullptr), "tsdf_integrate");
 }
 
 }  // namespace tsdf_shim

@@ -62,3 +62,60 @@ def test_shim_demo_frame_loop_matches_oracle(tmp_path):
     assert np.max(np.abs(np.array(final) - want[-1])) < 1e-6
     # the quaternion columns come from a det = -1 matrix (camera_tracking.cpp:7): only finiteness is meaningful
     assert np.all(np.isfinite(got[:, 4:8]))
+
+
+def write_tum_dir(root, n, w, h, step=3):
+    """A miniature TUM RGB-D directory (depth.txt + 16-bit depth PNGs, value = metres * 5000)."""
+    from PIL import Image
+    from tracking_sdf_amd import synth
+    seq = synth.Sequence(n_frames=n, width=w, height=h, noise=True, holes=0.02, step=step)
+    os.makedirs(os.path.join(root, "depth"), exist_ok=True)
+    depths = []
+    with open(os.path.join(root, "depth.txt"), "w") as f:
+        f.write("# depth maps\n# timestamp filename\n")
+        for k in range(n):
+            z = seq.frame(k)[0][..., 2]
+            d16 = np.where(np.isnan(z), 0, np.round(z * 5000.0)).astype(np.uint16)
+            name = "depth/%.6f.png" % seq.stamps[k]
+            Image.fromarray(d16).save(os.path.join(root, name))          # mode I;16
+            f.write("%.6f %s\n" % (seq.stamps[k], name))
+            depths.append(d16)
+    return seq, depths
+
+
+def test_offline_driver_compiles():
+    subprocess.check_call(["make", "-C", ROOT, "-s", "sdf_offline"])
+    assert os.access(os.path.join(ROOT, "build", "sdf_offline"), os.X_OK)
+
+
+@pytest.mark.gpu
+def test_offline_tum_driver_matches_python_binding(tmp_path):
+    """tools/sdf_offline.cpp (C++: PNG decoding, GPU pre-processing, track, integrate) against the same loop through
+    the Python binding on the same depth images: identical trajectories."""
+    import tracking_sdf_amd as ts
+    subprocess.check_call(["make", "-C", ROOT, "-s", "sdf_offline"])
+    exe = os.path.join(ROOT, "build", "sdf_offline")
+    root = str(tmp_path / "tum")
+    n, w, h, m, rad = 5, 160, 120, 64, 6
+    seq, depths = write_tum_dir(root, n, w, h)
+    K = seq.K
+    traj = str(tmp_path / "traj.txt")
+    p = subprocess.run([exe, root, str(m), traj, "0", str(K[0, 0]), str(K[1, 1]), str(K[0, 2]), str(K[1, 2]), str(rad)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = np.loadtxt(traj)
+    assert got.shape == (n - 1, 8)
+    s = ts.SDF(m, with_color=False)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(K)
+    want = []
+    for k in range(n):
+        s.set_depth_frame(depths[k], None, radius=rad)
+        if k > 0:
+            t.estimate_new_position()
+            want.append(t.trans.copy())
+        s.update()
+    want = np.array(want)
+    assert np.max(np.abs(got[:, 1:4] - want)) <= 5.1e-5                  # 4 decimals in the pose file
+    assert np.max(np.abs(want - seq.t[1:n])) < 0.05                      # and it follows the true path
+    assert '"track_errors": 0' in p.stdout
