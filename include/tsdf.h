@@ -18,6 +18,8 @@
  *   tsdf_gn_update                    src/camera_tracking.cpp:191-239 (+ eigen_utils::direct_exponential_map, src/eigen_utils.cpp:85-128)
  *   tsdf_sample                       SDF::interpolate_distance    sdf.h:86, src/sdf.cpp:127-163
  *   tsdf_download / tsdf_upload       the raw D / W (/Color_W,R,G,B) arrays the visualiser reads  sdf.h:41-55, src/sdf.cpp:47-49
+ *   tsdf_mesh_extract / _read         pcl::MarchingCubesSDF::performReconstruction  marching_cubes_sdf.h:434-435, src/marching_cubes_sdf.cpp:243-287
+ *                                     + the per-vertex colours of SDF::visualize / SDF::interpolate_color  src/sdf.cpp:353-383, :164-217
  *
  * Conventions
  *   - every call returns int: TSDF_OK (0) or a negative tsdf_status; nothing
@@ -179,6 +181,24 @@ int tsdf_reset(tsdf_handle *h);                                   /* back to the
  * restores nothing but the voxel state: pose and intrinsics stay with the caller. */
 int tsdf_save(tsdf_handle *h, const char *path);
 int tsdf_load(tsdf_handle *h, const char *path);
+
+/* ---- mesh extraction (the reference's visualiser thread, sdf.cpp:317-391) ---------
+ * tsdf_mesh_extract runs marching cubes over the cubes whose base voxel this handle owns (interior voxels
+ * 1..m-2 only, sdf.cpp:36-39; gate: all eight corner weights > 0, marching_cubes_sdf.cpp:219-239) and keeps the
+ * triangle soup in HBM: 9 floats per triangle, cubes in reference index order, vertex positions computed in
+ * float exactly as createSurface does (grid-local frame: add cfg.origin for world coordinates, sdf.cpp:355-369;
+ * the reference's half-voxel offset of that frame is kept).  with_color != 0 also evaluates
+ * SDF::interpolate_color at every vertex's world position (4 floats r,g,b,a per vertex, a = 1; r,g,b carry
+ * the reference's scaling: /255 when interpolated, raw 0..255 on an exact voxel hit, NaN with no coloured
+ * corner).  iso_level must be in [0,1) as in the reference (marching_cubes_sdf.cpp:246-252; it uses 0).
+ * The triangulation inside a cube uses this library's own case table: the reference table's polygons
+ * (same vertices, same triangle count) but other diagonals -- see tools/gen_mc_tables.py.
+ * On a sharded volume each rank meshes its own cubes (needs halo >= 1); rank order = index order.
+ * tsdf_mesh_read copies the last extraction to host arrays (colors may be NULL); tsdf_mesh_device hands out
+ * the device buffers (valid until the next extraction / destroy). */
+int tsdf_mesh_extract(tsdf_handle *h, float iso_level, int32_t with_color, int64_t *n_triangles);
+int tsdf_mesh_read(tsdf_handle *h, float *vertices /* n*9 */, float *colors /* n*12 or NULL */, int64_t capacity_triangles);
+int tsdf_mesh_device(tsdf_handle *h, const float **vertices, const float **colors, int64_t *n_triangles);
 
 /* ---- multi-GPU (one process per GPU; the volume is sharded in x-slabs) ------------------- */
 /* Owned range of `rank` out of `nranks` for an m-voxel axis (balanced contiguous slabs). */

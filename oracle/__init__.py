@@ -107,6 +107,10 @@ def lib():
     L.orc_gn_update.argtypes = [C.POINTER(_Tracker), dp, dp, dp]
     L.orc_estimate_new_position.argtypes = [C.POINTER(_Tracker), C.POINTER(_Sdf), C.c_void_p, C.c_int32,
                                             C.c_int32, C.POINTER(TrackStats)]
+    L.orc_interpolate_color.argtypes = [C.POINTER(_Sdf), dp, fp]
+    L.orc_mesh.restype = C.c_int64
+    L.orc_mesh.argtypes = [C.POINTER(_Sdf), C.c_float, C.c_int32, C.c_int32, fp, C.c_int64]
+    L.orc_mesh_colors.argtypes = [C.POINTER(_Sdf), fp, C.c_int64, fp]
     L.orc_direct_exponential_map.argtypes = [dp, C.c_double, dp]
     L.orc_inverse3.argtypes = [dp, dp]
     L.orc_inverse6.restype = C.c_int32
@@ -211,6 +215,31 @@ class SDF:
         ok = C.c_int32(0)
         val = lib().orc_interpolate_distance(self._p, _dp(v), C.byref(ok))
         return float(val), bool(ok.value)
+
+    def interpolate_color(self, world):
+        """SDF::interpolate_color (sdf.cpp:164-217) at a world point -> float32 rgba."""
+        g = _d(world, 3)
+        out = np.zeros(4, dtype=np.float32)
+        lib().orc_interpolate_color(self._p, _dp(g), out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def mesh(self, iso_level=0.0, i0=0, i1=None, with_color=False):
+        """performReconstruction (marching_cubes_sdf.cpp:243-287): (n_tri, 3, 3) float32 vertices in the
+        grid-local frame [, (n_tri, 3, 4) float32 colours as SDF::visualize attaches them]."""
+        i1 = self.m if i1 is None else i1
+        n = int(lib().orc_mesh(self._p, iso_level, i0, i1, None, 0))
+        if n < 0:
+            raise ValueError("iso level outside [0, 1)")
+        v = np.zeros((n, 3, 3), dtype=np.float32)
+        fpt = C.POINTER(C.c_float)
+        if n:
+            lib().orc_mesh(self._p, iso_level, i0, i1, v.ctypes.data_as(fpt), n)
+        if not with_color:
+            return v
+        c = np.zeros((n, 3, 4), dtype=np.float32)
+        if n:
+            lib().orc_mesh_colors(self._p, v.ctypes.data_as(fpt), 3 * n, c.ctypes.data_as(fpt))
+        return v, c
 
     def create_circle(self, radius, cx, cy, cz):
         lib().orc_create_circle(self._p, radius, cx, cy, cz)

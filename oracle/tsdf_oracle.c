@@ -628,3 +628,123 @@ void orc_estimate_new_position(orc_tracker *t, const orc_sdf *s, const orc_cloud
         memcpy(st->last_twist, twist, sizeof twist);
     }
 }
+
+/* ------------------------------------------------------------------ mesh extraction */
+
+#include "mc_tables.h"
+
+/* sdf.cpp:164-217 */
+void orc_interpolate_color(const orc_sdf *s, const double global[3], float rgba[4]) {
+    double vc[3];
+    orc_get_voxel_coordinates(s, global, vc);
+    float i = vc[0];
+    float j = vc[1];
+    float k = vc[2];
+    float w_sum = 0.0;
+    float aux = 0;
+    float r = 0.0, g = 0.0, b = 0.0;    /* std_msgs::ColorRGBA fields are float32 */
+    int32_t cv[3];
+    float w = 0;
+    float volume;
+    int64_t a_idx;
+    rgba[3] = 1.0;
+    for (int io = 0; io < 2; io++) {
+        for (int jo = 0; jo < 2; jo++) {
+            for (int ko = 0; ko < 2; ko++) {
+                cv[0] = trunc_f32(i) + io;
+                cv[1] = trunc_f32(j) + jo;
+                cv[2] = trunc_f32(k) + ko;
+                volume = fabsf(cv[0] - i) + fabsf(cv[1] - j) + fabsf(cv[2] - k);
+                a_idx = orc_get_array_index(s, cv);
+                if (a_idx != -1) {
+                    if (s->Color_W[a_idx] > 0) {
+                        if (volume < 0.00001) {          /* :195-200: stored values, not divided by 255 */
+                            rgba[0] = s->R[a_idx]; rgba[1] = s->G[a_idx]; rgba[2] = s->B[a_idx];
+                            return;
+                        }
+                        w = 1.0 / volume;
+                        w_sum += w;
+                        r += w * s->R[a_idx];
+                        g += w * s->G[a_idx];
+                        b += w * s->B[a_idx];
+                    }
+                }
+            }
+        }
+    }
+    aux = w_sum * 255.0;      /* double product narrowed, :212 */
+    rgba[0] = r / aux;
+    rgba[1] = g / aux;
+    rgba[2] = b / aux;
+}
+
+/* marching_cubes_sdf.cpp:87-94 */
+static void mc_interpolate_edge(float iso, const float p1[3], const float p2[3], float v1, float v2, float out[3]) {
+    float mu = (iso - v1) / (v2 - v1);
+    for (int a = 0; a < 3; ++a) out[a] = p1[a] + mu * (p2[a] - p1[a]);
+}
+
+int64_t orc_mesh(const orc_sdf *s, float iso, int32_t i0, int32_t i1, float *verts, int64_t cap) {
+    if (!(iso >= 0 && iso < 1)) return -1;                       /* :246-252 */
+    static const int edge_a[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3};    /* :146-169 */
+    static const int edge_b[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+    const int m = s->m;
+    const int64_t zy = (int64_t)m * m;                           /* zy_index_offset, marching_cubes_sdf.h:406 */
+    const float min_p[3] = {0, 0, 0};                            /* setBBox, :55-65 */
+    const float max_p[3] = {s->width, s->height, s->depth};
+    int64_t n_tri = 0;
+    for (int i = 1; i < m - 1; ++i) {                            /* voxel_coords order, sdf.cpp:26-40 */
+        if (i < i0 || i >= i1) continue;
+        for (int j = 1; j < m - 1; ++j)
+            for (int k = 1; k < m - 1; ++k) {
+                /* getNeighborList1D, :203-240 */
+                const int64_t g0 = (int64_t)i * zy + (int64_t)j * m + k;
+                const int64_t g[8] = {g0, g0 + zy, g0 + zy + 1, g0 + 1, g0 + m, g0 + m + zy, g0 + m + zy + 1, g0 + m + 1};
+                float leaf[8];
+                int all = 1;
+                for (int c = 0; c < 8; ++c) all = all && (s->W[g[c]] > 0);
+                for (int c = 0; c < 8; ++c) leaf[c] = all ? s->D[g[c]] : s->D[g0];
+                /* createSurface, :100-199 */
+                int cubeindex = 0;
+                for (int c = 0; c < 8; ++c) if (leaf[c] < iso) cubeindex |= 1 << c;
+                const int nt = kMcNumTri[cubeindex];
+                if (nt == 0) continue;                           /* edgeTable[cubeindex] == 0 */
+                const int idx3[3] = {i, j, k};
+                const int res[3] = {m, m, m};
+                float center[3];
+                for (int a = 0; a < 3; ++a)
+                    center[a] = min_p[a] + (max_p[a] - min_p[a]) * (float)idx3[a] / (float)res[a];
+                float p[8][3];
+                for (int c = 0; c < 8; ++c) {
+                    p[c][0] = center[0]; p[c][1] = center[1]; p[c][2] = center[2];
+                    if (c & 0x4) p[c][1] = (float)(center[1] + (max_p[1] - min_p[1]) / (float)res[1]);
+                    if (c & 0x2) p[c][2] = (float)(center[2] + (max_p[2] - min_p[2]) / (float)res[2]);
+                    if ((c & 0x1) ^ ((c >> 1) & 0x1)) p[c][0] = (float)(center[0] + (max_p[0] - min_p[0]) / (float)res[0]);
+                }
+                float vl[12][3];
+                for (int e = 0; e < 12; ++e) {
+                    const int a = edge_a[e], b = edge_b[e];
+                    if ((leaf[a] < iso) != (leaf[b] < iso))      /* bit e of edgeTable[cubeindex] */
+                        mc_interpolate_edge(iso, p[a], p[b], leaf[a], leaf[b], vl[e]);
+                }
+                for (int t = 0; t < nt; ++t) {
+                    if (verts && n_tri < cap)
+                        for (int v = 0; v < 3; ++v) {
+                            const int e = kMcTri[cubeindex][3 * t + v];
+                            for (int a = 0; a < 3; ++a) verts[9 * n_tri + 3 * v + a] = vl[e][a];
+                        }
+                    ++n_tri;
+                }
+            }
+    }
+    return n_tri;
+}
+
+/* sdf.cpp:353-383 */
+void orc_mesh_colors(const orc_sdf *s, const float *verts, int64_t n_vertices, float *rgba) {
+    for (int64_t v = 0; v < n_vertices; ++v) {
+        double g[3];
+        for (int a = 0; a < 3; ++a) g[a] = verts[3 * v + a] + s->sdf_origin[a];
+        orc_interpolate_color(s, g, &rgba[4 * v]);
+    }
+}

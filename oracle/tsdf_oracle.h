@@ -151,6 +151,26 @@ int32_t orc_gn_update(orc_tracker *t, const double A[36], const double b[6], dou
 void orc_estimate_new_position(orc_tracker *t, const orc_sdf *s, const orc_cloud *c,
                                int32_t threads, int32_t stale_carry, orc_track_stats *st);
 
+/* ---- mesh extraction (the visualiser thread's work, sdf.cpp:317-391) ------------------------------- */
+
+/* SDF::interpolate_color, sdf.cpp:164-217: inverse-L1 weights over the 8 corners gated by Color_W > 0;
+ * the sum is divided by 255 * sum of weights, but an exact hit returns the stored R,G,B undivided, and no
+ * valid corner gives 0/0 = NaN.  rgba[3] = 1. */
+void orc_interpolate_color(const orc_sdf *s, const double global[3], float rgba[4]);
+
+/* pcl::MarchingCubesSDF::performReconstruction, marching_cubes_sdf.cpp:243-287 (iso level 0 in the
+ * reference, sdf.cpp:44): interior voxels (1 <= i,j,k <= m-2, sdf.cpp:36-39) in index order, cube
+ * corners/gate of getNeighborList1D (:203-240), createSurface (:100-199) with float arithmetic.
+ * Triangulation table: oracle/mc_tables.h (generated; the reference's polygons, own diagonals).
+ * verts (may be NULL to count): 9 floats per triangle in the grid-local frame of the reference's cloud.
+ * Cubes with i in [i0, i1) only (0, m for all).  Returns the number of triangles (those beyond
+ * cap_triangles are counted, not written); -1 for an iso level outside [0,1) (:246-252). */
+int64_t orc_mesh(const orc_sdf *s, float iso_level, int32_t i0, int32_t i1, float *verts, int64_t cap_triangles);
+
+/* SDF::visualize, sdf.cpp:353-383: world position = cloud point + sdf_origin (double), colour =
+ * interpolate_color there.  rgba: 4 floats per vertex. */
+void orc_mesh_colors(const orc_sdf *s, const float *verts, int64_t n_vertices, float *rgba);
+
 /* eigen_utils::direct_exponential_map, eigen_utils.cpp:85-128.  out = 3x4 row-major [R|t] */
 void orc_direct_exponential_map(const double v[6], double delta_t, double out[12]);
 /* Eigen restatements exposed for tests */

@@ -1,0 +1,137 @@
+"""Mesh extraction on the GPU (tsdf_mesh_extract / tsdf_mesh_read) against the oracle's restatement of
+pcl::MarchingCubesSDF::performReconstruction + SDF::interpolate_color: bit-exact vertices, colours and order."""
+import numpy as np
+import pytest
+
+import oracle as orc
+import tracking_sdf_amd as ts
+from tracking_sdf_amd import synth
+from util import VOL, make_gpu, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+def sphere_pair(m, with_color=True):
+    K = synth.default_intrinsics(64, 48)
+    oo, _ = make_oracle(m, K)
+    oo.create_circle(1.0, 0.1, -0.2, 1.25)
+    go, _ = make_gpu(m, K, with_color=with_color)
+    go.upload(oo.D, oo.W)
+    if with_color:
+        rng = np.random.default_rng(3)
+        oo.Color_W[:] = (rng.random(oo.Color_W.size) > 0.05).astype(np.float32)     # a few uncoloured voxels
+        oo.R[:] = rng.integers(0, 256, oo.R.size)
+        oo.G[:] = rng.integers(0, 256, oo.G.size)
+        oo.B[:] = rng.integers(0, 256, oo.B.size)
+        go.upload_color(oo.Color_W, oo.R, oo.G, oo.B)
+    return oo, go
+
+
+@pytest.mark.parametrize("m", [16, 64, 97])
+def test_sphere_mesh_is_bit_identical_to_the_oracle(m):
+    oo, go = sphere_pair(m)
+    v_o, c_o = oo.mesh(with_color=True)
+    v_g, c_g = go.mesh(with_color=True)
+    assert len(v_o) > 0
+    assert same(v_g, v_o)
+    assert same(c_g, c_o)                       # NaN colours (no coloured corner) included, bit for bit
+    assert same(go.mesh(), v_o)                 # without colours: same soup
+    assert go.mesh(read=False) == len(v_o)
+
+
+def test_rows_longer_than_a_workgroup_and_other_iso_levels():
+    m = 300                                     # 298 cubes per row: two passes of the 256-thread workgroup
+    oo, go = sphere_pair(m, with_color=False)
+    for iso in (0.0, 0.125):
+        v_o = oo.mesh(iso_level=iso)
+        assert len(v_o) > 100000
+        assert same(go.mesh(iso_level=iso), v_o)
+
+
+def test_integrated_scene_mesh_and_colours_match_the_oracle():
+    m = 96
+    seq = synth.Sequence(n_frames=9, width=320, height=240, noise=True, holes=0.02, step=4)
+    go, gt = make_gpu(m, seq.K)
+    oo, _ = make_oracle(m, seq.K)
+    for k in range(0, 9, 2):
+        xyz, nrm, rgb = seq.frame(k)
+        gt.set_camera_transformation(seq.R[k], seq.t[k])
+        go.update(gt, xyz, nrm, rgb)
+    # hand the GPU's own volume to the oracle: this test is about the mesher, not about SDF::update
+    oo.D[:], oo.W[:] = go.download()
+    oo.Color_W[:], oo.R[:], oo.G[:], oo.B[:] = go.download_color()
+    v_o, c_o = oo.mesh(with_color=True)
+    v_g, c_g = go.mesh(with_color=True)
+    assert len(v_o) > 5000
+    assert same(v_g, v_o) and same(c_g, c_o)
+    # observed-only gate: far fewer triangles than cubes with a sign change in D alone
+    assert np.isfinite(v_g).all()
+    lo, hi = v_g.reshape(-1, 3).min(0), v_g.reshape(-1, 3).max(0)
+    assert (lo >= 0).all() and (hi <= np.array([VOL["width"], VOL["height"], VOL["depth"]])).all()
+
+
+def test_slab_meshes_concatenate_to_the_whole():
+    m, nr = 64, 3
+    seq = synth.Sequence(n_frames=3, width=160, height=120, noise=False, step=4)
+    frames = [seq.frame(k) for k in range(3)]
+    whole, wt = make_gpu(m, seq.K)
+    parts = []
+    for r in range(nr):
+        x0, x1 = ts.slab_range(m, nr, r)
+        parts.append(make_gpu(m, seq.K, slab=(x0, x1), halo=2))
+    for k, (xyz, nrm, rgb) in enumerate(frames):
+        for s, tr in [(whole, wt)] + parts:
+            tr.set_camera_transformation(seq.R[k], seq.t[k])
+            s.update(tr, xyz, nrm, rgb)
+    v_w, c_w = whole.mesh(with_color=True)
+    got = [s.mesh(with_color=True) for s, _ in parts]
+    assert len(v_w) > 1000 and sum(len(v) for v, _ in got) == len(v_w)
+    assert same(np.concatenate([v for v, _ in got]), v_w)
+    assert same(np.concatenate([c for _, c in got]), c_w)
+
+
+def test_sharded_volume_without_halo_is_refused():
+    seq = synth.Sequence(n_frames=1, width=64, height=48, step=4)
+    s, _ = make_gpu(32, seq.K, slab=(8, 16), halo=0)
+    with pytest.raises(ts.TsdfError) as e:
+        s.mesh()
+    assert e.value.code == ts.E_HALO
+    # the last slab has no layer above it to read: fine without halo when colours are not asked for
+    s2, _ = make_gpu(32, seq.K, slab=(24, 32), halo=0)
+    assert len(s2.mesh()) == 0
+
+
+def test_empty_volume_and_argument_errors():
+    seq = synth.Sequence(n_frames=1, width=64, height=48, step=4)
+    go, gt = make_gpu(32, seq.K)
+    with pytest.raises(ts.TsdfError):
+        go._check(ts.lib().tsdf_mesh_read(go._h, None, None, 0))      # nothing extracted yet
+    assert go.mesh().shape == (0, 3, 3)                               # fresh volume: W = 0 everywhere
+    for iso in (1.0, -0.5, float("nan")):
+        with pytest.raises(ts.TsdfError) as e:
+            go.mesh(iso_level=iso)
+        assert e.value.code == ts.E_BADARG
+    nc, _ = make_gpu(32, seq.K, with_color=False)
+    with pytest.raises(ts.TsdfError):
+        nc.mesh(with_color=True)
+    # capacity check of tsdf_mesh_read
+    oo, gs = sphere_pair(32, with_color=False)
+    n = gs.mesh(read=False)
+    assert n > 0
+    buf = np.zeros((n - 1, 3, 3), dtype=np.float32)
+    import ctypes as C
+    rc = ts.lib().tsdf_mesh_read(gs._h, buf.ctypes.data_as(C.POINTER(C.c_float)), None, n - 1)
+    assert rc == ts.E_BADARG
+    # growing and shrinking meshes reuse the buffers
+    gs.upload(np.full_like(oo.D, 1.0), oo.W)
+    assert gs.mesh().shape == (0, 3, 3)
+    gs.upload(oo.D, oo.W)
+    assert same(gs.mesh(), oo.mesh())

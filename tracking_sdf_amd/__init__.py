@@ -89,6 +89,7 @@ ABI_SYMBOLS = (
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_set_frame_device", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
+    "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
@@ -141,6 +142,9 @@ def lib():
         "tsdf_accumulate": (C.c_int, [H, dp, dp, C.POINTER(AccumStats)]),
         "tsdf_gn_update": (C.c_int, [H, dp, dp, dp, ip]),
         "tsdf_sample": (C.c_int, [H, dp, C.c_int32, fp, ip]),
+        "tsdf_mesh_extract": (C.c_int, [H, C.c_float, C.c_int32, C.POINTER(C.c_int64)]),
+        "tsdf_mesh_read": (C.c_int, [H, fp, fp, C.c_int64]),
+        "tsdf_mesh_device": (C.c_int, [H, C.POINTER(fp), C.POINTER(fp), C.POINTER(C.c_int64)]),
         "tsdf_download": (C.c_int, [H, fp, fp]),
         "tsdf_upload": (C.c_int, [H, fp, fp]),
         "tsdf_download_color": (C.c_int, [H, fp, fp, fp, fp]),
@@ -372,6 +376,20 @@ class SDF:
         ok = np.zeros(len(v), dtype=np.int32)
         self._check(lib().tsdf_sample(self._h, _dptr(v), len(v), _fptr(val), ok.ctypes.data_as(C.POINTER(C.c_int32))))
         return val, ok.astype(bool)
+
+    # -- the visualiser thread's mesh (sdf.cpp:317-391; pcl::MarchingCubesSDF::performReconstruction)
+    def mesh(self, iso_level=0.0, with_color=False, read=True):
+        """Marching cubes on the GPU.  Returns (n_tri, 3, 3) float32 vertices in the grid-local frame of the
+        reference's cloud [, (n_tri, 3, 4) float32 colours]; read=False leaves the result in HBM and returns
+        the triangle count."""
+        n = C.c_int64(0)
+        self._check(lib().tsdf_mesh_extract(self._h, iso_level, 1 if with_color else 0, C.byref(n)))
+        if not read:
+            return n.value
+        v = np.empty((n.value, 3, 3), dtype=np.float32)
+        c = np.empty((n.value, 3, 4), dtype=np.float32) if with_color else None
+        self._check(lib().tsdf_mesh_read(self._h, _fptr(v), _fptr(c) if with_color else None, n.value))
+        return (v, c) if with_color else v
 
     # -- host mirrors of D/W (what the reference hands to its mesher, sdf.cpp:47-49)
     def download(self):

@@ -95,6 +95,14 @@ struct tsdf_handle {
         bool active() const { return base != nullptr; }
     } shm;
 
+    // mesh extraction (grown on demand, kept between calls)
+    unsigned* mesh_row_count = nullptr; unsigned long long* mesh_row_offset = nullptr; size_t mesh_rows_cap = 0;
+    unsigned long long* mesh_total = nullptr;     // pinned: triangles of the last count pass, then the violation word
+    float* mesh_verts = nullptr; float4* mesh_colors = nullptr;
+    size_t mesh_verts_cap = 0, mesh_colors_cap = 0;   // triangles
+    int64_t mesh_ntri = -1;                        // -1: nothing extracted yet
+    bool mesh_has_color = false;
+
     // measurement
     bool timing = false;           // events around the integrate / pack launches (asynchronous, drained on read)
     bool timing_track = false;     // events around every tracker pass (needs a completed stop event per pass)
@@ -593,6 +601,11 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->work_count) (void)hipFree(h->work_count);
     if (h->rowbase) (void)hipFree(h->rowbase);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
+    if (h->mesh_row_count) (void)hipFree(h->mesh_row_count);
+    if (h->mesh_row_offset) (void)hipFree(h->mesh_row_offset);
+    if (h->mesh_total) (void)hipHostFree(h->mesh_total);
+    if (h->mesh_verts) (void)hipFree(h->mesh_verts);
+    if (h->mesh_colors) (void)hipFree(h->mesh_colors);
     if (h->dw) (void)hipFree(h->dw);
     if (h->crgb) (void)hipFree(h->crgb);
     for (auto& ep : h->ev_pool) { if (ep.a) (void)hipEventDestroy(ep.a); if (ep.b) (void)hipEventDestroy(ep.b); }
@@ -853,6 +866,100 @@ int tsdf_sample(tsdf_handle* h, const double* vox, int32_t n, float* val, int32_
     if (e != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_sample: %s", hipGetErrorString(e));
     for (int32_t i = 0; i < n; ++i)
         if (ok[i] < 0) return fail(h, TSDF_E_HALO, "tsdf_sample: point %d reads outside the stored layers", i);
+    return TSDF_OK;
+}
+
+// ---- mesh extraction ---------------------------------------------------------------------------------
+
+int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64_t* n_triangles) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (n_triangles) *n_triangles = 0;
+    h->mesh_ntri = -1;
+    if (!(iso_level >= 0.0f && iso_level < 1.0f))                 // marching_cubes_sdf.cpp:246-252
+        return fail(h, TSDF_E_BADARG, "tsdf_mesh_extract: iso level %g outside [0,1)", (double)iso_level);
+    if (with_color && !h->crgb) return fail(h, TSDF_E_BADARG, "tsdf_mesh_extract: the volume keeps no colour");
+    const Grid& g = h->grid;
+    MeshParams p{};
+    p.g = g;
+    p.extent[0] = h->cfg.width; p.extent[1] = h->cfg.height; p.extent[2] = h->cfg.depth;
+    p.iso = iso_level;
+    p.ci0 = g.own_x0 > 1 ? g.own_x0 : 1;
+    p.ci1 = g.own_x1 < g.m - 1 ? g.own_x1 : g.m - 1;              // cube layers [ci0, ci1): base voxels 1..m-2
+    if (p.ci1 > p.ci0 && g.xe < p.ci1 + 1)
+        return fail(h, TSDF_E_HALO, "tsdf_mesh_extract: a sharded volume needs halo >= 1 (cube layer %d reads layer %d)",
+                    p.ci1 - 1, p.ci1);
+    const size_t n_rows = (size_t)mesh_rows(p);
+    if (n_rows > (size_t)INT32_MAX) return fail(h, TSDF_E_BADARG, "tsdf_mesh_extract: too many rows");
+    if (n_rows > h->mesh_rows_cap) {
+        if (h->mesh_row_count) (void)hipFree(h->mesh_row_count);
+        if (h->mesh_row_offset) (void)hipFree(h->mesh_row_offset);
+        h->mesh_row_count = nullptr; h->mesh_row_offset = nullptr; h->mesh_rows_cap = 0;
+        if (hipMalloc((void**)&h->mesh_row_count, n_rows * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&h->mesh_row_offset, n_rows * sizeof(unsigned long long)) != hipSuccess)
+            return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: row tables (%zu rows)", n_rows);
+        h->mesh_rows_cap = n_rows;
+    }
+    if (!h->mesh_total) HIP_TRY(h, hipHostMalloc((void**)&h->mesh_total, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    h->mesh_total[0] = 0ull; h->mesh_total[1] = 0ull;
+    unsigned long long* d_total = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&d_total, h->mesh_total, 0));
+    HIP_TRY(h, launch_mesh_count(h->stream, p, h->dw, h->mesh_row_count, h->mesh_row_offset, d_total));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const unsigned long long n = h->mesh_total[0];
+    if (n > (unsigned long long)INT64_MAX / 64) return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: %llu triangles", n);
+    if (n > h->mesh_verts_cap) {
+        if (h->mesh_verts) (void)hipFree(h->mesh_verts);
+        h->mesh_verts = nullptr; h->mesh_verts_cap = 0;
+        const size_t cap = (size_t)n + (size_t)n / 8 + 1024;          // room to grow between calls
+        if (hipMalloc((void**)&h->mesh_verts, cap * 9 * sizeof(float)) != hipSuccess)
+            return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: %llu triangles need %zu bytes", n, cap * 9 * sizeof(float));
+        h->mesh_verts_cap = cap;
+    }
+    if (with_color && n > h->mesh_colors_cap) {
+        if (h->mesh_colors) (void)hipFree(h->mesh_colors);
+        h->mesh_colors = nullptr; h->mesh_colors_cap = 0;
+        const size_t cap = h->mesh_verts_cap;
+        if (hipMalloc((void**)&h->mesh_colors, cap * 3 * sizeof(float4)) != hipSuccess)
+            return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: colours of %llu triangles", n);
+        h->mesh_colors_cap = cap;
+    }
+    if (n) {
+        HIP_TRY(h, launch_mesh_emit(h->stream, p, h->dw, h->crgb, h->mesh_row_count, h->mesh_row_offset, h->mesh_verts,
+                                    with_color ? h->mesh_colors : nullptr, n, (unsigned*)(d_total + 1)));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->mesh_total[1])
+            return fail(h, TSDF_E_HALO, "tsdf_mesh_extract: a vertex colour reads outside the stored layers (halo >= 1 needed)");
+    }
+    h->mesh_ntri = (int64_t)n;
+    h->mesh_has_color = with_color != 0;
+    if (n_triangles) *n_triangles = (int64_t)n;
+    return TSDF_OK;
+}
+
+int tsdf_mesh_read(tsdf_handle* h, float* vertices, float* colors, int64_t capacity_triangles) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (h->mesh_ntri < 0) return fail(h, TSDF_E_BADARG, "tsdf_mesh_read: call tsdf_mesh_extract first");
+    if (!vertices && h->mesh_ntri > 0) return fail(h, TSDF_E_BADARG, "tsdf_mesh_read: vertices is NULL");
+    if (capacity_triangles < h->mesh_ntri)
+        return fail(h, TSDF_E_BADARG, "tsdf_mesh_read: room for %lld triangles, the mesh has %lld",
+                    (long long)capacity_triangles, (long long)h->mesh_ntri);
+    if (colors && !h->mesh_has_color) return fail(h, TSDF_E_BADARG, "tsdf_mesh_read: the last extraction had no colours");
+    const size_t n = (size_t)h->mesh_ntri;
+    if (n == 0) return TSDF_OK;
+    HIP_TRY(h, hipMemcpyAsync(vertices, h->mesh_verts, n * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (colors) HIP_TRY(h, hipMemcpyAsync(colors, h->mesh_colors, n * 12 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TSDF_OK;
+}
+
+int tsdf_mesh_device(tsdf_handle* h, const float** vertices, const float** colors, int64_t* n_triangles) {
+    if (!h) return TSDF_E_BADARG;
+    if (h->mesh_ntri < 0) return fail(h, TSDF_E_BADARG, "tsdf_mesh_device: call tsdf_mesh_extract first");
+    if (vertices) *vertices = h->mesh_verts;
+    if (colors) *colors = h->mesh_has_color ? reinterpret_cast<const float*>(h->mesh_colors) : nullptr;
+    if (n_triangles) *n_triangles = h->mesh_ntri;
     return TSDF_OK;
 }
 

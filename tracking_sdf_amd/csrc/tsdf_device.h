@@ -76,6 +76,14 @@ struct TrackParams {
     int32_t stale_carry;
 };
 
+// mesh extraction (mesh_kernels.hip): cubes with base voxel layer i in [ci0, ci1), j,k in [1, m-2]
+struct MeshParams {
+    Grid g;
+    float extent[3];         // width, height, depth (setBBox, marching_cubes_sdf.cpp:55-65)
+    float iso;
+    int32_t ci0, ci1;
+};
+
 // cumulative device counters (unsigned long long each)
 enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntItems = 2, kNumCounters = 4 };
 
@@ -106,6 +114,13 @@ size_t track_partials_doubles(int32_t n_samples);
 hipError_t launch_preproc(hipStream_t s, const uint16_t* d16, const float* dflt, float scale, int w, int h,
                           const float* K /*fx fy cx cy*/, int R, float sigma_s, float sigma_r, int nr, float max_change,
                           float* z, float* zf, float* xyz, float* nrm);
+// row_count / row_offset: mesh_rows(p) entries; total: one 64-bit word (triangles)
+inline long long mesh_rows(const MeshParams& p) { return (long long)(p.ci1 > p.ci0 ? p.ci1 - p.ci0 : 0) * (p.g.m - 2); }
+hipError_t launch_mesh_count(hipStream_t s, const MeshParams& p, const float2* dw, unsigned* row_count,
+                             unsigned long long* row_offset, unsigned long long* total);
+hipError_t launch_mesh_emit(hipStream_t s, const MeshParams& p, const float2* dw, const float4* crgb,
+                            const unsigned* row_count, const unsigned long long* row_offset, float* verts, float4* colors,
+                            unsigned long long capacity, unsigned* violations);
 hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const double* vox, int32_t n,
                          float* val, int32_t* ok);
 hipError_t launch_split(hipStream_t s, const float2* dw, float* d, float* w, int64_t n);
