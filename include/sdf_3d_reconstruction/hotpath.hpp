@@ -11,6 +11,7 @@
 //   SDF::SDF(m, width, height, depth, origin, delta, epsilon)           include/sdf_3d_reconstruction/sdf.h:78-79
 //   SDF::update(CameraTracking*, cloud_filtered, normals)               sdf.h:161-163
 //   SDF::interpolate_distance(voxel_coordinates, is_interpolated)       sdf.h:86
+//   SDF::mesh(vertices, colors)          the body of SDF::visualize       sdf.cpp:317-391 (mc->performReconstruction + interpolate_color)
 //   SDF::m, m_div_width/height/depth, get_number_of_voxels()            sdf.h:69-72,107
 //   CameraTracking::CameraTracking(max_iter, max_twist_diff, v_h, w_h, sdf)   camera_tracking.cpp:3-4 (definition order)
 //   CameraTracking::estimate_new_position(sdf, point_cloud)             camera_tracking.h:101
@@ -102,6 +103,19 @@ public:
         const size_t n = (size_t)(c.slab_x1 - c.slab_x0) * m * m;
         D.resize(n); W.resize(n);
         check(tsdf_download(h_, D.data(), W.data()), "tsdf_download");
+    }
+
+    // What the visualiser thread computes every tick (SDF::visualize, sdf.cpp:317-391): marching cubes over the
+    // observed cubes + (optionally) SDF::interpolate_color at every vertex, on the GPU.  vertices: 9 floats per
+    // triangle in the grid-local frame of pcl::MarchingCubesSDF::performReconstruction (add sdf_origin for the
+    // marker points, sdf.cpp:355-369); colors: 4 floats per vertex.  Returns the number of triangles.
+    int64_t mesh(std::vector<float>& vertices, std::vector<float>* colors = nullptr, float iso_level = 0.0f) const {
+        int64_t n = 0;
+        check(tsdf_mesh_extract(h_, iso_level, colors ? 1 : 0, &n), "tsdf_mesh_extract");
+        vertices.resize((size_t)n * 9);
+        if (colors) colors->resize((size_t)n * 12);
+        check(tsdf_mesh_read(h_, vertices.data(), colors ? colors->data() : nullptr, n), "tsdf_mesh_read");
+        return n;
     }
 
     tsdf_handle* handle() const { return h_; }

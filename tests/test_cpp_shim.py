@@ -100,7 +100,8 @@ def test_offline_tum_driver_matches_python_binding(tmp_path):
     seq, depths = write_tum_dir(root, n, w, h)
     K = seq.K
     traj = str(tmp_path / "traj.txt")
-    p = subprocess.run([exe, root, str(m), traj, "0", str(K[0, 0]), str(K[1, 1]), str(K[0, 2]), str(K[1, 2]), str(rad)],
+    ply = str(tmp_path / "mesh.ply")
+    p = subprocess.run([exe, root, str(m), traj, "0", str(K[0, 0]), str(K[1, 1]), str(K[0, 2]), str(K[1, 2]), str(rad), ply],
                        capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     got = np.loadtxt(traj)
@@ -119,3 +120,12 @@ def test_offline_tum_driver_matches_python_binding(tmp_path):
     assert np.max(np.abs(got[:, 1:4] - want)) <= 5.1e-5                  # 4 decimals in the pose file
     assert np.max(np.abs(want - seq.t[1:n])) < 0.05                      # and it follows the true path
     assert '"track_errors": 0' in p.stdout
+    # the mesh the driver wrote = the binding's mesh of the same volume, moved to the world frame
+    v = s.mesh()
+    assert len(v) > 100 and '"mesh_triangles": %d' % len(v) in p.stdout
+    raw = open(ply, "rb").read()
+    body = raw[raw.index(b"end_header\n") + len(b"end_header\n"):]
+    got_v = np.frombuffer(body[:len(v) * 36], dtype="<f4").reshape(-1, 3, 3)
+    want_v = (v.astype(np.float64) + np.array([-3.0, -3.0, -0.5])).astype(np.float32)
+    assert np.array_equal(got_v, want_v)
+    assert len(body) == len(v) * (36 + 13)

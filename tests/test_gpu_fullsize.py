@@ -163,3 +163,49 @@ def test_config5_2048_cubed_on_one_gpu():
     A, b, st = t.accumulate()
     assert st["n_ok"] > 100000 and np.array_equal(A, A.T)
     s.close()
+
+
+def test_mesh_at_512_properties():
+    """Mesh extraction at the headline volume size: the triangle count equals a NumPy count of the case numbers of
+    the downloaded volume, every vertex sits on a cube edge, and extraction is repeatable bit for bit."""
+    import os
+    import sys
+    import tracking_sdf_amd as ts
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_mc_tables as gen
+    m = 512
+    seq, fr = seq_frames(4, step=10)
+    s = ts.SDF(m, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    for k in range(4):
+        t.set_camera_transformation(seq.R[k], seq.t[k])
+        s.update(t, *fr[k])
+    v, c = s.mesh(with_color=True)
+    assert len(v) > 100000 and c.shape == (len(v), 3, 4)
+    v2 = s.mesh()
+    assert np.array_equal(v.view(np.int32), v2.view(np.int32))
+    # NumPy count, layer by layer (marching_cubes_sdf.cpp:108-115, :203-239)
+    ntri = np.array([len(x) for x in gen.build()], dtype=np.int64)
+    D, W = s.download()
+    D = D.reshape(m, m, m); W = W.reshape(m, m, m)
+    offs = [(0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)]
+    total = 0
+    for i in range(1, m - 1):
+        idx = np.zeros((m - 2, m - 2), dtype=np.int64)
+        ok = np.ones((m - 2, m - 2), dtype=bool)
+        for cnr, (dx, dy, dz) in enumerate(offs):
+            sl = (i + dx, slice(1 + dy, m - 1 + dy), slice(1 + dz, m - 1 + dz))
+            idx |= (D[sl] < 0).astype(np.int64) << cnr
+            ok &= W[sl] > 0
+        total += int(ntri[idx[ok]].sum())
+    assert total == len(v)
+    # every vertex lies on an edge of the reference's cube lattice (spacing extent/m, no half-voxel offset)
+    cell = np.array([6.0 / m, 6.0 / m, 3.5 / m])
+    q = v.reshape(-1, 3).astype(np.float64) / cell
+    off = np.abs(q - np.round(q))
+    assert np.all(np.sort(off, axis=1)[:, 1] < 1e-3)
+    # colours: interpolated values are /255-scaled, exact hits raw 0..255, never negative
+    rgb = c[..., :3]
+    assert np.all(c[..., 3] == 1.0) and np.nanmin(rgb) >= 0.0 and np.nanmax(rgb) <= 255.0
+    s.close()

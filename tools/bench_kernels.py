@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--no-color", action="store_true")
     ap.add_argument("--frame-step", type=int, default=8)
     ap.add_argument("--no-track-timing", action="store_true", help="time tracker passes by wall clock only (no events)")
+    ap.add_argument("--mesh", type=int, default=0, help="also time N mesh extractions of the integrated volume")
     ap.add_argument("--roll", type=float, default=0.0, help="extra camera roll in degrees (exercises the row-major records)")
     args = ap.parse_args()
 
@@ -84,6 +85,16 @@ def main():
     out.update({"track_pass_kernel_ms": kms, "track_pass_wall_ms": wall * 1e3,
                 "track_in_grid": st["n_in_grid_owned"], "track_ok": st["n_ok"],
                 "track_gather_GBs": 832.0 * st["n_in_grid_owned"] / (kms * 1e-3) / 1e9 if kms else None})
+    if args.mesh:
+        for color in (False, True) if not args.no_color else (False,):
+            n = sdf.mesh(with_color=color, read=False)          # warm-up: buffers get allocated here
+            t0 = time.perf_counter()
+            for _ in range(args.mesh):
+                n = sdf.mesh(with_color=color, read=False)
+            dt = (time.perf_counter() - t0) / args.mesh
+            out["mesh_color_ms" if color else "mesh_ms"] = dt * 1e3
+            out["mesh_triangles"] = n
+        out["mesh_sweep_GBs"] = 8.0 * args.m ** 3 / (out["mesh_ms"] * 1e-3) / 1e9      # D,W once per voxel
     print(json.dumps(out))
 
 

@@ -102,9 +102,30 @@ static void quat_from_rot(const Mat3& R, double q[4] /*x y z w*/) {
     }
 }
 
+// Binary little-endian PLY triangle soup; vertices moved to the world frame as SDF::visualize does (sdf.cpp:355-369).
+static bool write_ply(const char* path, const std::vector<float>& verts, const Vec3& origin) {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return false;
+    const size_t nv = verts.size() / 3, nt = nv / 3;
+    std::fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\nproperty float x\nproperty float y\n"
+                    "property float z\nelement face %zu\nproperty list uchar int vertex_indices\nend_header\n", nv, nt);
+    for (size_t v = 0; v < nv; ++v) {
+        const float p[3] = {(float)(verts[3 * v] + origin[0]), (float)(verts[3 * v + 1] + origin[1]),
+                            (float)(verts[3 * v + 2] + origin[2])};
+        std::fwrite(p, sizeof(float), 3, f);
+    }
+    for (size_t t = 0; t < nt; ++t) {
+        const unsigned char three = 3;
+        const int32_t idx[3] = {(int32_t)(3 * t), (int32_t)(3 * t + 1), (int32_t)(3 * t + 2)};
+        std::fwrite(&three, 1, 1, f);
+        std::fwrite(idx, sizeof(int32_t), 3, f);
+    }
+    return std::fclose(f) == 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: %s <tum_dir> <voxels> <trajectory.txt> [max_frames] [fx fy cx cy] [bilateral_radius]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <tum_dir> <voxels> <trajectory.txt> [max_frames] [fx fy cx cy] [bilateral_radius] [mesh.ply]\n", argv[0]);
         return 2;
     }
     const std::string dir = argv[1];
@@ -162,6 +183,13 @@ int main(int argc, char** argv) {
             hot += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
         std::fclose(out);
+        long long n_tri = -1;
+        if (argc > 10) {                                                          // the visualiser's mesh, once, at the end
+            std::vector<float> verts;
+            n_tri = sdf.mesh(verts);
+            if (!write_ply(argv[10], verts, origin)) { std::perror(argv[10]); return 2; }
+        }
+        std::printf("{\"mesh_triangles\": %lld}\n", n_tri);
         std::printf("{\"frames\": %d, \"track_errors\": %d, \"fps_incl_upload_and_preprocessing\": %.1f, "
                     "\"final_t\": [%.9f, %.9f, %.9f]}\n", frame_num, lost, frame_num / hot,
                     tracker.trans[0], tracker.trans[1], tracker.trans[2]);

@@ -96,9 +96,10 @@ struct tsdf_handle {
     } shm;
 
     // mesh extraction (grown on demand, kept between calls)
-    unsigned* mesh_row_count = nullptr; unsigned long long* mesh_row_offset = nullptr; size_t mesh_rows_cap = 0;
+    unsigned* mesh_row_count = nullptr; unsigned* mesh_row_offset = nullptr; size_t mesh_rows_cap = 0;
+    unsigned* mesh_group_sum = nullptr; unsigned long long* mesh_group_base = nullptr;   // per 1024 rows
     unsigned long long* mesh_total = nullptr;     // pinned: triangles of the last count pass, then the violation word
-    float* mesh_verts = nullptr; float4* mesh_colors = nullptr;
+    float* mesh_verts = nullptr; float4* mesh_colors = nullptr; unsigned long long* mesh_desc = nullptr;
     size_t mesh_verts_cap = 0, mesh_colors_cap = 0;   // triangles
     int64_t mesh_ntri = -1;                        // -1: nothing extracted yet
     bool mesh_has_color = false;
@@ -603,8 +604,11 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->mesh_row_count) (void)hipFree(h->mesh_row_count);
     if (h->mesh_row_offset) (void)hipFree(h->mesh_row_offset);
+    if (h->mesh_group_sum) (void)hipFree(h->mesh_group_sum);
+    if (h->mesh_group_base) (void)hipFree(h->mesh_group_base);
     if (h->mesh_total) (void)hipHostFree(h->mesh_total);
     if (h->mesh_verts) (void)hipFree(h->mesh_verts);
+    if (h->mesh_desc) (void)hipFree(h->mesh_desc);
     if (h->mesh_colors) (void)hipFree(h->mesh_colors);
     if (h->dw) (void)hipFree(h->dw);
     if (h->crgb) (void)hipFree(h->crgb);
@@ -894,9 +898,15 @@ int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64
     if (n_rows > h->mesh_rows_cap) {
         if (h->mesh_row_count) (void)hipFree(h->mesh_row_count);
         if (h->mesh_row_offset) (void)hipFree(h->mesh_row_offset);
+        if (h->mesh_group_sum) (void)hipFree(h->mesh_group_sum);
+        if (h->mesh_group_base) (void)hipFree(h->mesh_group_base);
         h->mesh_row_count = nullptr; h->mesh_row_offset = nullptr; h->mesh_rows_cap = 0;
+        h->mesh_group_sum = nullptr; h->mesh_group_base = nullptr;
+        const size_t n_groups = (size_t)mesh_scan_groups((long long)n_rows);
         if (hipMalloc((void**)&h->mesh_row_count, n_rows * sizeof(unsigned)) != hipSuccess ||
-            hipMalloc((void**)&h->mesh_row_offset, n_rows * sizeof(unsigned long long)) != hipSuccess)
+            hipMalloc((void**)&h->mesh_row_offset, n_rows * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&h->mesh_group_sum, n_groups * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void**)&h->mesh_group_base, n_groups * sizeof(unsigned long long)) != hipSuccess)
             return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: row tables (%zu rows)", n_rows);
         h->mesh_rows_cap = n_rows;
     }
@@ -904,15 +914,18 @@ int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64
     h->mesh_total[0] = 0ull; h->mesh_total[1] = 0ull;
     unsigned long long* d_total = nullptr;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&d_total, h->mesh_total, 0));
-    HIP_TRY(h, launch_mesh_count(h->stream, p, h->dw, h->mesh_row_count, h->mesh_row_offset, d_total));
+    HIP_TRY(h, launch_mesh_count(h->stream, p, h->dw, h->mesh_row_count, h->mesh_row_offset, h->mesh_group_sum,
+                                 h->mesh_group_base, d_total));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const unsigned long long n = h->mesh_total[0];
     if (n > (unsigned long long)INT64_MAX / 64) return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: %llu triangles", n);
     if (n > h->mesh_verts_cap) {
         if (h->mesh_verts) (void)hipFree(h->mesh_verts);
-        h->mesh_verts = nullptr; h->mesh_verts_cap = 0;
+        if (h->mesh_desc) (void)hipFree(h->mesh_desc);
+        h->mesh_verts = nullptr; h->mesh_desc = nullptr; h->mesh_verts_cap = 0;
         const size_t cap = (size_t)n + (size_t)n / 8 + 1024;          // room to grow between calls
-        if (hipMalloc((void**)&h->mesh_verts, cap * 9 * sizeof(float)) != hipSuccess)
+        if (hipMalloc((void**)&h->mesh_verts, cap * 9 * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&h->mesh_desc, cap * sizeof(unsigned long long)) != hipSuccess)
             return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: %llu triangles need %zu bytes", n, cap * 9 * sizeof(float));
         h->mesh_verts_cap = cap;
     }
@@ -925,7 +938,8 @@ int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64
         h->mesh_colors_cap = cap;
     }
     if (n) {
-        HIP_TRY(h, launch_mesh_emit(h->stream, p, h->dw, h->crgb, h->mesh_row_count, h->mesh_row_offset, h->mesh_verts,
+        HIP_TRY(h, launch_mesh_emit(h->stream, p, h->dw, h->crgb, h->mesh_row_count, h->mesh_row_offset, h->mesh_group_base,
+                                    h->mesh_desc, h->mesh_verts,
                                     with_color ? h->mesh_colors : nullptr, n, (unsigned*)(d_total + 1)));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->mesh_total[1])

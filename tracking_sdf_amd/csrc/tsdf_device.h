@@ -114,13 +114,17 @@ size_t track_partials_doubles(int32_t n_samples);
 hipError_t launch_preproc(hipStream_t s, const uint16_t* d16, const float* dflt, float scale, int w, int h,
                           const float* K /*fx fy cx cy*/, int R, float sigma_s, float sigma_r, int nr, float max_change,
                           float* z, float* zf, float* xyz, float* nrm);
-// row_count / row_offset: mesh_rows(p) entries; total: one 64-bit word (triangles)
+// row_count / row_offset: mesh_rows(p) entries; group_sum / group_base: mesh_scan_groups(rows) entries (groups of
+// 1024 rows); total: one 64-bit word (triangles).  Row r starts at triangle group_base[r >> 10] + row_offset[r].
 inline long long mesh_rows(const MeshParams& p) { return (long long)(p.ci1 > p.ci0 ? p.ci1 - p.ci0 : 0) * (p.g.m - 2); }
+inline long long mesh_scan_groups(long long n_rows) { return (n_rows + 1023) >> 10; }
 hipError_t launch_mesh_count(hipStream_t s, const MeshParams& p, const float2* dw, unsigned* row_count,
-                             unsigned long long* row_offset, unsigned long long* total);
+                             unsigned* row_offset, unsigned* group_sum, unsigned long long* group_base,
+                             unsigned long long* total);
 hipError_t launch_mesh_emit(hipStream_t s, const MeshParams& p, const float2* dw, const float4* crgb,
-                            const unsigned* row_count, const unsigned long long* row_offset, float* verts, float4* colors,
-                            unsigned long long capacity, unsigned* violations);
+                            const unsigned* row_count, const unsigned* row_offset, const unsigned long long* group_base,
+                            unsigned long long* desc /* one per triangle */, float* verts, float4* colors,
+                            unsigned long long n_triangles, unsigned* violations);
 hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const double* vox, int32_t n,
                          float* val, int32_t* ok);
 hipError_t launch_split(hipStream_t s, const float2* dw, float* d, float* w, int64_t n);
