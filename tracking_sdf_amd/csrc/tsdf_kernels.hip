@@ -568,20 +568,41 @@ struct Vol {
     int m, xs, xe;
 };
 
+typedef float vol_f4 __attribute__((ext_vector_type(4), aligned(8)));   // two neighbouring voxels {D,W,D,W}
+
 __device__ __forceinline__ bool interp(const Vol& V, double vx, double vy, double vz, float& out, unsigned& viol) {
     const float fi = (float)vx, fj = (float)vy, fk = (float)vz;          // f64 -> f32, sdf.cpp:130-132
     const int bi = trunc_x86(fi), bj = trunc_x86(fj), bk = trunc_x86(fk);
-    // issue all 8 corner loads first (independent), then run the reference's accumulation order
+    // Issue the loads first (independent), then run the reference's accumulation order.  The corners k and k+1
+    // of one (i,j) voxel row are neighbours in memory: ONE 16-byte load per row instead of two 8-byte ones --
+    // the tracker's gathers are bound by the number of scattered requests the vector L1 takes, not by bytes.
     float2 c[8];
     bool in[8];
+    const bool pair_ok = (bk >= 0) & (bk + 1 < V.m);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int ci = bi + (q >> 2), cj = bj + ((q >> 1) & 1), ck = bk + (q & 1);
-        bool ok = (ci >= 0) & (cj >= 0) & (ck >= 0) & (ci < V.m) & (cj < V.m) & (ck < V.m);   // sdf.h:113-119
-        if (ok && (ci < V.xs || ci >= V.xe)) { viol = 1u; ok = false; }
-        in[q] = ok;
-        const long long idx = ok ? ((long long)(ci - V.xs) * V.m + cj) * V.m + ck : 0ll;
-        c[q] = ok ? V.dw[idx] : make_float2(0.0f, 0.0f);
+    for (int r = 0; r < 4; ++r) {
+        const int ci = bi + (r >> 1), cj = bj + (r & 1);
+        bool row_ok = (ci >= 0) & (cj >= 0) & (ci < V.m) & (cj < V.m);                        // sdf.h:113-119
+        if (row_ok && (ci < V.xs || ci >= V.xe)) {
+            // the row is in the grid but not stored here: a violation if any of its two corners is in the grid
+            if (((bk >= 0) & (bk < V.m)) | ((bk + 1 >= 0) & (bk + 1 < V.m))) viol = 1u;
+            row_ok = false;
+        }
+        const long long rowbase = row_ok ? ((long long)(ci - V.xs) * V.m + cj) * V.m : 0ll;
+        if (pair_ok) {
+            const vol_f4 v = *reinterpret_cast<const vol_f4*>(reinterpret_cast<const float*>(V.dw + rowbase + (row_ok ? bk : 0)));
+            c[2 * r] = row_ok ? make_float2(v.x, v.y) : make_float2(0.0f, 0.0f);
+            c[2 * r + 1] = row_ok ? make_float2(v.z, v.w) : make_float2(0.0f, 0.0f);
+            in[2 * r] = row_ok; in[2 * r + 1] = row_ok;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ck = bk + u;
+                const bool ok = row_ok & (ck >= 0) & (ck < V.m);
+                in[2 * r + u] = ok;
+                c[2 * r + u] = ok ? V.dw[rowbase + ck] : make_float2(0.0f, 0.0f);
+            }
+        }
     }
     float w_sum = 0.0f, sum_d = 0.0f;
     bool any = false;
