@@ -660,17 +660,20 @@ hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const d
 // Stale carry-over (:156-159,176-182,261-268): an out-of-grid pixel re-adds the previous successful
 // pixel's terms, i.e. a successful sample counts 1 + #{out-of-grid samples between it and the next
 // in-grid one, NaN samples skipped} times.  Classification needs geometry only, so every workgroup
-// classifies a 256-sample window starting at its own 16 samples (64-bit ballots = 64 consecutive
+// classifies a 256-sample window starting at its own 32 samples (64-bit ballots = 64 consecutive
 // samples of the reference's column-major visiting order) and reads the run lengths off the masks,
 // looking further ahead cooperatively in the rare case a run outlives the window.
 //
+// Work split: 8 lanes per sample, lane q < 7 does look-up q and (q < 6) look-up 7 + q -- two look-ups = eight
+// 16-byte gathers in flight per lane; 4280 wavefronts for 640x480, all resident at once (16 lanes with one
+// look-up each needed 8560 wavefronts: a second, nearly empty round on 256 CUs x 32 waves).
 // Reduction: lane q < 6 of a group forms J[q] J[(q+d)%6] (d = 0..3: all 21 unique products) and
-// r J[q]; the 4 groups of a wavefront are added by shuffles, the 4 wavefronts through LDS, one row of
+// r J[q]; the 8 groups of a wavefront are added by shuffles, the 4 wavefronts through LDS, one row of
 // `partials` per workgroup; track_final_kernel adds the rows in a fixed order (bitwise reproducible).
 
 enum { kClsSkip = 0, kClsOog = 1, kClsIn = 2 };
-constexpr int kLanesPerSample = 16;
-constexpr int kSamplesPerBlock = kTrackBlock / kLanesPerSample;   // 16
+constexpr int kLanesPerSample = 8;
+constexpr int kSamplesPerBlock = kTrackBlock / kLanesPerSample;   // 32
 
 struct SampleGeom {
     double px, py, pz;   // camera-frame point
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     __shared__ double s_red[NW][8][8];                     // [wave][q][slot]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's 16 samples
+    const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's 32 samples
 
     // ---- phase A: classify the window [base, base+256) -- thread t looks at sample base+t
     SampleGeom win;
@@ -728,8 +731,8 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     }
     __syncthreads();
 
-    // ---- phase B: this thread's own sample (group g) and look-up (q)
-    const int g = tid >> 4, q = tid & 15;
+    // ---- phase B: this thread's own sample (group g) and look-ups (q and q + 7)
+    const int g = tid >> 3, q = tid & 7;
     const int n = base + g;
     SampleGeom sg;
     const int cls = classify(p, samples, n, sg);
@@ -737,14 +740,14 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     // stale-carry multiplicity of sample g: out-of-grid samples between it and the next in-grid one
     unsigned mult = 1;
     if (p.stale_carry) {
-        // (wave-uniform) does any of the 16 own samples' run reach past the 256-sample window?
-        const unsigned long long own_in = s_in[0] & 0xFFFFull;
+        // (workgroup-uniform) does the run of the last own in-grid sample reach past the 256-sample window?
+        const unsigned long long own_in = s_in[0] & 0xFFFFFFFFull;
         bool need_tail = false;
         unsigned tail = 0;
         if (own_in) {
-            // the last own in-grid sample's run reaches the window end iff no in-grid bit follows it
-            const int last_own = 63 - __clzll((long long)own_in);
-            const unsigned long long above = (last_own == 63) ? 0ull : (~0ull << (last_own + 1));
+            // it reaches the window end iff no in-grid bit follows it
+            const int last_own = 63 - __clzll((long long)own_in);                  // <= 31
+            const unsigned long long above = ~0ull << (last_own + 1);
             need_tail = ((s_in[0] & above) == 0ull) && (s_in[1] | s_in[2] | s_in[3]) == 0ull;
         }
         if (need_tail) {
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             }
         }
         if (cls == kClsIn) {
-            const unsigned long long above = ~0ull << (g + 1);          // g <= 15
+            const unsigned long long above = ~0ull << (g + 1);          // g <= 31
             unsigned cnt = 0;
             bool found = false;
             unsigned long long mi = s_in[0] & above;
@@ -796,34 +799,40 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         }
     }
 
-    // ---- the look-up of this lane (camera_tracking.cpp:269-361)
+    // ---- the look-ups of this lane (camera_tracking.cpp:269-361): slot A = look-up q (centre, +x -x +y -y +z -z)
+    // on lanes 0..6, slot B = look-up 7 + q (r1p r1m r2p r2m r3p r3m) on lanes 0..5
     const bool owned = (cls == kClsIn) && (sg.vx >= (double)p.g.own_x0) && (sg.vx < (double)p.g.own_x1);
-    float val = 0.0f;
+    float valA = 0.0f, valB = 0.0f;
     unsigned viol = 0;
-    bool ok = false;
-    if (owned && q < 13) {
+    bool okA = false, okB = false;
+    if (owned && q < 7) {
         Vol V{dw, p.g.m, p.g.xs, p.g.xe};
-        double vx = sg.vx, vy = sg.vy, vz = sg.vz;
-        if (q >= 7) {
-            voxel_of(p, &p.rpm[9 * (q - 7)], sg, vx, vy, vz);        // r1p r1m r2p r2m r3p r3m
-        } else if (q >= 1) {
+        double ax = sg.vx, ay = sg.vy, az = sg.vz;
+        if (q >= 1) {
             const int a = (q - 1) >> 1;
             const double step = ((q - 1) & 1) ? -(double)p.v_h : (double)p.v_h;
-            if (a == 0) vx += step; else if (a == 1) vy += step; else vz += step;
+            if (a == 0) ax += step; else if (a == 1) ay += step; else az += step;
         }
-        ok = interp(V, vx, vy, vz, val, viol);
+        okA = interp(V, ax, ay, az, valA, viol);
+        if (q < 6) {
+            double bx, by, bz;
+            voxel_of(p, &p.rpm[9 * q], sg, bx, by, bz);
+            okB = interp(V, bx, by, bz, valB, viol);
+        }
     }
-    const unsigned long long okmask = __ballot(ok);
-    const bool all_ok = ((okmask >> (16 * (lane >> 4))) & 0x1FFFull) == 0x1FFFull;   // the group's 13 look-ups
+    const int gl = lane & 56;                                   // first lane of this group in the wave
+    const unsigned long long maskA = __ballot(okA), maskB = __ballot(okB);
+    const bool all_ok = (((maskA >> gl) & 0x7Full) == 0x7Full) && (((maskB >> gl) & 0x3Full) == 0x3Full);   // the 13 look-ups
     const unsigned long long violmask = __ballot(viol != 0u);
-    const bool any_viol = ((violmask >> (16 * (lane >> 4))) & 0xFFFFull) != 0ull;
+    const bool any_viol = ((violmask >> gl) & 0xFFull) != 0ull;
 
     // ---- J[q] on lanes 0..5 of the group, from the +/- partners (float quotient widened, :286,331)
-    const int gl = lane & 48;                                   // first lane of this group in the wave
-    const float r0 = __shfl(val, gl);
+    const float r0 = __shfl(valA, gl);
     const int qa = q < 6 ? q : 0;
-    const float fp = __shfl(val, gl + 1 + 2 * qa);
-    const float fm = __shfl(val, gl + 2 + 2 * qa);
+    const int pt = qa < 3 ? 1 + 2 * qa : 2 * (qa - 3);          // lane of the + partner (slot A for q < 3, slot B after)
+    const float fpA = __shfl(valA, gl + pt), fmA = __shfl(valA, gl + pt + 1);
+    const float fpB = __shfl(valB, gl + pt), fmB = __shfl(valB, gl + pt + 1);
+    const float fp = qa < 3 ? fpA : fpB, fm = qa < 3 ? fmA : fmB;
     const float h = qa == 0 ? p.vh2[0] : (qa == 1 ? p.vh2[1] : (qa == 2 ? p.vh2[2] : p.wh2));
     const double Jq = (double)((fp - fm) / h);
     const double J1 = __shfl(Jq, gl + (qa + 1) % 6);
@@ -846,16 +855,17 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     if (q == 0) {
         if (any_viol) acc[6] = 1.0;
     }
-    // geometry-only statistics of the 16 own samples, carried by q == 1..4 lanes' slot 5
+    // geometry-only statistics of the own samples, carried by q == 1..4 lanes' slot 5
     if (q == 1 && owned) acc[5] = 1.0;
     if (q == 2 && cls == kClsOog) acc[5] = 1.0;
     if (q == 3 && n < p.n_samples && cls == kClsSkip) acc[5] = 1.0;
     if (q == 4 && n < p.n_samples) acc[5] = 1.0;
 
-    // ---- reduction over the 4 groups of the wave (xor 16, 32), then the 4 waves through LDS
+    // ---- reduction over the 8 groups of the wave (xor 8, 16, 32), then the 4 waves through LDS
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         double v = acc[e];
+        v += __shfl_xor(v, 8);
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         acc[e] = v;
