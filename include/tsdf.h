@@ -125,7 +125,10 @@ int tsdf_get_pose(const tsdf_handle *h, double rot[9], double trans[3],
  * tsdf_set_frame copies host images to the device (pinned staging, async).  nrm / rgb may be NULL
  * (tracking needs xyz only; integration needs nrm; rgb is needed only when with_color = 1).
  * tsdf_set_frame_device borrows DEVICE pointers (same layouts) that must stay valid until the next
- * set_frame* call or destroy. */
+ * set_frame* call or destroy, and whose contents must be complete when the call is made.
+ * The frame-side work of tsdf_set_frame / tsdf_set_depth_frame (staging copies, pre-processing, the packing
+ * kernel) runs on an internal second stream, so setting frame k+1 right after tsdf_integrate(k) overlaps it
+ * with that integration; the hot calls wait for it on the device. */
 int tsdf_set_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uint8_t *rgb,
                    int32_t width, int32_t height);
 int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb,
@@ -263,7 +266,8 @@ int tsdf_set_timing(tsdf_handle *h, int32_t on);
 int tsdf_read_timing(tsdf_handle *h, tsdf_timing *out, int32_t reset);
 int tsdf_read_counters(tsdf_handle *h, tsdf_counters *out, int32_t reset);
 int tsdf_synchronize(tsdf_handle *h);
-/* The hipStream_t the handle launches on, as an opaque pointer (for callers that record their own events). */
+/* The hipStream_t the hot kernels (track, integrate, mesh) are launched on, as an opaque pointer (for callers
+ * that record their own events).  tsdf_synchronize waits for this and for the internal frame stream. */
 void *tsdf_stream(tsdf_handle *h);
 
 #ifdef __cplusplus

@@ -67,9 +67,20 @@ struct tsdf_handle {
     size_t in_cap = 0;             // pixels the staging buffers hold
     float* pre_z = nullptr; float* pre_zf = nullptr; void* pre_depth = nullptr; void* pin_depth = nullptr;   // pre-processing scratch
     size_t pre_cap = 0;
-    float4* pn = nullptr;          // 2 x float4 per pixel
-    float4* samples = nullptr;
+    float4* pn = nullptr;          // 2 x float4 per pixel      } the CURRENT frame's buffers: one of the two below
+    float4* samples = nullptr;     //                            }
     size_t pn_cap = 0, samples_cap = 0;
+    // Frame side stream: H2D staging copies, pre-processing and pack_kernel of frame k+1 run on `fstream`, so they
+    // overlap the integration of frame k that is still running on `stream`.  The packed records are double-buffered;
+    // `ev_frame` makes `stream` wait for the pack, `ev_buf_used[b]` makes the pack wait for the last integration that
+    // read buffer b (the tracker passes are host-synchronous and need no event).
+    hipStream_t fstream = nullptr;
+    hipEvent_t ev_frame = nullptr;
+    hipEvent_t ev_buf_used[2] = {nullptr, nullptr};
+    bool used_valid[2] = {false, false};
+    float4* pn_buf[2] = {nullptr, nullptr};
+    float4* samples_buf[2] = {nullptr, nullptr};
+    int fidx = 0;
 
     // tracker reduction buffers
     double* partials = nullptr; size_t partials_cap = 0;   // doubles
@@ -169,16 +180,22 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
     const int32_t st = h->cfg.pixel_stride;
     const int32_t ncols = (w + st - 1) / st, nrows = (hh + st - 1) / st;
     const size_t ns = (size_t)ncols * nrows;
+    if (npix > h->pn_cap || ns > h->samples_cap) {
+        // growing: nothing may still read the old buffers
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->used_valid[0] = h->used_valid[1] = false;
+    }
     if (npix > h->pn_cap) {
-        if (h->pn) (void)hipFree(h->pn);
-        h->pn = nullptr; h->pn_cap = 0;
-        HIP_TRY(h, hipMalloc((void**)&h->pn, npix * 2 * sizeof(float4)));
+        for (int b = 0; b < 2; ++b) { if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]); h->pn_buf[b] = nullptr; }
+        h->pn = nullptr; h->pn_cap = 0; h->have_frame = false;
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->pn_buf[b], npix * 2 * sizeof(float4)));
         h->pn_cap = npix;
     }
     if (ns > h->samples_cap) {
-        if (h->samples) (void)hipFree(h->samples);
-        h->samples = nullptr; h->samples_cap = 0;
-        HIP_TRY(h, hipMalloc((void**)&h->samples, ns * sizeof(float4)));
+        for (int b = 0; b < 2; ++b) { if (h->samples_buf[b]) (void)hipFree(h->samples_buf[b]); h->samples_buf[b] = nullptr; }
+        h->samples = nullptr; h->samples_cap = 0; h->have_frame = false;
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->samples_buf[b], ns * sizeof(float4)));
         h->samples_cap = ns;
     }
     const size_t nb = track_partials_doubles((int32_t)ns);
@@ -206,6 +223,7 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
 
 int drain_events(tsdf_handle* h) {
     if (h->ev_used == 0) return TSDF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.f;
@@ -217,7 +235,7 @@ int drain_events(tsdf_handle* h) {
     return TSDF_OK;
 }
 
-int timed_begin(tsdf_handle* h, int kind, EventPair** out) {
+int timed_begin(tsdf_handle* h, int kind, EventPair** out, hipStream_t st) {
     *out = nullptr;
     if (!h->timing) return TSDF_OK;
     if (h->ev_used == h->ev_pool.size()) {
@@ -235,13 +253,13 @@ int timed_begin(tsdf_handle* h, int kind, EventPair** out) {
     EventPair* ep = &h->ev_pool[h->ev_used];
     h->ev_kind[h->ev_used] = kind;
     h->ev_used++;
-    HIP_TRY(h, hipEventRecord(ep->a, h->stream));
+    HIP_TRY(h, hipEventRecord(ep->a, st));
     *out = ep;
     return TSDF_OK;
 }
 
-int timed_end(tsdf_handle* h, EventPair* ep) {
-    if (ep) HIP_TRY(h, hipEventRecord(ep->b, h->stream));
+int timed_end(tsdf_handle* h, EventPair* ep, hipStream_t st) {
+    if (ep) HIP_TRY(h, hipEventRecord(ep->b, st));
     return TSDF_OK;
 }
 
@@ -257,15 +275,26 @@ void choose_pixel_layout(tsdf_handle* h) {
     else { h->pix_su = 1; h->pix_sv = h->fw; }
 }
 
-int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb) {
+// st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
+// overlaps the running integration like they do.  Device-resident inputs pack on the main stream: measured, a
+// pack_kernel squeezed in beside the persistent integrate_kernel slows that one down by as much as it takes.
+int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st) {
     choose_pixel_layout(h);
+    const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
+    const bool side = st != h->stream;
+    if (side && h->used_valid[nb]) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
     EventPair* ep;
-    int rc = timed_begin(h, 1, &ep);
+    int rc = timed_begin(h, 1, &ep, st);
     if (rc) return rc;
-    HIP_TRY(h, launch_pack(h->stream, xyz, nrm, rgb, h->fw, h->fh, h->cfg.pixel_stride, h->pix_su, h->pix_sv,
-                           h->pn, h->samples, h->ncols, h->nrows));
-    rc = timed_end(h, ep);
+    HIP_TRY(h, launch_pack(st, xyz, nrm, rgb, h->fw, h->fh, h->cfg.pixel_stride, h->pix_su, h->pix_sv,
+                           h->pn_buf[nb], h->samples_buf[nb], h->ncols, h->nrows));
+    rc = timed_end(h, ep, st);
     if (rc) return rc;
+    if (side) {
+        HIP_TRY(h, hipEventRecord(h->ev_frame, st));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));   // everything queued on `stream` from here on sees the frame
+    }
+    h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
     h->have_frame = true;
     h->frame_has_nrm = nrm != nullptr;
     h->frame_has_rgb = rgb != nullptr;
@@ -549,6 +578,10 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[0], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
     CREATE_TRY(hipMalloc((void**)&h->dw, (size_t)h->n_stored * sizeof(float2)));
     if (cfg->with_color) CREATE_TRY(hipMalloc((void**)&h->crgb, (size_t)h->n_stored * sizeof(float4)));
@@ -586,13 +619,18 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
 void tsdf_destroy(tsdf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->comm.destroy();
     shm_close(h);
     free_frame(h);
     free_preproc(h);
-    if (h->pn) (void)hipFree(h->pn);
-    if (h->samples) (void)hipFree(h->samples);
+    for (int b = 0; b < 2; ++b) {
+        if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]);
+        if (h->samples_buf[b]) (void)hipFree(h->samples_buf[b]);
+        if (h->ev_buf_used[b]) (void)hipEventDestroy(h->ev_buf_used[b]);
+    }
+    if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
@@ -615,6 +653,7 @@ void tsdf_destroy(tsdf_handle* h) {
     for (auto& ep : h->ev_pool) { if (ep.a) (void)hipEventDestroy(ep.a); if (ep.b) (void)hipEventDestroy(ep.b); }
     if (h->ev_track.a) (void)hipEventDestroy(h->ev_track.a);
     if (h->ev_track.b) (void)hipEventDestroy(h->ev_track.b);
+    if (h->fstream) (void)hipStreamDestroy(h->fstream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -669,19 +708,20 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     rc = ensure_frame_buffers(h, width, height, true);
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
-    // the pinned staging buffers may still feed the previous frame's async copies
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // the pinned staging buffers may still feed the previous frame's async copies (frame stream only: the
+    // integration of the previous frame keeps running on the main stream meanwhile)
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
     std::memcpy(h->pin_xyz, xyz, npix * 3 * sizeof(float));
-    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, h->pin_xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, h->pin_xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     if (nrm) {
         std::memcpy(h->pin_nrm, nrm, npix * 3 * sizeof(float));
-        HIP_TRY(h, hipMemcpyAsync(h->in_nrm, h->pin_nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->in_nrm, h->pin_nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     }
     if (rgb) {
         std::memcpy(h->pin_rgb, rgb, npix * 3);
-        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
     }
-    return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr);
+    return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
 }
 
 int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
@@ -690,7 +730,7 @@ int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, false);
     if (rc) return rc;
-    return run_pack(h, d_xyz, d_nrm, d_rgb);
+    return run_pack(h, d_xyz, d_nrm, d_rgb, h->stream);
 }
 
 // ---- depth pre-processing (optional stage in front of the hot path) -------------------------------------------
@@ -727,20 +767,20 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
         HIP_TRY(h, hipHostMalloc((void**)&h->pin_depth, npix * sizeof(float), hipHostMallocDefault));
         h->pre_cap = npix;
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));           // pinned staging may still feed the previous frame
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));          // pinned staging may still feed the previous frame
     const size_t dbytes = npix * (depth16 ? sizeof(uint16_t) : sizeof(float));
     std::memcpy(h->pin_depth, depth16 ? (const void*)depth16 : (const void*)depthf, dbytes);
-    HIP_TRY(h, hipMemcpyAsync(h->pre_depth, h->pin_depth, dbytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->pre_depth, h->pin_depth, dbytes, hipMemcpyHostToDevice, h->fstream));
     if (rgb) {
         std::memcpy(h->pin_rgb, rgb, npix * 3);
-        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
     }
     const float Kf[4] = {(float)h->K[0], (float)h->K[4], (float)h->K[2], (float)h->K[5]};
-    HIP_TRY(h, launch_preproc(h->stream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
+    HIP_TRY(h, launch_preproc(h->fstream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
                               depth16 ? nullptr : (const float*)h->pre_depth, pp.depth_scale, width, height, Kf,
                               pp.radius, pp.sigma_s, pp.sigma_r, pp.normal_radius, pp.max_depth_change,
                               h->pre_z, h->pre_zf, h->in_xyz, h->in_nrm));
-    return run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr);
+    return run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
 }
 
 int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {
@@ -748,9 +788,9 @@ int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {
     if (rc) return rc;
     if (!h->in_xyz || h->in_cap < (size_t)h->fw * h->fh) return fail(h, TSDF_E_NO_FRAME, "no pre-processed frame held");
     const size_t bytes = (size_t)h->fw * h->fh * 3 * sizeof(float);
-    if (xyz) HIP_TRY(h, hipMemcpyAsync(xyz, h->in_xyz, bytes, hipMemcpyDeviceToHost, h->stream));
-    if (nrm) HIP_TRY(h, hipMemcpyAsync(nrm, h->in_nrm, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (xyz) HIP_TRY(h, hipMemcpyAsync(xyz, h->in_xyz, bytes, hipMemcpyDeviceToHost, h->fstream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(nrm, h->in_nrm, bytes, hipMemcpyDeviceToHost, h->fstream));
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
     return TSDF_OK;
 }
 
@@ -779,12 +819,14 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
         std::memcpy(before, h->counters_host, sizeof before);
     }
     EventPair* ep;
-    rc = timed_begin(h, 0, &ep);
+    rc = timed_begin(h, 0, &ep, h->stream);
     if (rc) return rc;
     HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
                                 h->rowbase, h->integrate_blocks, h->integrate_launches++));
-    rc = timed_end(h, ep);
+    rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_buf_used[h->fidx], h->stream));     // the next-but-one pack may overwrite this buffer after this
+    h->used_valid[h->fidx] = true;
     h->cnt.integrate_calls++;
     h->cnt.n_voxels_swept += h->n_stored;
     if (stats) {
@@ -1295,6 +1337,7 @@ int tsdf_read_counters(tsdf_handle* h, tsdf_counters* out, int32_t reset) {
 int tsdf_synchronize(tsdf_handle* h) {
     int rc = check_ready(h, false);
     if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return TSDF_OK;
 }
