@@ -80,3 +80,33 @@ def test_hip_path_reproduces_golden():
             assert tr["iterations"] == int(G["track_iterations"]) and tr["stopped"] == int(G["track_stopped"])
             assert np.max(np.abs(t.rot - G["track_rot"])) < 1e-9 and np.max(np.abs(t.trans - G["track_trans"])) < 1e-9
         s.close()
+
+
+# ---- the visualiser's mesh of the golden volume (tests/golden/mesh_m24.npz, tools/make_golden.py mesh) ----------
+GM = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mesh_m24.npz"))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
+
+
+def test_oracle_reproduces_golden_mesh():
+    import oracle as orc
+    s = orc.SDF(int(G["m"]), VOL["width"], VOL["height"], VOL["depth"], VOL["origin"], VOL["delta"], VOL["epsilon"])
+    for name in ("D", "W", "Color_W", "R", "G", "B"):
+        getattr(s, name)[:] = G["vol_" + name]
+    v, c = s.mesh(with_color=True)
+    assert len(v) == len(GM["vertices"]) > 100
+    assert np.array_equal(_bits(v), _bits(GM["vertices"])) and np.array_equal(_bits(c), _bits(GM["colors"]))
+    assert np.array_equal(_bits(s.mesh(iso_level=0.25)), _bits(GM["vertices_iso025"]))
+
+
+@pytest.mark.gpu
+def test_hip_mesh_reproduces_golden():
+    import tracking_sdf_amd as ts
+    s = ts.SDF(int(G["m"]), VOL["width"], VOL["height"], VOL["depth"], VOL["origin"], VOL["delta"], VOL["epsilon"])
+    s.upload(G["vol_D"], G["vol_W"])
+    s.upload_color(G["vol_Color_W"], G["vol_R"], G["vol_G"], G["vol_B"])
+    v, c = s.mesh(with_color=True)
+    assert np.array_equal(_bits(v), _bits(GM["vertices"])) and np.array_equal(_bits(c), _bits(GM["colors"]))
+    assert np.array_equal(_bits(s.mesh(iso_level=0.25)), _bits(GM["vertices_iso025"]))

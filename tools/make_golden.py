@@ -6,7 +6,8 @@ so these vectors come from the CPU oracle (oracle/tsdf_oracle.c, itself pinned b
 of tests/test_oracle_kat.py).  They serve two purposes: they freeze the oracle against regressions
 (CPU test) and they let the GPU parity test check the HIP path against committed data.
 
-Run from the repo root:  python tools/make_golden.py
+Run from the repo root:  python tools/make_golden.py          (hot path)
+                         python tools/make_golden.py mesh     (mesh of the golden volume -> mesh_m24.npz)
 """
 import os
 import sys
@@ -69,5 +70,23 @@ def main():
           "terms", out["acc_stats_stale1"][-1], out["acc_stats_stale0"][-1])
 
 
+def mesh_golden():
+    """tests/golden/mesh_m24.npz: the visualiser's mesh (marching cubes + per-vertex colours) of the golden volume
+    of hotpath_m24.npz.  Kept in its own file so that the hot-path vectors stay byte-identical."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "hotpath_m24.npz"))
+    s = orc.SDF(int(G["m"]), VOL["width"], VOL["height"], VOL["depth"], VOL["origin"], VOL["delta"], VOL["epsilon"])
+    for name in ("D", "W", "Color_W", "R", "G", "B"):
+        getattr(s, name)[:] = G["vol_" + name]
+    v, c = s.mesh(with_color=True)
+    v25 = s.mesh(iso_level=0.25)
+    dst = os.path.join(ROOT, "tests", "golden", "mesh_m24.npz")
+    np.savez_compressed(dst, vertices=v, colors=c, vertices_iso025=v25)
+    print("wrote", dst, os.path.getsize(dst), "bytes;", len(v), "triangles,", len(v25), "at iso 0.25,",
+          int(np.isnan(c).any(axis=(1, 2)).sum()), "with an uncoloured vertex")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "mesh":
+        mesh_golden()
+    else:
+        main()
