@@ -361,8 +361,10 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     double* host_row = h->red_host;          // where the final kernel publishes this rank's row
     if (use_shm)
         host_row = reinterpret_cast<double*>(h->shm.dev_base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot);
-    // single rank + polling: the folded rows come to the host directly (one dependent launch fewer)
-    const bool host_fold = h->host_fold && !use_rccl && !use_shm && h->poll && !h->timing_track;
+    // polling + no RCCL: the folded rows come to the host directly (one dependent launch fewer); with the
+    // shared-memory fan-in the host then publishes this rank's row itself (a host-memory store instead of a
+    // device write over PCIe)
+    const bool host_fold = h->host_fold && !use_rccl && h->poll && !h->timing_track;
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
     HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
                             use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, seq));
@@ -407,6 +409,13 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         }
         track_unpack_row(tot, h->red_host);
         arrived = true;
+        if (use_shm) {
+            char* slot = h->shm.base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot;
+            std::memcpy(slot, h->red_host, kRedWidth * sizeof(double));
+            __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), seq, __ATOMIC_RELEASE);
+            int rc2 = shm_fan_in(h, seq, kRedAllreduce);
+            if (rc2) return rc2;
+        }
     } else if (use_shm) {
         int rc2 = shm_fan_in(h, seq, kRedAllreduce);
         if (rc2) return rc2;
