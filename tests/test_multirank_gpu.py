@@ -18,14 +18,14 @@ COMMON = ["--voxels", "128", "--width", "320", "--height", "240", "--steps", "6"
           "--frame-step", "3"]
 
 
-def run_bench(extra, nproc, traj, port):
+def run_bench(extra, nproc, traj, port, env=None):
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + COMMON + ["--trajectory-out", traj] + extra
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                "--gpus", str(nproc), "--dist-backend", "gloo", "--trajectory-out", traj] + COMMON + extra
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line), np.loadtxt(traj)
@@ -40,6 +40,14 @@ def test_sharded_bench_reproduces_single_rank_trajectory(tmp_path, mode, nproc):
     assert t1.shape == tn.shape and np.array_equal(t1, tn)          # 4-decimal TUM lines, identical
     assert abs(jn["ate_rmse_m"] - j1["ate_rmse_m"]) < 1e-9
     assert jn["gn_iterations_per_frame"] == j1["gn_iterations_per_frame"]
+
+
+def test_device_published_rows_give_the_same_trajectory(tmp_path):
+    """TSDF_HOST_FOLD=0: every rank's final kernel writes its row into the shared segment through the
+    hipHostRegister alias (the path used when the host fold is off); same bits as the host-folded default."""
+    ja, ta = run_bench(["--allreduce", "shm"], 2, str(tmp_path / "a.txt"), 29641)
+    jb, tb = run_bench(["--allreduce", "shm"], 2, str(tmp_path / "b.txt"), 29643, env={"TSDF_HOST_FOLD": "0"})
+    assert np.array_equal(ta, tb) and abs(ja["ate_rmse_m"] - jb["ate_rmse_m"]) < 1e-12
 
 
 def test_rccl_path_in_tracker_with_one_rank():

@@ -318,7 +318,7 @@ constexpr size_t kShmSlot = 512;   // bytes per (rank, parity) slot: 34 doubles 
 void shm_close(tsdf_handle* h) {
     if (!h->shm.active()) return;
     (void)hipStreamSynchronize(h->stream);
-    (void)hipHostUnregister(h->shm.base);
+    if (h->shm.dev_base) (void)hipHostUnregister(h->shm.base);
     munmap(h->shm.base, h->shm.bytes);
     if (h->shm.rank == 0) shm_unlink(h->shm.name.c_str());
     h->shm.base = h->shm.dev_base = nullptr;
@@ -359,12 +359,14 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     const bool use_shm = reduce_ranks && !use_rccl && h->shm.active();
     const unsigned long long seq = ++h->pass_seq;
     double* host_row = h->red_host;          // where the final kernel publishes this rank's row
-    if (use_shm)
+    if (use_shm && h->shm.dev_base)
         host_row = reinterpret_cast<double*>(h->shm.dev_base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot);
     // polling + no RCCL: the folded rows come to the host directly (one dependent launch fewer); with the
     // shared-memory fan-in the host then publishes this rank's row itself (a host-memory store instead of a
     // device write over PCIe)
     const bool host_fold = h->host_fold && !use_rccl && h->poll && !h->timing_track;
+    if (use_shm && !host_fold && !h->shm.dev_base)
+        return fail(h, TSDF_E_COMM, "shared-memory fan-in without the host fold needs the segment registered with HIP, which failed");
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
     HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
                             use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, seq));
@@ -1213,13 +1215,15 @@ int tsdf_comm_init_shm(tsdf_handle* h, int32_t nranks, int32_t rank, const char*
     void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return fail(h, TSDF_E_COMM, "mmap(%s) failed", name);
+    // The device alias is only needed when a rank's final kernel writes its slot itself (host fold off); with the
+    // default host fold the segment is touched by hosts only, so a failed registration is not fatal.
     hipError_t e = hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
     void* dptr = nullptr;
-    if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, m, 0);
-    if (e != hipSuccess) {
-        munmap(m, bytes);
-        return fail(h, TSDF_E_HIP, "hipHostRegister of the shared segment failed: %s", hipGetErrorString(e));
+    if (e == hipSuccess) {
+        e = hipHostGetDevicePointer(&dptr, m, 0);
+        if (e != hipSuccess) { (void)hipHostUnregister(m); dptr = nullptr; }
     }
+    if (e != hipSuccess) { (void)hipGetLastError(); dptr = nullptr; }
     h->shm.nranks = nranks; h->shm.rank = rank; h->shm.base = (char*)m; h->shm.dev_base = (char*)dptr;
     h->shm.bytes = bytes; h->shm.name = name;
     h->pass_seq = 0;               // every rank counts passes from the same origin
@@ -1255,11 +1259,13 @@ int tsdf_allreduce(tsdf_handle* h, double* buf, int32_t n) {
         return TSDF_OK;
     }
     if (h->shm.active()) {
+        // host buffer in, host buffer out: publish with a host store (what a tracker pass does after its host fold)
         const unsigned long long seq = ++h->pass_seq;
-        double* slot = reinterpret_cast<double*>(h->shm.dev_base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot);
-        HIP_TRY(h, hipMemsetAsync(h->red_dev, 0, kRedWidth * sizeof(double), h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->red_dev, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, launch_track_publish(h->stream, h->red_dev, slot, seq));
+        char* slot = h->shm.base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot;
+        double row[kRedWidth];
+        for (int e = 0; e < kRedWidth; ++e) row[e] = e < n ? buf[e] : 0.0;
+        std::memcpy(slot, row, sizeof row);
+        __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), seq, __ATOMIC_RELEASE);
         int rc2 = shm_fan_in(h, seq, n);
         if (rc2) return rc2;
         std::memcpy(buf, h->red_host, (size_t)n * sizeof(double));
