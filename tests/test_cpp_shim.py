@@ -129,3 +129,50 @@ def test_offline_tum_driver_matches_python_binding(tmp_path):
     want_v = (v.astype(np.float64) + np.array([-3.0, -3.0, -0.5])).astype(np.float32)
     assert np.array_equal(got_v, want_v)
     assert len(body) == len(v) * (36 + 13)
+
+
+@pytest.mark.gpu
+def test_offline_driver_fusion_only_mode(tmp_path):
+    """The reference's _useGroundTruth switch (sdf_reconstruction.cpp:51-66) in the C++ driver: no tracking, every
+    depth frame fused at the ground-truth pose nearest in time.  Poses come from a TUM-format file (quaternions), so
+    the synthetic path is mirrored into a proper-rotation world first (x -> -x; the default volume is symmetric)."""
+    import tracking_sdf_amd as ts
+    from scipy.spatial.transform import Rotation
+    subprocess.check_call(["make", "-C", ROOT, "-s", "sdf_offline"])
+    exe = os.path.join(ROOT, "build", "sdf_offline")
+    root = str(tmp_path / "tum")
+    n, w, h, m, rad = 6, 160, 120, 64, 4
+    seq, depths = write_tum_dir(root, n, w, h)
+    M = np.diag([-1.0, 1.0, 1.0])
+    Rs = [M @ seq.R[k] for k in range(n)]
+    ts_ = [M @ seq.t[k] for k in range(n)]
+    assert all(np.linalg.det(R) > 0.999 for R in Rs)
+    gt = str(tmp_path / "groundtruth.txt")
+    with open(gt, "w") as f:
+        f.write("# ground truth trajectory\n# timestamp tx ty tz qx qy qz qw\n")
+        for k in range(n):
+            if k == 3:
+                continue                                   # frame 3 has no pose within 20 ms: must be skipped
+            q = Rotation.from_matrix(Rs[k]).as_quat()      # x y z w
+            f.write("%.6f %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n" % (seq.stamps[k] + 0.004, *ts_[k], *q))
+    K = seq.K
+    traj, ply = str(tmp_path / "traj.txt"), str(tmp_path / "mesh.ply")
+    p = subprocess.run([exe, root, str(m), traj, "0", str(K[0, 0]), str(K[1, 1]), str(K[0, 2]), str(K[1, 2]), str(rad), ply, gt],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert '"fusion_only": true' in p.stdout and '"frames_without_pose": 1' in p.stdout and '"frames": 5' in p.stdout
+    assert os.path.getsize(traj) == 0                      # no tracking, no pose lines
+    # the same loop through the Python binding
+    s = ts.SDF(m, with_color=False)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(K)
+    for k in range(n):
+        if k == 3:
+            continue
+        s.set_depth_frame(depths[k], None, radius=rad)
+        q = Rotation.from_matrix(Rs[k]).as_quat()
+        t.set_camera_transformation(Rotation.from_quat(q).as_matrix(), ts_[k])
+        s.update()
+    v = s.mesh()
+    n_cpp = int(p.stdout.split('"mesh_triangles": ')[1].split(",")[0])
+    assert len(v) > 500 and abs(n_cpp - len(v)) <= 0.01 * len(v)      # poses agree to ~1e-16, not bit for bit

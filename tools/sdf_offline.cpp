@@ -3,7 +3,11 @@
 // (metres = value / 5000), pre-processes each image on the GPU (tsdf_set_depth_frame), tracks, appends the pose
 // to a TUM-format trajectory file (sdf_reconstruction.cpp:4-17) and integrates.
 //
-//   sdf_offline <tum_dir> <voxels> <trajectory.txt> [max_frames] [fx fy cx cy] [bilateral_radius]
+//   sdf_offline <tum_dir> <voxels> <trajectory.txt> [max_frames] [fx fy cx cy] [bilateral_radius] [mesh.ply] [groundtruth.txt]
+//
+// mesh.ply ("-" = none): the visualiser's mesh of the final volume.  groundtruth.txt (TUM format: stamp tx ty tz qx qy qz
+// qw, camera -> world): the reference's _useGroundTruth mode (sdf_reconstruction.cpp:51-66) -- no tracking, every depth
+// frame is fused at the ground-truth pose nearest in time (frames without a pose within 20 ms are skipped).
 //
 // Only zlib is needed (minimal PNG reader below: 8/16-bit greyscale, non-interlaced, all five filters).
 #include <zlib.h>
@@ -102,6 +106,41 @@ static void quat_from_rot(const Mat3& R, double q[4] /*x y z w*/) {
     }
 }
 
+struct GtPose { double stamp, t[3], q[4]; };
+
+static std::vector<GtPose> read_groundtruth(const std::string& path) {
+    std::vector<GtPose> out;
+    std::ifstream f(path);
+    for (std::string line; std::getline(f, line);) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        GtPose g;
+        if (ss >> g.stamp >> g.t[0] >> g.t[1] >> g.t[2] >> g.q[0] >> g.q[1] >> g.q[2] >> g.q[3]) out.push_back(g);
+    }
+    return out;
+}
+
+// pose nearest in time (poses sorted by stamp, as TUM files are); -1 if none within max_dt
+static int nearest_pose(const std::vector<GtPose>& gt, double stamp, double max_dt) {
+    size_t lo = 0, hi = gt.size();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (gt[mid].stamp < stamp) lo = mid + 1; else hi = mid; }
+    int best = -1;
+    double bd = max_dt;
+    for (size_t c = lo > 0 ? lo - 1 : 0; c < gt.size() && c <= lo; ++c) {
+        const double d = std::fabs(gt[c].stamp - stamp);
+        if (d <= bd) { bd = d; best = (int)c; }
+    }
+    return best;
+}
+
+static Mat3 rot_from_quat(const double q[4] /*x y z w*/) {
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+    return Mat3{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+}
+
 // Binary little-endian PLY triangle soup; vertices moved to the world frame as SDF::visualize does (sdf.cpp:355-369).
 static bool write_ply(const char* path, const std::vector<float>& verts, const Vec3& origin) {
     FILE* f = std::fopen(path, "wb");
@@ -125,7 +164,7 @@ static bool write_ply(const char* path, const std::vector<float>& verts, const V
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: %s <tum_dir> <voxels> <trajectory.txt> [max_frames] [fx fy cx cy] [bilateral_radius] [mesh.ply]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <tum_dir> <voxels> <trajectory.txt> [max_frames] [fx fy cx cy] [bilateral_radius] [mesh.ply|-] [groundtruth.txt]\n", argv[0]);
         return 2;
     }
     const std::string dir = argv[1];
@@ -147,6 +186,12 @@ int main(int argc, char** argv) {
         if (ss >> stamp >> name) items.emplace_back(stamp, name);
     }
     if (max_frames > 0 && (int)items.size() > max_frames) items.resize(max_frames);
+    std::vector<GtPose> gt;
+    if (argc > 11) {
+        gt = read_groundtruth(argv[11]);
+        if (gt.empty()) { std::fprintf(stderr, "no poses in %s\n", argv[11]); return 2; }
+    }
+    const bool fusion_only = !gt.empty();
 
     try {
         const Vec3 origin{-3.0, -3.0, -0.5};
@@ -159,7 +204,7 @@ int main(int argc, char** argv) {
         FILE* out = std::fopen(argv[3], "w");
         if (!out) { std::perror(argv[3]); return 2; }
         std::vector<uint16_t> depth;
-        int frame_num = 0, lost = 0;
+        int frame_num = 0, lost = 0, skipped = 0;
         double hot = 0.0;
         for (const auto& it : items) {
             int w = 0, h = 0;
@@ -167,10 +212,15 @@ int main(int argc, char** argv) {
                 std::fprintf(stderr, "skipping unreadable %s\n", it.second.c_str());
                 continue;
             }
+            int gi = -1;
+            if (fusion_only && (gi = nearest_pose(gt, it.first, 0.02)) < 0) { ++skipped; continue; }
             ++frame_num;
             const auto t0 = std::chrono::steady_clock::now();
             sdf.set_depth_frame(depth.data(), nullptr, w, h, &pp);
-            if (frame_num > 1) {                                                  // sdf_reconstruction.cpp:69-72
+            if (fusion_only) {                                                    // sdf_reconstruction.cpp:51-66
+                const Vec3 tr{gt[gi].t[0], gt[gi].t[1], gt[gi].t[2]};
+                tracker.set_camera_transformation(rot_from_quat(gt[gi].q), tr);
+            } else if (frame_num > 1) {                                                  // sdf_reconstruction.cpp:69-72
                 try { tracker.estimate_new_position(&sdf); }
                 catch (const Error& e) { ++lost; std::fprintf(stderr, "frame %d: %s\n", frame_num, e.what()); }
                 double q[4];
@@ -184,12 +234,13 @@ int main(int argc, char** argv) {
         }
         std::fclose(out);
         long long n_tri = -1;
-        if (argc > 10) {                                                          // the visualiser's mesh, once, at the end
+        if (argc > 10 && std::strcmp(argv[10], "-") != 0) {                       // the visualiser's mesh, once, at the end
             std::vector<float> verts;
             n_tri = sdf.mesh(verts);
             if (!write_ply(argv[10], verts, origin)) { std::perror(argv[10]); return 2; }
         }
-        std::printf("{\"mesh_triangles\": %lld}\n", n_tri);
+        std::printf("{\"mesh_triangles\": %lld, \"fusion_only\": %s, \"frames_without_pose\": %d}\n", n_tri,
+                    fusion_only ? "true" : "false", skipped);
         std::printf("{\"frames\": %d, \"track_errors\": %d, \"fps_incl_upload_and_preprocessing\": %.1f, "
                     "\"final_t\": [%.9f, %.9f, %.9f]}\n", frame_num, lost, frame_num / hot,
                     tracker.trans[0], tracker.trans[1], tracker.trans[2]);
