@@ -78,15 +78,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
                                                     const uint8_t* __restrict__ rgb, int width, int height,
                                                     int stride, int pix_su, int pix_sv, float4* __restrict__ pn,
                                                     float4* __restrict__ samples, int ncols, int nrows) {
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= width * height) return;
+    // 16 x 16 pixel tiles; consecutive threads follow the direction in which the records are contiguous, so a
+    // wavefront writes four runs of 512 bytes whichever layout is chosen (the plane reads of a tile stay within
+    // a few cache lines per image row either way)
+    const int tiles_x = (width + 15) >> 4;
+    const int tx0 = (blockIdx.x % tiles_x) << 4, ty0 = (blockIdx.x / tiles_x) << 4;
+    const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+    const int col = tx0 + (pix_sv == 1 ? a : b), row = ty0 + (pix_sv == 1 ? b : a);
+    if (col >= width || row >= height) return;
+    const int pix = row * width + col;
     const float qnan = __int_as_float(0x7fc00000);
     const float px = xyz[3 * pix + 0], py = xyz[3 * pix + 1], pz = xyz[3 * pix + 2];
     float nx = qnan, ny = qnan, nz = qnan;
     if (nrm) { nx = nrm[3 * pix + 0]; ny = nrm[3 * pix + 1]; nz = nrm[3 * pix + 2]; }
     unsigned c = 0;
     if (rgb) c = (unsigned)rgb[3 * pix + 0] | ((unsigned)rgb[3 * pix + 1] << 8) | ((unsigned)rgb[3 * pix + 2] << 16);
-    const int col = pix % width, row = pix / width;
     const long long rec = (long long)col * pix_su + (long long)row * pix_sv;   // row- or column-major records
     pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
     // sdf.cpp:294: cosine = |cam_vect . n| / |n| depends on the pixel only.  Its f32 rounding rides in the
@@ -101,9 +107,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
                        int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
                        float4* pn, float4* samples, int32_t ncols, int32_t nrows) {
-    const int n = width * height;
-    pack_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(xyz, nrm, rgb, width, height, stride, pix_su, pix_sv, pn,
-                                                              samples, ncols, nrows);
+    const int tiles = ((width + 15) >> 4) * ((height + 15) >> 4);
+    pack_kernel<<<dim3(tiles), dim3(256), 0, s>>>(xyz, nrm, rgb, width, height, stride, pix_su, pix_sv, pn,
+                                                   samples, ncols, nrows);
     return hipGetLastError();
 }
 
