@@ -21,7 +21,10 @@ constexpr int kRedAllreduce = 30;   // the leading part that is summed over rank
 // d <= 3 and r*J[q] for d = 4, then counters
 constexpr int kPartTerms = 30, kPartViol = 31, kPartOk = 32, kPartInOwned = 33, kPartOog = 34, kPartNan = 35,
               kPartSamples = 36, kPartWidth = 40;
-constexpr int kFoldBlocks = 64;          // rows left after track_fold_kernel
+#ifndef TSDF_FOLD_BLOCKS
+#define TSDF_FOLD_BLOCKS 32   // measured: 64 rows 3373, 32 rows 3432, 16 rows 3380, 8 rows 3285 frames/s
+#endif
+constexpr int kFoldBlocks = TSDF_FOLD_BLOCKS;          // rows left after track_fold_kernel
 constexpr int kFoldSlotDoubles = 48;     // pinned host slot per folded row: 40 values + pass-number word + pad
 
 // partial row (kPartWidth) -> result row (kRedWidth); shared by track_final_kernel's logic and the host fold

@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void track_fold_kernel(const double* __restric
     fold_rows(partials, first, last, tot);
     if (threadIdx.x < 64) {                                   // one wave
         if (host_rows) {
-            // single-rank hand-off: the <= 64 folded rows go straight to pinned host memory (one coalesced
+            // single-rank hand-off: the <= kFoldBlocks folded rows go straight to pinned host memory (one coalesced
             // 320-byte store), a system-scope fence, then the pass number; the host adds the rows in block
             // order -- the device-side final kernel (one more dependent launch, ~5 us) is not needed.
             double* slot = host_rows + (size_t)blockIdx.x * kFoldSlotDoubles;
