@@ -135,3 +135,29 @@ def test_empty_volume_and_argument_errors():
     assert gs.mesh().shape == (0, 3, 3)
     gs.upload(oo.D, oo.W)
     assert same(gs.mesh(), oo.mesh())
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_fields_match_the_oracle(case):
+    """Noise volumes: every one of the 256 cases, weight gates everywhere, odd sizes down to a single cube."""
+    rng = np.random.default_rng(500 + case)
+    m = [2, 3, 4, 5, 9, 17, 31, 40, 64, 130][case]
+    K = synth.default_intrinsics(64, 48)
+    oo, _ = make_oracle(m, K)
+    go, _ = make_gpu(m, K)
+    n = m ** 3
+    oo.D[:] = rng.uniform(-1.0, 1.0, n).astype(np.float32)
+    oo.D[rng.random(n) < 0.05] = 0.0                                   # values exactly on the iso level
+    oo.W[:] = (rng.random(n) > 0.08).astype(np.float32)
+    oo.Color_W[:] = (rng.random(n) > 0.3).astype(np.float32) * rng.uniform(0.1, 5.0, n).astype(np.float32)
+    oo.R[:] = rng.integers(0, 256, n); oo.G[:] = rng.integers(0, 256, n); oo.B[:] = rng.integers(0, 256, n)
+    go.upload(oo.D, oo.W)
+    go.upload_color(oo.Color_W, oo.R, oo.G, oo.B)
+    iso = [0.0, 0.0, 0.5, 0.0, 0.25, 0.0, 0.9, 0.0, 0.125, 0.0][case]
+    v_o, c_o = oo.mesh(iso_level=iso, with_color=True)
+    v_g, c_g = go.mesh(iso_level=iso, with_color=True)
+    assert same(v_g, v_o) and same(c_g, c_o)
+    if m >= 5:
+        assert len(v_o) > 0
+    else:
+        assert len(v_o) <= 5 * (m - 2) ** 3 if m > 2 else len(v_o) == 0
