@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--frame-step", type=int, default=8)
     ap.add_argument("--no-track-timing", action="store_true", help="time tracker passes by wall clock only (no events)")
     ap.add_argument("--mesh", type=int, default=0, help="also time N mesh extractions of the integrated volume")
+    ap.add_argument("--look-along-k", action="store_true",
+                    help="experiment: re-pose the camera so that it looks along the volume's fastest axis (k)")
     ap.add_argument("--roll", type=float, default=0.0, help="extra camera roll in degrees (exercises the row-major records)")
     args = ap.parse_args()
 
@@ -42,6 +44,13 @@ def main():
         Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
         seq.R = np.array([R @ Rz for R in seq.R])
     frames = [seq.frame(k) for k in range(args.frames)]
+    if args.look_along_k:
+        # the images stay what they are (camera frame); only the world pose changes: world -y (the viewing direction
+        # of the reference's initial pose) is mapped to world +z, the camera moved to the bottom of the volume
+        Q = np.array([[1.0, 0, 0], [0, 0, -1.0], [0, -1.0, 0]])
+        c = np.array([0.0, 1.0, -0.3])
+        seq.t = np.array([Q @ t + c for t in seq.t])
+        seq.R = np.array([Q @ R for R in seq.R])
     d = [(torch.from_numpy(x).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev)) for x, n, c in frames]
     torch.cuda.synchronize()
     sdf = ts.SDF(args.m, with_color=not args.no_color)
