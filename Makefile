@@ -46,3 +46,9 @@ sdf_offline: $(LIB)
 	@mkdir -p $(ROOT)build
 	g++ -std=c++17 -O2 -Wall -Wextra -o $(ROOT)build/sdf_offline $(ROOT)tools/sdf_offline.cpp -L$(LIBDIR) -ltsdf_hip -lz -Wl,-rpath,$(LIBDIR)
 .PHONY: sdf_offline
+
+# measured HBM ceiling for the roofline (streaming RMW over volume-shaped arrays); run on the GPU box
+rmw_probe:
+	@mkdir -p $(ROOT)build
+	$(HIPCC) --offload-arch=gfx950 -O3 -o $(ROOT)build/rmw_probe $(ROOT)tools/rmw_probe.hip
+.PHONY: rmw_probe

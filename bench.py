@@ -375,6 +375,15 @@ def main():
             with open(pmc) as f:
                 out["roofline"]["traffic"] = json.load(f)["integrate_launch_traffic_bytes"]
             out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        # measured ceiling for this access pattern (streaming 48 B/voxel RMW in 64-voxel items; tools/rmw_probe.hip)
+        probe = os.path.join(ROOT, "profiles", "r01_rmw_probe.json")
+        if os.path.exists(probe):
+            with open(probe) as f:
+                pj = json.load(f)
+            ceil_gbs = pj["item_granular_rows_rmw_GBs"] if not args.no_color else pj["float2_rmw_GBs"]
+            out["roofline"]["measured_rmw_ceiling_GBs"] = ceil_gbs
+            out["roofline"]["frac_of_measured_ceiling"] = achieved / ceil_gbs
+            out["roofline"]["ceiling_source"] = "profiles/r01_rmw_probe.json (build/rmw_probe on MI355X)"
         if args.trajectory_out:
             with open(args.trajectory_out, "w") as f:
                 for k in range(1, len(est)):
