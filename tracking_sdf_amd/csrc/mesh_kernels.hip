@@ -62,16 +62,23 @@ __device__ __forceinline__ MeshRowPtrs mesh_rows_of(const MeshParams& p, const f
     return q;
 }
 
-// voxels k, k+1 (own load) and k+2 (from lane+1) of one voxel row
+// voxels k, k+1 (own load) and k+2 (from lane+1) of one voxel row.  The load and the shuffle are separate so that a
+// caller can keep the raw load in flight (the shuffle needs the data and would wait for it on the spot).
 struct MeshRow3 { float d[3], w[3]; };
-__device__ __forceinline__ MeshRow3 mesh_load_row(const float* __restrict__ row, int k, int m) {
+__device__ __forceinline__ mesh_f4 mesh_load_raw(const float* __restrict__ row, int k, int m) {
     mesh_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if (k + 1 < m) v = *reinterpret_cast<const mesh_f4*>(row + 2 * k);
     else if (k < m) { const mesh_f2 h = *reinterpret_cast<const mesh_f2*>(row + 2 * k); v.x = h.x; v.y = h.y; }
+    return v;
+}
+__device__ __forceinline__ MeshRow3 mesh_expand(const mesh_f4 v) {
     MeshRow3 r;
     r.d[0] = v.x; r.w[0] = v.y; r.d[1] = v.z; r.w[1] = v.w;
     r.d[2] = __shfl_down(v.x, 1, 64); r.w[2] = __shfl_down(v.y, 1, 64);
     return r;
+}
+__device__ __forceinline__ MeshRow3 mesh_load_row(const float* __restrict__ row, int k, int m) {
+    return mesh_expand(mesh_load_raw(row, k, m));
 }
 
 // case numbers of the cubes k (c0) and k + 1 (c1) from the voxel rows (i,j) (i+1,j) (i,j+1) (i+1,j+1); 0 when
@@ -163,14 +170,16 @@ __global__ __launch_bounds__(kMeshBlock) void mesh_count_kernel(MeshParams p, co
     const int k = s * kMeshStep + 2 * lane;
     const long long plane = 2ll * m * m;
     const float* row_j = reinterpret_cast<const float*>(dw + ((long long)(i_begin - p.g.xs) * m + j) * m);
-    MeshRow3 a0 = mesh_load_row(row_j, k, m), a2 = mesh_load_row(row_j + 2 * m, k, m);                  // layer i
-    MeshRow3 b0 = mesh_load_row(row_j + plane, k, m), b2 = mesh_load_row(row_j + plane + 2 * m, k, m);  // layer i + 1
+    // layers i, i+1 expanded; layer i+2 raw (requested one step ago); layer i+3 requested at the top of the step:
+    // every load has two steps to arrive
+    const int last_layer = p.g.xe - 1;
+    auto layer_ptr = [&](int layer) { return row_j + (long long)((layer < last_layer ? layer : last_layer) - i_begin) * plane; };
+    MeshRow3 a0 = mesh_load_row(row_j, k, m), a2 = mesh_load_row(row_j + 2 * m, k, m);
+    MeshRow3 b0 = mesh_load_row(layer_ptr(i_begin + 1), k, m), b2 = mesh_load_row(layer_ptr(i_begin + 1) + 2 * m, k, m);
+    mesh_f4 c0r = mesh_load_raw(layer_ptr(i_begin + 2), k, m), c2r = mesh_load_raw(layer_ptr(i_begin + 2) + 2 * m, k, m);
     for (int i = i_begin; i < i_end; ++i) {
-        row_j += plane;
-        // layer i + 2 is requested before layer i / i + 1 are used (the last step reads one layer it does not
-        // need; clamp it to a stored layer)
-        const float* nxt = (i + 2 < p.g.xe) ? row_j + plane : row_j;
-        const MeshRow3 n0 = mesh_load_row(nxt, k, m), n2 = mesh_load_row(nxt + 2 * m, k, m);
+        const float* nxt = layer_ptr(i + 3);
+        const mesh_f4 d0r = mesh_load_raw(nxt, k, m), d2r = mesh_load_raw(nxt + 2 * m, k, m);
         int c0, c1;
         mesh_classify(p, a0, b0, a2, b2, k, lane, c0, c1);
         unsigned n = (unsigned)s_ntri[c0] + (unsigned)s_ntri[c1];
@@ -179,7 +188,9 @@ __global__ __launch_bounds__(kMeshBlock) void mesh_count_kernel(MeshParams p, co
             for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
             if (lane == 0) atomicAdd(&row_count[(i - p.ci0) * inner + (j - 1)], n);
         }
-        a0 = b0; a2 = b2; b0 = n0; b2 = n2;
+        a0 = b0; a2 = b2;
+        b0 = mesh_expand(c0r); b2 = mesh_expand(c2r);
+        c0r = d0r; c2r = d2r;
     }
 }
 
