@@ -105,8 +105,10 @@ __device__ __forceinline__ void mesh_classify(const MeshParams& p, const MeshRow
 
 __device__ __forceinline__ void mesh_two_cubes(const MeshParams& p, const MeshRowPtrs& q, int kb, int lane, int& c0, int& c1) {
     const int m = p.g.m, k = kb + 2 * lane;
-    const MeshRow3 r0 = mesh_load_row(q.r[0], k, m), r1 = mesh_load_row(q.r[1], k, m);
-    const MeshRow3 r2 = mesh_load_row(q.r[2], k, m), r3 = mesh_load_row(q.r[3], k, m);
+    // the four loads first, then the shuffles (a shuffle waits for its load)
+    const mesh_f4 v0 = mesh_load_raw(q.r[0], k, m), v1 = mesh_load_raw(q.r[1], k, m);
+    const mesh_f4 v2 = mesh_load_raw(q.r[2], k, m), v3 = mesh_load_raw(q.r[3], k, m);
+    const MeshRow3 r0 = mesh_expand(v0), r1 = mesh_expand(v1), r2 = mesh_expand(v2), r3 = mesh_expand(v3);
     mesh_classify(p, r0, r1, r2, r3, k, lane, c0, c1);
 }
 
@@ -303,12 +305,20 @@ __global__ __launch_bounds__(kMeshBlock) void mesh_list_kernel(MeshParams p, con
                                                                 const unsigned long long* __restrict__ group_base,
                                                                 unsigned long long* __restrict__ desc,
                                                                 unsigned long long capacity) {
-    __shared__ unsigned char s_ntri[256];
-    s_ntri[threadIdx.x] = kMcNumTri[threadIdx.x];
-    __syncthreads();
     int i, j0;
     if (!mesh_block_rows(p, i, j0)) return;
     const int inner = p.g.m - 2;
+    // most workgroups own four rows without a triangle: leave before the table load and its barrier
+    {
+        const int r0 = (i - p.ci0) * inner + (j0 - 1);
+        unsigned any = 0u;
+#pragma unroll
+        for (int w = 0; w < kMeshRowsPerBlock; ++w) any |= (j0 + w <= inner) ? row_count[r0 + w] : 0u;
+        if (any == 0u) return;                               // workgroup-uniform
+    }
+    __shared__ unsigned char s_ntri[256];
+    s_ntri[threadIdx.x] = kMcNumTri[threadIdx.x];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int j = j0 + (int)(threadIdx.x >> 6);
     if (j > inner) return;                                   // wave-uniform
