@@ -576,56 +576,77 @@ struct Vol {
 
 typedef float vol_f4 __attribute__((ext_vector_type(4), aligned(8)));   // two neighbouring voxels {D,W,D,W}
 
-__device__ __forceinline__ bool interp(const Vol& V, double vx, double vy, double vz, float& out, unsigned& viol) {
-    const float fi = (float)vx, fj = (float)vy, fk = (float)vz;          // f64 -> f32, sdf.cpp:130-132
-    const int bi = trunc_x86(fi), bj = trunc_x86(fj), bk = trunc_x86(fk);
-    // Issue the loads first (independent), then run the reference's accumulation order.  The corners k and k+1
-    // of one (i,j) voxel row are neighbours in memory: ONE 16-byte load per row instead of two 8-byte ones --
-    // the tracker's gathers are bound by the number of scattered requests the vector L1 takes, not by bytes.
-    float2 c[8];
-    bool in[8];
-    const bool pair_ok = (bk >= 0) & (bk + 1 < V.m);
+// One look-up in two halves, both straight-line code: lookup_issue computes the addresses and requests the data,
+// lookup_finish runs the reference's accumulation.  With branches around the loads (as the first version had) hipcc
+// put an s_waitcnt vmcnt(0) after every one of the four row loads -- four serialized round trips per look-up,
+// eight for a lane with two look-ups; branch-free, all loads of a lane are in flight together.
+// The corners k and k+1 of one (i,j) voxel row are neighbours in memory: ONE 16-byte load per row instead of two
+// 8-byte ones (the gathers are bound by the number of scattered requests the vector L1 takes, not by bytes).  The
+// pair is read at kc = clamp(bk, 0, m-2) so that the address is always valid; bk - kc says where the corners are.
+struct Lookup {
+    float fi, fj, fk;
+    int bi, bj, bk;
+    int sel;                 // bk - kc: 0 = corners (v.xy, v.zw); -1 = (none, v.xy); +1 = (v.zw, none); else none
+    bool k_ok[2];            // corner k / k+1 inside the grid in k
+    bool row_ok[4];          // voxel row (i,j) inside the grid and stored on this rank
+    vol_f4 v[4];
+};
+
+__device__ __forceinline__ void lookup_issue(const Vol& V, double vx, double vy, double vz, Lookup& L, unsigned& viol) {
+    L.fi = (float)vx; L.fj = (float)vy; L.fk = (float)vz;                // f64 -> f32, sdf.cpp:130-132
+    L.bi = trunc_x86(L.fi); L.bj = trunc_x86(L.fj); L.bk = trunc_x86(L.fk);
+    const int bk = L.bk;
+    int kc = bk < 0 ? 0 : bk;
+    kc = kc > V.m - 2 ? V.m - 2 : kc;
+    // INT_MIN + 1 wraps nowhere: bk + 1 is only compared
+    L.k_ok[0] = (bk >= 0) & (bk < V.m);
+    L.k_ok[1] = (bk >= -1) & (bk < V.m - 1);
+    const long long d = (long long)bk - (long long)kc;
+    L.sel = d < -1 ? 2 : (d > 1 ? 2 : (int)d);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int ci = bi + (r >> 1), cj = bj + (r & 1);
-        bool row_ok = (ci >= 0) & (cj >= 0) & (ci < V.m) & (cj < V.m);                        // sdf.h:113-119
-        if (row_ok && (ci < V.xs || ci >= V.xe)) {
-            // the row is in the grid but not stored here: a violation if any of its two corners is in the grid
-            if (((bk >= 0) & (bk < V.m)) | ((bk + 1 >= 0) & (bk + 1 < V.m))) viol = 1u;
-            row_ok = false;
-        }
-        const long long rowbase = row_ok ? ((long long)(ci - V.xs) * V.m + cj) * V.m : 0ll;
-        if (pair_ok) {
-            const vol_f4 v = *reinterpret_cast<const vol_f4*>(reinterpret_cast<const float*>(V.dw + rowbase + (row_ok ? bk : 0)));
-            c[2 * r] = row_ok ? make_float2(v.x, v.y) : make_float2(0.0f, 0.0f);
-            c[2 * r + 1] = row_ok ? make_float2(v.z, v.w) : make_float2(0.0f, 0.0f);
-            in[2 * r] = row_ok; in[2 * r + 1] = row_ok;
-        } else {
+        const int ci = L.bi + (r >> 1), cj = L.bj + (r & 1);
+        const bool in_grid = (ci >= 0) & (cj >= 0) & (ci < V.m) & (cj < V.m);                  // sdf.h:113-119
+        const bool stored = in_grid & (ci >= V.xs) & (ci < V.xe);
+        // the row is in the grid but not stored here: a violation if one of its two corners is in the grid
+        if (in_grid & !stored & (L.k_ok[0] | L.k_ok[1])) viol = 1u;
+        L.row_ok[r] = stored;
+        const long long at = stored ? ((long long)(ci - V.xs) * V.m + cj) * V.m + kc : 0ll;
+        L.v[r] = *reinterpret_cast<const vol_f4*>(reinterpret_cast<const float*>(V.dw + at));
+    }
+}
+
+__device__ __forceinline__ bool lookup_finish(const Lookup& L, float& out) {
+    float w_sum = 0.0f, sum_d = 0.0f, hit_val = 0.0f;
+    bool any = false, hit = false;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ck = bk + u;
-                const bool ok = row_ok & (ck >= 0) & (ck < V.m);
-                in[2 * r + u] = ok;
-                c[2 * r + u] = ok ? V.dw[rowbase + ck] : make_float2(0.0f, 0.0f);
+    for (int q = 0; q < 8; ++q) {
+        const int r = q >> 1, u = q & 1;
+        const int ci = L.bi + (q >> 2), cj = L.bj + ((q >> 1) & 1), ck = L.bk + u;
+        const float volume = (fabsf((float)ci - L.fi) + fabsf((float)cj - L.fj)) + fabsf((float)ck - L.fk);
+        // which half of the pair is this corner?
+        const bool lo_half = (L.sel == 0 && u == 0) || (L.sel == -1 && u == 1);
+        const bool hi_half = (L.sel == 0 && u == 1) || (L.sel == 1 && u == 0);
+        const float cd = lo_half ? L.v[r].x : L.v[r].z, cw = lo_half ? L.v[r].y : L.v[r].w;
+        const bool in = L.row_ok[r] & L.k_ok[u] & (lo_half | hi_half);
+        if (in && cw > 0.0f && !hit) {
+            any = true;
+            if ((double)volume < 0.00001) { hit = true; hit_val = cd; }       // exact hit, sdf.cpp:151-153: returns this corner
+            else {
+                const float w = 1.0f / volume;
+                w_sum += w;
+                sum_d += w * cd;
             }
         }
     }
-    float w_sum = 0.0f, sum_d = 0.0f;
-    bool any = false;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int ci = bi + (q >> 2), cj = bj + ((q >> 1) & 1), ck = bk + (q & 1);
-        const float volume = (fabsf((float)ci - fi) + fabsf((float)cj - fj)) + fabsf((float)ck - fk);
-        if (in[q] && c[q].y > 0.0f) {
-            any = true;
-            if ((double)volume < 0.00001) { out = c[q].x; return true; }   // exact hit, sdf.cpp:151-153
-            const float w = 1.0f / volume;
-            w_sum += w;
-            sum_d += w * c[q].x;
-        }
-    }
-    out = sum_d / w_sum;
+    out = hit ? hit_val : sum_d / w_sum;
     return any;
+}
+
+__device__ __forceinline__ bool interp(const Vol& V, double vx, double vy, double vz, float& out, unsigned& viol) {
+    Lookup L;
+    lookup_issue(V, vx, vy, vz, L, viol);
+    return lookup_finish(L, out);
 }
 
 __global__ __launch_bounds__(256) void sample_kernel(Grid g, const float2* __restrict__ dw,
@@ -811,20 +832,28 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     float valA = 0.0f, valB = 0.0f;
     unsigned viol = 0;
     bool okA = false, okB = false;
-    if (owned && q < 7) {
+    {
+        // both look-ups are issued before either is evaluated; lanes without a look-up run the same code on their
+        // sample's centre (in-cache, results masked) so that the whole section stays one basic block
+        const bool actA = owned && q < 7, actB = owned && q < 6;
         Vol V{dw, p.g.m, p.g.xs, p.g.xe};
         double ax = sg.vx, ay = sg.vy, az = sg.vz;
-        if (q >= 1) {
+        if (q >= 1 && q < 7) {
             const int a = (q - 1) >> 1;
             const double step = ((q - 1) & 1) ? -(double)p.v_h : (double)p.v_h;
-            if (a == 0) ax += step; else if (a == 1) ay += step; else az += step;
+            ax += (a == 0) ? step : 0.0; ay += (a == 1) ? step : 0.0; az += (a == 2) ? step : 0.0;
         }
-        okA = interp(V, ax, ay, az, valA, viol);
-        if (q < 6) {
-            double bx, by, bz;
-            voxel_of(p, &p.rpm[9 * q], sg, bx, by, bz);
-            okB = interp(V, bx, by, bz, valB, viol);
-        }
+        double bx, by, bz;
+        voxel_of(p, &p.rpm[9 * (q < 6 ? q : 0)], sg, bx, by, bz);
+        Lookup LA, LB;
+        unsigned violA = 0u, violB = 0u;
+        lookup_issue(V, ax, ay, az, LA, violA);
+        lookup_issue(V, bx, by, bz, LB, violB);
+        const bool fa = lookup_finish(LA, valA), fb = lookup_finish(LB, valB);
+        okA = actA && fa; okB = actB && fb;
+        viol = (actA ? violA : 0u) | (actB ? violB : 0u);
+        if (!actA) valA = 0.0f;
+        if (!actB) valB = 0.0f;
     }
     const int gl = lane & 56;                                   // first lane of this group in the wave
     const unsigned long long maskA = __ballot(okA), maskB = __ballot(okB);
