@@ -616,28 +616,46 @@ __device__ __forceinline__ void lookup_issue(const Vol& V, double vx, double vy,
     }
 }
 
+// 1.0f / v, correctly rounded, for v in (1e-5, 4]: the fused-multiply-add core of the compiler's own f32 division
+// (rcp, two refinements of the reciprocal, quotient, two residual corrections) without its range scaling and
+// special-case fix-up, which do nothing in this range -- same bits, 7 instructions instead of 12.  For any other v
+// (0, NaN) the value is garbage and the caller discards it.
+__device__ __forceinline__ float recip_ieee_small(float v) {
+    float r = __builtin_amdgcn_rcpf(v);
+    const float e0 = __builtin_fmaf(-v, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    float q = r;                                            // 1.0f * r
+    const float e1 = __builtin_fmaf(-v, q, 1.0f);
+    q = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-v, q, 1.0f);
+    return __builtin_fmaf(e2, r, q);
+}
+
+// The reference's loop (sdf.cpp:139-162) without a branch: every corner is evaluated, skipped ones add +0.0f (the
+// sums start at +0.0f and can never become -0.0f, so that changes no bit), the exact-hit early return becomes a
+// latched flag.  (double)volume < 0.00001 is volume <= 1e-5f: 1e-5f is the largest float below the double constant.
 __device__ __forceinline__ bool lookup_finish(const Lookup& L, float& out) {
+    const float di[2] = {fabsf((float)L.bi - L.fi), fabsf((float)(L.bi + 1) - L.fi)};
+    const float dj[2] = {fabsf((float)L.bj - L.fj), fabsf((float)(L.bj + 1) - L.fj)};
+    const float dk[2] = {fabsf((float)L.bk - L.fk), fabsf((float)(L.bk + 1) - L.fk)};
+    const bool hi0 = L.sel == 1, lo1 = L.sel == -1;         // corner k sits in the high half / corner k+1 in the low half
     float w_sum = 0.0f, sum_d = 0.0f, hit_val = 0.0f;
     bool any = false, hit = false;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int r = q >> 1, u = q & 1;
-        const int ci = L.bi + (q >> 2), cj = L.bj + ((q >> 1) & 1), ck = L.bk + u;
-        const float volume = (fabsf((float)ci - L.fi) + fabsf((float)cj - L.fj)) + fabsf((float)ck - L.fk);
-        // which half of the pair is this corner?
-        const bool lo_half = (L.sel == 0 && u == 0) || (L.sel == -1 && u == 1);
-        const bool hi_half = (L.sel == 0 && u == 1) || (L.sel == 1 && u == 0);
-        const float cd = lo_half ? L.v[r].x : L.v[r].z, cw = lo_half ? L.v[r].y : L.v[r].w;
-        const bool in = L.row_ok[r] & L.k_ok[u] & (lo_half | hi_half);
-        if (in && cw > 0.0f && !hit) {
-            any = true;
-            if ((double)volume < 0.00001) { hit = true; hit_val = cd; }       // exact hit, sdf.cpp:151-153: returns this corner
-            else {
-                const float w = 1.0f / volume;
-                w_sum += w;
-                sum_d += w * cd;
-            }
-        }
+        const float volume = (di[q >> 2] + dj[(q >> 1) & 1]) + dk[u];
+        const float cd = u == 0 ? (hi0 ? L.v[r].z : L.v[r].x) : (lo1 ? L.v[r].x : L.v[r].z);
+        const float cw = u == 0 ? (hi0 ? L.v[r].w : L.v[r].y) : (lo1 ? L.v[r].y : L.v[r].w);
+        const bool take = L.row_ok[r] & L.k_ok[u] & (cw > 0.0f) & !hit;
+        const bool exact = take & (volume <= 1.0e-5f);
+        const bool acc = take & !exact;
+        const float w = recip_ieee_small(volume);
+        w_sum += acc ? w : 0.0f;
+        sum_d += acc ? w * cd : 0.0f;
+        hit_val = exact ? cd : hit_val;
+        any |= take;
+        hit |= exact;
     }
     out = hit ? hit_val : sum_d / w_sum;
     return any;
@@ -707,11 +725,9 @@ struct SampleGeom {
     double vx, vy, vz;   // continuous voxel coordinates of its world position
 };
 
-__device__ __forceinline__ int classify(const TrackParams& p, const float4* __restrict__ samples, int n,
-                                        SampleGeom& sg) {
+__device__ __forceinline__ int classify_sample(const TrackParams& p, const float4 s, bool exists, SampleGeom& sg) {
     sg.px = sg.py = sg.pz = 0.0; sg.vx = sg.vy = sg.vz = 0.0;
-    if (n >= p.n_samples) return kClsSkip;
-    const float4 s = samples[n];
+    if (!exists) return kClsSkip;
     if (is_nan(s.x) || is_nan(s.y) || is_nan(s.z)) return kClsSkip;          // camera_tracking.cpp:168
     sg.px = (double)s.x; sg.py = (double)s.y; sg.pz = (double)s.z;
     // project_camera_to_world (:55-58) + get_voxel_coordinates (sdf.h:143-147)
@@ -725,6 +741,12 @@ __device__ __forceinline__ int classify(const TrackParams& p, const float4* __re
     if (sg.vx < 0 || sg.vy < 0 || sg.vz < 0) return kClsOog;                 // :261-264
     if (sg.vx >= dm || sg.vy >= dm || sg.vz >= dm) return kClsOog;           // :265-268
     return kClsIn;
+}
+
+__device__ __forceinline__ int classify(const TrackParams& p, const float4* __restrict__ samples, int n, SampleGeom& sg) {
+    const bool exists = n < p.n_samples;
+    const float4 s = exists ? samples[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return classify_sample(p, s, exists, sg);
 }
 
 __device__ __forceinline__ void voxel_of(const TrackParams& p, const double* R, const SampleGeom& sg,
@@ -744,25 +766,34 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     __shared__ unsigned long long s_in[NW], s_oog[NW];     // the 256-sample window of this workgroup
     __shared__ unsigned long long s_in2[NW], s_oog2[NW];   // look-ahead windows
     __shared__ double s_red[NW][8][8];                     // [wave][q][slot]
+    __shared__ double s_rpm[54];                           // the six perturbed rotations, for lane-indexed access
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's 32 samples
+    // p.rpm[9*q] with a per-lane q is a vector load from the kernel-argument segment: a memory round trip in
+    // front of the look-ups.  Stage the matrices in LDS while the samples are being classified.
+    if (tid < 54) s_rpm[tid] = p.rpm[tid];
 
     // ---- phase A: classify the window [base, base+256) -- thread t looks at sample base+t
     SampleGeom win;
-    const int wcls = classify(p, samples, base + tid, win);
+    __shared__ float4 s_own[kSamplesPerBlock];             // the workgroup's own samples: the first 32 of the window
     {
+        const bool exists = base + tid < p.n_samples;
+        const float4 smp = exists ? samples[base + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < kSamplesPerBlock) s_own[tid] = smp;
+        const int wcls = classify_sample(p, smp, exists, win);
         const unsigned long long b_in = __ballot(wcls == kClsIn);
         const unsigned long long b_oog = __ballot(wcls == kClsOog);
         if (lane == 0) { s_in[wv] = b_in; s_oog[wv] = b_oog; }
     }
     __syncthreads();
 
-    // ---- phase B: this thread's own sample (group g) and look-ups (q and q + 7)
+    // ---- phase B: this thread's own sample (group g, handed over through LDS: no second trip to memory) and
+    // its look-ups (q and q + 7)
     const int g = tid >> 3, q = tid & 7;
     const int n = base + g;
     SampleGeom sg;
-    const int cls = classify(p, samples, n, sg);
+    const int cls = classify_sample(p, s_own[g], n < p.n_samples, sg);
 
     // stale-carry multiplicity of sample g: out-of-grid samples between it and the next in-grid one
     unsigned mult = 1;
@@ -844,7 +875,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             ax += (a == 0) ? step : 0.0; ay += (a == 1) ? step : 0.0; az += (a == 2) ? step : 0.0;
         }
         double bx, by, bz;
-        voxel_of(p, &p.rpm[9 * (q < 6 ? q : 0)], sg, bx, by, bz);
+        voxel_of(p, &s_rpm[9 * (q < 6 ? q : 0)], sg, bx, by, bz);
         Lookup LA, LB;
         unsigned violA = 0u, violB = 0u;
         lookup_issue(V, ax, ay, az, LA, violA);
