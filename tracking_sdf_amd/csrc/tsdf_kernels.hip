@@ -603,15 +603,23 @@ __device__ __forceinline__ void lookup_issue(const Vol& V, double vx, double vy,
     L.k_ok[1] = (bk >= -1) & (bk < V.m - 1);
     const long long d = (long long)bk - (long long)kc;
     L.sel = d < -1 ? 2 : (d > 1 ? 2 : (int)d);
+    // the four voxel rows (i,j), (i,j+1), (i+1,j), (i+1,j+1): validity per axis, one 64-bit base address
+    const int m = V.m, bi = L.bi, bj = L.bj;
+    const bool i_in[2] = {bi >= 0 && bi < m, bi >= -1 && bi < m - 1};                       // sdf.h:113-119
+    const bool j_in[2] = {bj >= 0 && bj < m, bj >= -1 && bj < m - 1};
+    const bool i_st[2] = {i_in[0] && bi >= V.xs && bi < V.xe, i_in[1] && bi + 1 >= V.xs && bi + 1 < V.xe};
+    const bool k_any = L.k_ok[0] | L.k_ok[1];
+    const long long mm = (long long)m * m;
+    const long long base = (((long long)bi - V.xs) * m + bj) * m + kc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int ci = L.bi + (r >> 1), cj = L.bj + (r & 1);
-        const bool in_grid = (ci >= 0) & (cj >= 0) & (ci < V.m) & (cj < V.m);                  // sdf.h:113-119
-        const bool stored = in_grid & (ci >= V.xs) & (ci < V.xe);
+        const int io = r >> 1, jo = r & 1;
+        const bool in_grid = i_in[io] & j_in[jo];
+        const bool stored = i_st[io] & j_in[jo];
         // the row is in the grid but not stored here: a violation if one of its two corners is in the grid
-        if (in_grid & !stored & (L.k_ok[0] | L.k_ok[1])) viol = 1u;
+        viol |= (in_grid & !stored & k_any) ? 1u : 0u;
         L.row_ok[r] = stored;
-        const long long at = stored ? ((long long)(ci - V.xs) * V.m + cj) * V.m + kc : 0ll;
+        const long long at = stored ? base + (io ? mm : 0ll) + (jo ? (long long)m : 0ll) : 0ll;
         L.v[r] = *reinterpret_cast<const vol_f4*>(reinterpret_cast<const float*>(V.dw + at));
     }
 }
