@@ -594,7 +594,10 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
-    CREATE_TRY(hipMalloc((void**)&h->dw, (size_t)h->n_stored * sizeof(float2)));
+    // two extra voxels {D = 0, W = 0} behind the volume: look-ups of rows that are not stored read this pair instead
+    // of carrying a validity flag per row (W = 0 makes the reference's own W > 0 test skip them)
+    CREATE_TRY(hipMalloc((void**)&h->dw, ((size_t)h->n_stored + 2) * sizeof(float2)));
+    CREATE_TRY(hipMemset(h->dw + h->n_stored, 0, 2 * sizeof(float2)));
     if (cfg->with_color) CREATE_TRY(hipMalloc((void**)&h->crgb, (size_t)h->n_stored * sizeof(float4)));
     CREATE_TRY(hipMalloc((void**)&h->counters, kNumCounters * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(h->counters, 0, kNumCounters * sizeof(unsigned long long), h->stream));

@@ -572,6 +572,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
 struct Vol {
     const float2* dw;
     int m, xs, xe;
+    __device__ __forceinline__ long long dummy() const { return (long long)(xe - xs) * m * m; }   // the {0,0} pair behind the volume
 };
 
 typedef float vol_f4 __attribute__((ext_vector_type(4), aligned(8)));   // two neighbouring voxels {D,W,D,W}
@@ -588,8 +589,7 @@ struct Lookup {
     int bi, bj, bk;
     int sel;                 // bk - kc: 0 = corners (v.xy, v.zw); -1 = (none, v.xy); +1 = (v.zw, none); else none
     bool k_ok[2];            // corner k / k+1 inside the grid in k
-    bool row_ok[4];          // voxel row (i,j) inside the grid and stored on this rank
-    vol_f4 v[4];
+    vol_f4 v[4];             // rows that are not stored (or outside the grid) hold the dummy pair: W = 0
 };
 
 __device__ __forceinline__ void lookup_issue(const Vol& V, double vx, double vy, double vz, Lookup& L, unsigned& viol) {
@@ -618,8 +618,7 @@ __device__ __forceinline__ void lookup_issue(const Vol& V, double vx, double vy,
         const bool stored = i_st[io] & j_in[jo];
         // the row is in the grid but not stored here: a violation if one of its two corners is in the grid
         viol |= (in_grid & !stored & k_any) ? 1u : 0u;
-        L.row_ok[r] = stored;
-        const long long at = stored ? base + (io ? mm : 0ll) + (jo ? (long long)m : 0ll) : 0ll;
+        const long long at = stored ? base + (io ? mm : 0ll) + (jo ? (long long)m : 0ll) : V.dummy();
         L.v[r] = *reinterpret_cast<const vol_f4*>(reinterpret_cast<const float*>(V.dw + at));
     }
 }
@@ -655,7 +654,7 @@ __device__ __forceinline__ bool lookup_finish(const Lookup& L, float& out) {
         const float volume = (di[q >> 2] + dj[(q >> 1) & 1]) + dk[u];
         const float cd = u == 0 ? (hi0 ? L.v[r].z : L.v[r].x) : (lo1 ? L.v[r].x : L.v[r].z);
         const float cw = u == 0 ? (hi0 ? L.v[r].w : L.v[r].y) : (lo1 ? L.v[r].y : L.v[r].w);
-        const bool take = L.row_ok[r] & L.k_ok[u] & (cw > 0.0f) & !hit;
+        const bool take = L.k_ok[u] & (cw > 0.0f) & !hit;
         const bool exact = take & (volume <= 1.0e-5f);
         const bool acc = take & !exact;
         const float w = recip_ieee_small(volume);
