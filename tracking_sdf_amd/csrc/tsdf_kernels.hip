@@ -783,24 +783,31 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
 
     // ---- phase A: classify the window [base, base+256) -- thread t looks at sample base+t
     SampleGeom win;
-    __shared__ float4 s_own[kSamplesPerBlock];             // the workgroup's own samples: the first 32 of the window
+    __shared__ double s_geom[kSamplesPerBlock][6];         // geometry + class of the workgroup's own samples (the first
+    __shared__ int s_cls[kSamplesPerBlock];                // 32 of the window), handed over by the threads that classify them
     {
         const bool exists = base + tid < p.n_samples;
         const float4 smp = exists ? samples[base + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < kSamplesPerBlock) s_own[tid] = smp;
         const int wcls = classify_sample(p, smp, exists, win);
+        if (tid < kSamplesPerBlock) {
+            s_geom[tid][0] = win.px; s_geom[tid][1] = win.py; s_geom[tid][2] = win.pz;
+            s_geom[tid][3] = win.vx; s_geom[tid][4] = win.vy; s_geom[tid][5] = win.vz;
+            s_cls[tid] = wcls;
+        }
         const unsigned long long b_in = __ballot(wcls == kClsIn);
         const unsigned long long b_oog = __ballot(wcls == kClsOog);
         if (lane == 0) { s_in[wv] = b_in; s_oog[wv] = b_oog; }
     }
     __syncthreads();
 
-    // ---- phase B: this thread's own sample (group g, handed over through LDS: no second trip to memory) and
+    // ---- phase B: this thread's own sample (group g; no second trip to memory, no second classification) and
     // its look-ups (q and q + 7)
     const int g = tid >> 3, q = tid & 7;
     const int n = base + g;
     SampleGeom sg;
-    const int cls = classify_sample(p, s_own[g], n < p.n_samples, sg);
+    sg.px = s_geom[g][0]; sg.py = s_geom[g][1]; sg.pz = s_geom[g][2];
+    sg.vx = s_geom[g][3]; sg.vy = s_geom[g][4]; sg.vz = s_geom[g][5];
+    const int cls = s_cls[g];
 
     // stale-carry multiplicity of sample g: out-of-grid samples between it and the next in-grid one
     unsigned mult = 1;
