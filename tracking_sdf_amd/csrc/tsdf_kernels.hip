@@ -712,7 +712,7 @@ hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const d
 // Stale carry-over (:156-159,176-182,261-268): an out-of-grid pixel re-adds the previous successful
 // pixel's terms, i.e. a successful sample counts 1 + #{out-of-grid samples between it and the next
 // in-grid one, NaN samples skipped} times.  Classification needs geometry only, so every workgroup
-// classifies a 256-sample window starting at its own 32 samples (64-bit ballots = 64 consecutive
+// classifies a window of kTrackBlock samples starting at its own kSamplesPerBlock samples (64-bit ballots = 64 consecutive
 // samples of the reference's column-major visiting order) and reads the run lengths off the masks,
 // looking further ahead cooperatively in the rare case a run outlives the window.
 //
@@ -725,7 +725,7 @@ hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const d
 
 enum { kClsSkip = 0, kClsOog = 1, kClsIn = 2 };
 constexpr int kLanesPerSample = 8;
-constexpr int kSamplesPerBlock = kTrackBlock / kLanesPerSample;   // 32
+constexpr int kSamplesPerBlock = kTrackBlock / kLanesPerSample;   // 48
 
 struct SampleGeom {
     double px, py, pz;   // camera-frame point
@@ -770,13 +770,13 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
                                                              const float4* __restrict__ samples,
                                                              double* __restrict__ partials) {
     constexpr int NW = kTrackBlock / 64;
-    __shared__ unsigned long long s_in[NW], s_oog[NW];     // the 256-sample window of this workgroup
+    __shared__ unsigned long long s_in[NW], s_oog[NW];     // the window of this workgroup (kTrackBlock samples)
     __shared__ unsigned long long s_in2[NW], s_oog2[NW];   // look-ahead windows
     __shared__ double s_red[NW][8][8];                     // [wave][q][slot]
     __shared__ double s_rpm[54];                           // the six perturbed rotations, for lane-indexed access
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's 32 samples
+    const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's own samples
     // p.rpm[9*q] with a per-lane q is a vector load from the kernel-argument segment: a memory round trip in
     // front of the look-ups.  Stage the matrices in LDS while the samples are being classified.
     if (tid < 54) s_rpm[tid] = p.rpm[tid];
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     // ---- phase A: classify the window [base, base+256) -- thread t looks at sample base+t
     SampleGeom win;
     __shared__ double s_geom[kSamplesPerBlock][6];         // geometry + class of the workgroup's own samples (the first
-    __shared__ int s_cls[kSamplesPerBlock];                // 32 of the window), handed over by the threads that classify them
+    __shared__ int s_cls[kSamplesPerBlock];                // ones of the window), handed over by the threads that classify them
     {
         const bool exists = base + tid < p.n_samples;
         const float4 smp = exists ? samples[base + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -812,15 +812,19 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     // stale-carry multiplicity of sample g: out-of-grid samples between it and the next in-grid one
     unsigned mult = 1;
     if (p.stale_carry) {
-        // (workgroup-uniform) does the run of the last own in-grid sample reach past the 256-sample window?
-        const unsigned long long own_in = s_in[0] & 0xFFFFFFFFull;
+        // (workgroup-uniform) does the run of the last own in-grid sample reach past the window?
+        constexpr unsigned long long kOwnMask = kSamplesPerBlock >= 64 ? ~0ull : ((1ull << (kSamplesPerBlock & 63)) - 1ull);
+        static_assert(kSamplesPerBlock <= 64, "the own samples must fit the first ballot word");
+        const unsigned long long own_in = s_in[0] & kOwnMask;
         bool need_tail = false;
         unsigned tail = 0;
         if (own_in) {
             // it reaches the window end iff no in-grid bit follows it
-            const int last_own = 63 - __clzll((long long)own_in);                  // <= 31
-            const unsigned long long above = ~0ull << (last_own + 1);
-            need_tail = ((s_in[0] & above) == 0ull) && (s_in[1] | s_in[2] | s_in[3]) == 0ull;
+            const int last_own = 63 - __clzll((long long)own_in);
+            const unsigned long long above = last_own == 63 ? 0ull : ~0ull << (last_own + 1);
+            unsigned long long later = s_in[0] & above;
+            for (int w = 1; w < NW; ++w) later |= s_in[w];
+            need_tail = later == 0ull;
         }
         if (need_tail) {
             bool found = false;
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             }
         }
         if (cls == kClsIn) {
-            const unsigned long long above = ~0ull << (g + 1);          // g <= 31
+            const unsigned long long above = g == 63 ? 0ull : ~0ull << (g + 1);
             unsigned cnt = 0;
             bool found = false;
             unsigned long long mi = s_in[0] & above;
