@@ -712,7 +712,7 @@ hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const d
 // Stale carry-over (:156-159,176-182,261-268): an out-of-grid pixel re-adds the previous successful
 // pixel's terms, i.e. a successful sample counts 1 + #{out-of-grid samples between it and the next
 // in-grid one, NaN samples skipped} times.  Classification needs geometry only, so every workgroup
-// classifies a window of kTrackBlock samples starting at its own kSamplesPerBlock samples (64-bit ballots = 64 consecutive
+// classifies a window of 64 samples starting at its own kSamplesPerBlock samples (64-bit ballots = 64 consecutive
 // samples of the reference's column-major visiting order) and reads the run lengths off the masks,
 // looking further ahead cooperatively in the rare case a run outlives the window.
 //
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
                                                              const float4* __restrict__ samples,
                                                              double* __restrict__ partials) {
     constexpr int NW = kTrackBlock / 64;
-    __shared__ unsigned long long s_in[NW], s_oog[NW];     // the window of this workgroup (kTrackBlock samples)
+    __shared__ unsigned long long s_in[1], s_oog[1];       // the 64-sample window of this workgroup
     __shared__ unsigned long long s_in2[NW], s_oog2[NW];   // look-ahead windows
     __shared__ double s_red[NW][8][8];                     // [wave][q][slot]
     __shared__ double s_rpm[54];                           // the six perturbed rotations, for lane-indexed access
@@ -781,22 +781,24 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     // front of the look-ups.  Stage the matrices in LDS while the samples are being classified.
     if (tid < 54) s_rpm[tid] = p.rpm[tid];
 
-    // ---- phase A: classify the window [base, base+256) -- thread t looks at sample base+t
-    SampleGeom win;
-    __shared__ double s_geom[kSamplesPerBlock][6];         // geometry + class of the workgroup's own samples (the first
-    __shared__ int s_cls[kSamplesPerBlock];                // ones of the window), handed over by the threads that classify them
-    {
-        const bool exists = base + tid < p.n_samples;
-        const float4 smp = exists ? samples[base + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- phase A: the first wavefront classifies the 64-sample window [base, base+64): the workgroup's own samples
+    // and the ones right after them (where the run of an own sample usually ends); the kernel is bound by instruction
+    // issue, so the other wavefronts do not repeat this for samples that are rarely needed
+    __shared__ double s_geom[kSamplesPerBlock][6];         // geometry + class of the own samples, handed over by the
+    __shared__ int s_cls[kSamplesPerBlock];                // threads that classify them
+    if (wv == 0) {
+        SampleGeom win;
+        const bool exists = base + lane < p.n_samples;
+        const float4 smp = exists ? samples[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
         const int wcls = classify_sample(p, smp, exists, win);
-        if (tid < kSamplesPerBlock) {
-            s_geom[tid][0] = win.px; s_geom[tid][1] = win.py; s_geom[tid][2] = win.pz;
-            s_geom[tid][3] = win.vx; s_geom[tid][4] = win.vy; s_geom[tid][5] = win.vz;
-            s_cls[tid] = wcls;
+        if (lane < kSamplesPerBlock) {
+            s_geom[lane][0] = win.px; s_geom[lane][1] = win.py; s_geom[lane][2] = win.pz;
+            s_geom[lane][3] = win.vx; s_geom[lane][4] = win.vy; s_geom[lane][5] = win.vz;
+            s_cls[lane] = wcls;
         }
         const unsigned long long b_in = __ballot(wcls == kClsIn);
         const unsigned long long b_oog = __ballot(wcls == kClsOog);
-        if (lane == 0) { s_in[wv] = b_in; s_oog[wv] = b_oog; }
+        if (lane == 0) { s_in[0] = b_in; s_oog[0] = b_oog; }
     }
     __syncthreads();
 
@@ -822,13 +824,11 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             // it reaches the window end iff no in-grid bit follows it
             const int last_own = 63 - __clzll((long long)own_in);
             const unsigned long long above = last_own == 63 ? 0ull : ~0ull << (last_own + 1);
-            unsigned long long later = s_in[0] & above;
-            for (int w = 1; w < NW; ++w) later |= s_in[w];
-            need_tail = later == 0ull;
+            need_tail = (s_in[0] & above) == 0ull;
         }
         if (need_tail) {
             bool found = false;
-            for (int pos = base + kTrackBlock; !found && pos < p.n_samples; pos += kTrackBlock) {
+            for (int pos = base + 64; !found && pos < p.n_samples; pos += kTrackBlock) {
                 SampleGeom tmp;
                 const int c2 = classify(p, samples, pos + tid, tmp);
                 const unsigned long long i2 = __ballot(c2 == kClsIn);
@@ -851,25 +851,12 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         if (cls == kClsIn) {
             const unsigned long long above = g == 63 ? 0ull : ~0ull << (g + 1);
             unsigned cnt = 0;
-            bool found = false;
-            unsigned long long mi = s_in[0] & above;
+            const unsigned long long mi = s_in[0] & above;
             if (mi) {
                 const int nxt = __ffsll((long long)mi) - 1;
                 cnt = __popcll(s_oog[0] & above & ((1ull << nxt) - 1ull));
-                found = true;
             } else {
-                cnt = __popcll(s_oog[0] & above);
-                for (int w = 1; w < NW && !found; ++w) {
-                    mi = s_in[w];
-                    if (mi) {
-                        const int nxt = __ffsll((long long)mi) - 1;
-                        cnt += __popcll(s_oog[w] & ((1ull << nxt) - 1ull));
-                        found = true;
-                    } else {
-                        cnt += __popcll(s_oog[w]);
-                    }
-                }
-                if (!found) cnt += tail;
+                cnt = __popcll(s_oog[0] & above) + tail;
             }
             mult = 1u + cnt;
         }
