@@ -262,7 +262,7 @@ def main():
     # launch, i.e. on the GPU's idle time.  Same calls, same error checks.
     import ctypes as C
     L = ts.lib()
-    f_set, f_track, f_integrate, f_pose = L.tsdf_set_frame_device, L.tsdf_track, L.tsdf_integrate, L.tsdf_get_pose
+    f_set, f_step, f_pose = L.tsdf_set_frame_device, L.tsdf_track_and_integrate, L.tsdf_get_pose
     handle = sdf._h
     dev_args = None
     if not (args.depth_input or args.host_frames):
@@ -280,11 +280,10 @@ def main():
             a = dev_args[k]
             sdf._check(f_set(handle, a[0], a[1], a[2], args.width, args.height))
         tq = perf()
-        rc = f_track(handle, None)
+        rc = f_step(handle, 1, None, None)                  # estimate_new_position + update, sdf_reconstruction.cpp:70,74
         if timed:
             track_wall[0] += perf() - tq
         sdf._check(rc)
-        sdf._check(f_integrate(handle, None))
         f_pose(handle, None, pose_t_ptr, None, None)        # host-side pose read while the integration runs
         est.append(pose_t.copy())
 

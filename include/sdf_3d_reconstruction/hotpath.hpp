@@ -169,6 +169,13 @@ public:
         sync();
         sdf->check(rc, "tsdf_track");
     }
+    // estimate_new_position(sdf) + sdf->update(this) in one call (the pair of sdf_reconstruction.cpp:70,74): the
+    // integration is launched the moment the last Gauss-Newton pass is solved
+    void estimate_new_position_and_update(const SDF* sdf, tsdf_track_stats* stats = nullptr) {
+        const int rc = tsdf_track_and_integrate(sdf->handle(), 1, stats, nullptr);
+        sync();
+        sdf->check(rc, "tsdf_track_and_integrate");
+    }
     void sync() {
         tsdf_get_pose(sdf_->handle(), rot.data(), trans.data(), rot_inv.data(), rot_inv_trans.data());
     }

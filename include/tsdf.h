@@ -158,6 +158,10 @@ int tsdf_get_preprocessed(tsdf_handle *h, float *xyz, float *nrm);
 /* ---- the hot path ------------------------------------------------------------------------- */
 int tsdf_integrate(tsdf_handle *h, tsdf_integrate_stats *stats);  /* SDF::update at the current pose */
 int tsdf_track(tsdf_handle *h, tsdf_track_stats *stats);          /* estimate_new_position: updates the pose */
+/* The two hot calls of kinect_callback back to back (sdf_reconstruction.cpp:69-74): track when do_track != 0 (every
+ * frame but the first), then integrate at the resulting pose.  One ABI crossing instead of two: the integration is
+ * launched the moment the last Gauss-Newton pass is solved.  A tracking error is returned and nothing is integrated. */
+int tsdf_track_and_integrate(tsdf_handle *h, int32_t do_track, tsdf_track_stats *track_stats, tsdf_integrate_stats *integrate_stats);
 /* One accumulation pass at the current pose.  A (6x6 row-major) and b are this rank's partial sums
  * (NOT all-reduced), so a test can add the partials of several slabs itself. */
 int tsdf_accumulate(tsdf_handle *h, double A[36], double b[6], tsdf_accum_stats *stats);

@@ -438,3 +438,34 @@ def test_checkpoint_roundtrip(tmp_path):
         go3.load(path)
     with pytest.raises(ts.TsdfError):
         go2.load(str(tmp_path / "missing.tsdf"))
+
+
+def test_track_and_integrate_equals_the_two_calls():
+    """tsdf_track_and_integrate = tsdf_track followed by tsdf_integrate (same pose, same volume), and it integrates
+    nothing when tracking fails."""
+    import ctypes as C
+    import tracking_sdf_amd as ts
+    m = 48
+    seq = synth.Sequence(n_frames=3, width=160, height=120, noise=True, holes=0.02, step=3)
+    frames = [seq.frame(k) for k in range(3)]
+    out = []
+    for fused in (False, True):
+        s, t = make_gpu(m, seq.K)
+        s.update(t, *frames[0])
+        for k in (1, 2):
+            s.set_frame(*frames[k])
+            if fused:
+                s._check(ts.lib().tsdf_track_and_integrate(s._h, 1, None, None))
+            else:
+                t.estimate_new_position()
+                s.update()
+        out.append((t.rot.copy(), t.trans.copy()) + s.download())
+        if fused:
+            nan = np.full_like(frames[0][0], np.nan)
+            s.set_frame(nan, frames[0][1], frames[0][2])
+            assert ts.lib().tsdf_track_and_integrate(s._h, 1, None, None) == ts.E_NO_SAMPLES
+            D, W = s.download()
+            assert np.array_equal(W, out[-1][3])              # nothing was integrated after the failed track
+        s.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)

@@ -87,7 +87,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p
 ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
-    "tsdf_set_frame_device", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
+    "tsdf_set_frame_device", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
@@ -141,6 +141,7 @@ def lib():
         "tsdf_track": (C.c_int, [H, C.POINTER(TrackStats)]),
         "tsdf_accumulate": (C.c_int, [H, dp, dp, C.POINTER(AccumStats)]),
         "tsdf_gn_update": (C.c_int, [H, dp, dp, dp, ip]),
+        "tsdf_track_and_integrate": (C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p]),
         "tsdf_sample": (C.c_int, [H, dp, C.c_int32, fp, ip]),
         "tsdf_mesh_extract": (C.c_int, [H, C.c_float, C.c_int32, C.POINTER(C.c_int64)]),
         "tsdf_mesh_read": (C.c_int, [H, fp, fp, C.c_int64]),

@@ -908,6 +908,14 @@ int tsdf_track(tsdf_handle* h, tsdf_track_stats* stats) {
     return TSDF_OK;
 }
 
+int tsdf_track_and_integrate(tsdf_handle* h, int32_t do_track, tsdf_track_stats* track_stats, tsdf_integrate_stats* integrate_stats) {
+    if (do_track) {
+        const int rc = tsdf_track(h, track_stats);
+        if (rc) return rc;
+    }
+    return tsdf_integrate(h, integrate_stats);
+}
+
 int tsdf_sample(tsdf_handle* h, const double* vox, int32_t n, float* val, int32_t* ok) {
     int rc = check_ready(h, false);
     if (rc) return rc;
