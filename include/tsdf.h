@@ -14,6 +14,7 @@
  *   tsdf_set_frame / _device          the borrowed cloud_filtered + normals arguments of the two hot calls
  *   tsdf_integrate                    SDF::update                  sdf.h:161-163, src/sdf.cpp:224-315
  *   tsdf_track                        CameraTracking::estimate_new_position  camera_tracking.h:101, src/camera_tracking.cpp:66-245
+ *   tsdf_track_and_integrate          the pair of calls in kinect_callback  src/sdf_reconstruction.cpp:69-74
  *   tsdf_accumulate                   one Gauss-Newton pass, src/camera_tracking.cpp:81-189 (+ get_partial_derivative :246-363)
  *   tsdf_gn_update                    src/camera_tracking.cpp:191-239 (+ eigen_utils::direct_exponential_map, src/eigen_utils.cpp:85-128)
  *   tsdf_sample                       SDF::interpolate_distance    sdf.h:86, src/sdf.cpp:127-163
