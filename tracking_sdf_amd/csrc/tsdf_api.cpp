@@ -47,7 +47,8 @@ struct tsdf_handle {
 
     int device = 0;
     hipStream_t stream = nullptr;
-    float2* dw = nullptr;
+    float2* dw = nullptr;          // first voxel of the stored slab (inside dw_alloc, after the front padding)
+    float2* dw_alloc = nullptr;
     float4* crgb = nullptr;
     int64_t n_stored = 0;          // voxels in [xs, xe)
     unsigned long long* counters = nullptr;     // device, kNumCounters
@@ -313,6 +314,7 @@ void fill_track_params(const tsdf_handle* h, TrackParams& p) {
     p.stale_carry = h->cfg.stale_carry;
 }
 
+constexpr size_t kVolumePadFront = 16;   // voxels of {0,0} padding in front of the volume (128 bytes)
 constexpr size_t kShmSlot = 512;   // bytes per (rank, parity) slot: 34 doubles + the pass-number word, padded
 
 void shm_close(tsdf_handle* h) {
@@ -594,9 +596,13 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
-    // two extra voxels {D = 0, W = 0} behind the volume: look-ups of rows that are not stored read this pair instead
-    // of carrying a validity flag per row (W = 0 makes the reference's own W > 0 test skip them)
-    CREATE_TRY(hipMalloc((void**)&h->dw, ((size_t)h->n_stored + 2) * sizeof(float2)));
+    // Padding voxels {D = 0, W = 0} around the volume (16 in front: keeps the 128-byte alignment of the rows; 2 behind).
+    // Tracker look-ups read the corner pair (k, k+1) with one 16-byte load at k in [-1, m-1]: at the two ends of a row
+    // that touches the neighbouring row or, for the first / last row, this padding; the pair behind the volume also
+    // stands in for rows that are not stored (W = 0 makes the reference's own W > 0 test skip it).
+    CREATE_TRY(hipMalloc((void**)&h->dw_alloc, ((size_t)h->n_stored + kVolumePadFront + 2) * sizeof(float2)));
+    CREATE_TRY(hipMemset(h->dw_alloc, 0, kVolumePadFront * sizeof(float2)));
+    h->dw = h->dw_alloc + kVolumePadFront;
     CREATE_TRY(hipMemset(h->dw + h->n_stored, 0, 2 * sizeof(float2)));
     if (cfg->with_color) CREATE_TRY(hipMalloc((void**)&h->crgb, (size_t)h->n_stored * sizeof(float4)));
     CREATE_TRY(hipMalloc((void**)&h->counters, kNumCounters * sizeof(unsigned long long)));
@@ -662,7 +668,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->mesh_verts) (void)hipFree(h->mesh_verts);
     if (h->mesh_desc) (void)hipFree(h->mesh_desc);
     if (h->mesh_colors) (void)hipFree(h->mesh_colors);
-    if (h->dw) (void)hipFree(h->dw);
+    if (h->dw_alloc) (void)hipFree(h->dw_alloc);
     if (h->crgb) (void)hipFree(h->crgb);
     for (auto& ep : h->ev_pool) { if (ep.a) (void)hipEventDestroy(ep.a); if (ep.b) (void)hipEventDestroy(ep.b); }
     if (h->ev_track.a) (void)hipEventDestroy(h->ev_track.a);

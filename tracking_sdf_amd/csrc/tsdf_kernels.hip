@@ -582,27 +582,25 @@ typedef float vol_f4 __attribute__((ext_vector_type(4), aligned(8)));   // two n
 // put an s_waitcnt vmcnt(0) after every one of the four row loads -- four serialized round trips per look-up,
 // eight for a lane with two look-ups; branch-free, all loads of a lane are in flight together.
 // The corners k and k+1 of one (i,j) voxel row are neighbours in memory: ONE 16-byte load per row instead of two
-// 8-byte ones (the gathers are bound by the number of scattered requests the vector L1 takes, not by bytes).  The
-// pair is read at kc = clamp(bk, 0, m-2) so that the address is always valid; bk - kc says where the corners are.
+// 8-byte ones.
 struct Lookup {
     float fi, fj, fk;
     int bi, bj, bk;
-    int sel;                 // bk - kc: 0 = corners (v.xy, v.zw); -1 = (none, v.xy); +1 = (v.zw, none); else none
     bool k_ok[2];            // corner k / k+1 inside the grid in k
-    vol_f4 v[4];             // rows that are not stored (or outside the grid) hold the dummy pair: W = 0
+    vol_f4 v[4];             // {D,W} of corner k (x,y) and k+1 (z,w); rows that are not stored hold the dummy pair: W = 0
 };
 
+// The pair is read at k = bk clamped to [-1, m-1]: at k = -1 / m-1 one half is the last / first voxel of the
+// neighbouring row (or the padding around the volume) and k_ok masks it.
 __device__ __forceinline__ void lookup_issue(const Vol& V, double vx, double vy, double vz, Lookup& L, unsigned& viol) {
     L.fi = (float)vx; L.fj = (float)vy; L.fk = (float)vz;                // f64 -> f32, sdf.cpp:130-132
     L.bi = trunc_x86(L.fi); L.bj = trunc_x86(L.fj); L.bk = trunc_x86(L.fk);
     const int bk = L.bk;
-    int kc = bk < 0 ? 0 : bk;
-    kc = kc > V.m - 2 ? V.m - 2 : kc;
+    int kc = bk < -1 ? -1 : bk;
+    kc = kc > V.m - 1 ? V.m - 1 : kc;
     // INT_MIN + 1 wraps nowhere: bk + 1 is only compared
     L.k_ok[0] = (bk >= 0) & (bk < V.m);
     L.k_ok[1] = (bk >= -1) & (bk < V.m - 1);
-    const long long d = (long long)bk - (long long)kc;
-    L.sel = d < -1 ? 2 : (d > 1 ? 2 : (int)d);
     // the four voxel rows (i,j), (i,j+1), (i+1,j), (i+1,j+1): validity per axis, one 64-bit base address
     const int m = V.m, bi = L.bi, bj = L.bj;
     const bool i_in[2] = {bi >= 0 && bi < m, bi >= -1 && bi < m - 1};                       // sdf.h:113-119
@@ -645,15 +643,14 @@ __device__ __forceinline__ bool lookup_finish(const Lookup& L, float& out) {
     const float di[2] = {fabsf((float)L.bi - L.fi), fabsf((float)(L.bi + 1) - L.fi)};
     const float dj[2] = {fabsf((float)L.bj - L.fj), fabsf((float)(L.bj + 1) - L.fj)};
     const float dk[2] = {fabsf((float)L.bk - L.fk), fabsf((float)(L.bk + 1) - L.fk)};
-    const bool hi0 = L.sel == 1, lo1 = L.sel == -1;         // corner k sits in the high half / corner k+1 in the low half
     float w_sum = 0.0f, sum_d = 0.0f, hit_val = 0.0f;
     bool any = false, hit = false;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int r = q >> 1, u = q & 1;
         const float volume = (di[q >> 2] + dj[(q >> 1) & 1]) + dk[u];
-        const float cd = u == 0 ? (hi0 ? L.v[r].z : L.v[r].x) : (lo1 ? L.v[r].x : L.v[r].z);
-        const float cw = u == 0 ? (hi0 ? L.v[r].w : L.v[r].y) : (lo1 ? L.v[r].y : L.v[r].w);
+        const float cd = u == 0 ? L.v[r].x : L.v[r].z;
+        const float cw = u == 0 ? L.v[r].y : L.v[r].w;
         const bool take = L.k_ok[u] & (cw > 0.0f) & !hit;
         const bool exact = take & (volume <= 1.0e-5f);
         const bool acc = take & !exact;
