@@ -246,7 +246,9 @@ int tsdf_host_gn_step(double rot[9], double trans[3], const double A[36], const 
 /* GPU time measured with HIP events recorded on the handle's own stream around each kernel launch,
  * summed since the last reset.  Off by default.  tsdf_set_timing(h, mask): bit 0 = integrate + pack
  * launches (events are read back lazily, no extra synchronisation); bit 1 = every tracker pass (the stop
- * event of each pass must complete before the host continues, which costs a few microseconds per pass). */
+ * event of each pass must complete before the host continues, which costs a few microseconds per pass);
+ * bits 8..15 = sampling period n for the integrate / pack events (0 or 1: every launch; n: every n-th launch of a
+ * kind is bracketed -- an event pair per launch costs a 512^3 frame loop about 6 % of its rate). */
 typedef struct tsdf_timing {
     double  integrate_ms;       /* integrate_kernel only                                              */
     int64_t integrate_launches;

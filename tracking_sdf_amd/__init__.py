@@ -469,11 +469,11 @@ class SDF:
         return a
 
     # -- measurement
-    def set_timing(self, on=True, track=None):
-        """HIP-event timing: integrate/pack launches when ``on``; tracker passes too when ``track``
-        (default: same as ``on``; per-pass events cost a few microseconds each)."""
+    def set_timing(self, on=True, track=None, period=1):
+        """HIP-event timing: integrate/pack launches when ``on`` (every ``period``-th launch of a kind); tracker
+        passes too when ``track`` (default: same as ``on``; per-pass events cost a few microseconds each)."""
         track = on if track is None else track
-        self._check(lib().tsdf_set_timing(self._h, (1 if on else 0) | (2 if track else 0)))
+        self._check(lib().tsdf_set_timing(self._h, (1 if on else 0) | (2 if track else 0) | ((int(period) & 0xFF) << 8)))
 
     def read_timing(self, reset=False):
         t = Timing()
