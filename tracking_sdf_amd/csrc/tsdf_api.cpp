@@ -79,6 +79,8 @@ struct tsdf_handle {
     hipEvent_t ev_frame = nullptr;
     hipEvent_t ev_buf_used[2] = {nullptr, nullptr};
     bool used_valid[2] = {false, false};
+    bool used_untracked[2] = {false, false};   // read by an integration that recorded no event
+    bool frame_side = false;                   // the current frame was packed on the frame stream
     float4* pn_buf[2] = {nullptr, nullptr};
     float4* samples_buf[2] = {nullptr, nullptr};
     int fidx = 0;
@@ -188,6 +190,7 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
         HIP_TRY(h, hipStreamSynchronize(h->fstream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->used_valid[0] = h->used_valid[1] = false;
+        h->used_untracked[0] = h->used_untracked[1] = false;
     }
     if (npix > h->pn_cap) {
         for (int b = 0; b < 2; ++b) { if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]); h->pn_buf[b] = nullptr; }
@@ -288,7 +291,18 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
     const bool side = st != h->stream;
-    if (side && h->used_valid[nb]) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
+    if (side) {
+        if (h->used_valid[nb]) {
+            HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
+        } else if (h->used_untracked[nb]) {
+            // the buffer was last read by an integration that recorded no event (device-resident frames do not pay
+            // for one): order behind everything queued on the main stream, once
+            HIP_TRY(h, hipEventRecord(h->ev_buf_used[nb], h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
+        }
+        h->used_untracked[nb] = false;
+    }
+    h->frame_side = side;
     EventPair* ep;
     int rc = timed_begin(h, 1, &ep, st);
     if (rc) return rc;
@@ -850,8 +864,13 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
                                 h->rowbase, h->integrate_blocks, h->integrate_launches++));
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev_buf_used[h->fidx], h->stream));     // the next-but-one pack may overwrite this buffer after this
-    h->used_valid[h->fidx] = true;
+    if (h->frame_side) {     // the next-but-one pack (on the frame stream) may overwrite this buffer after this launch
+        HIP_TRY(h, hipEventRecord(h->ev_buf_used[h->fidx], h->stream));
+        h->used_valid[h->fidx] = true;
+    } else {                 // frames packed on the main stream are ordered by the stream itself: no event per frame
+        h->used_valid[h->fidx] = false;
+        h->used_untracked[h->fidx] = true;
+    }
     h->cnt.integrate_calls++;
     h->cnt.n_voxels_swept += h->n_stored;
     if (stats) {
