@@ -110,3 +110,25 @@ def test_large_delta_uses_library_exp():
     """delta - epsilon > 0.35 m switches the weight from the Taylor path to exp(): still matches the oracle."""
     vol = dict(width=6.0, height=6.0, depth=3.5, origin=(-3.0, -3.0, -0.5), delta=1.2, epsilon=0.05)
     compare_update_and_accumulate(48, 120, 90, vol)
+
+
+def test_many_handles_are_created_and_released_cleanly():
+    """Create / use / destroy in a loop: device memory comes back (no leak in the handle's many lazily grown buffers)."""
+    import torch
+    seq, (xyz, nrm, rgb) = render(96, 72)
+    free0 = None
+    for it in range(12):
+        go, gt = make_gpu(40 + (it % 3) * 8, seq.K)
+        go.update(gt, xyz, nrm, rgb)
+        go.set_frame(xyz)
+        gt.accumulate()
+        go.mesh(with_color=True)
+        go.set_depth_frame((np.nan_to_num(xyz[..., 2]) * 5000).astype(np.uint16), rgb, radius=3)
+        go.update()
+        go.close()
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        if it == 2:
+            free0 = free
+        if it > 2:
+            assert free >= free0 - (64 << 20), (it, free0, free)      # allocator granularity, not growth
