@@ -53,8 +53,8 @@ typedef enum tsdf_status {
     TSDF_E_HIP = -3,           /* a HIP runtime call failed (message in tsdf_last_error)                */
     TSDF_E_NO_INTRINSICS = -4, /* tsdf_integrate before tsdf_set_intrinsics (reference: exit(0), sdf.cpp:227-230) */
     TSDF_E_NO_FRAME = -5,      /* hot call before tsdf_set_frame / tsdf_set_frame_device                */
-    TSDF_E_SINGULAR = -6,      /* normal matrix singular / pose not finite (reference: silent NaN pose, camera_tracking.cpp:191); pose left unchanged */
-    TSDF_E_NO_SAMPLES = -7,    /* no valid tracking sample in the frame; pose left unchanged            */
+    TSDF_E_SINGULAR = -6,      /* normal matrix singular / pose not finite (reference: silent NaN pose, camera_tracking.cpp:191) */
+    TSDF_E_NO_SAMPLES = -7,    /* no valid tracking sample in the frame                                 */
     TSDF_E_HALO = -8,          /* a tracking look-up left this rank's slab+halo: halo too small         */
     TSDF_E_COMM = -9,          /* RCCL / all-reduce hook failure                                        */
     TSDF_E_NOMEM = -10
@@ -158,7 +158,9 @@ int tsdf_get_preprocessed(tsdf_handle *h, float *xyz, float *nrm);
 
 /* ---- the hot path ------------------------------------------------------------------------- */
 int tsdf_integrate(tsdf_handle *h, tsdf_integrate_stats *stats);  /* SDF::update at the current pose */
-int tsdf_track(tsdf_handle *h, tsdf_track_stats *stats);          /* estimate_new_position: updates the pose */
+/* estimate_new_position: updates the pose.  On ANY error (also one raised by a later Gauss-Newton pass, after earlier
+ * passes have moved the pose) the handle's pose is the one it had when the call was made. */
+int tsdf_track(tsdf_handle *h, tsdf_track_stats *stats);
 /* The two hot calls of kinect_callback back to back (sdf_reconstruction.cpp:69-74): track when do_track != 0 (every
  * frame but the first), then integrate at the resulting pose.  One ABI crossing instead of two: the integration is
  * launched the moment the last Gauss-Newton pass is solved.  A tracking error is returned and nothing is integrated. */
@@ -179,14 +181,19 @@ int tsdf_upload(tsdf_handle *h, const float *D, const float *W);
 int tsdf_download_color(tsdf_handle *h, float *Color_W, float *R, float *G, float *B);
 int tsdf_upload_color(tsdf_handle *h, const float *Color_W, const float *R, const float *G, const float *B);
 /* Re-integrate nothing, just make halo layers consistent after tsdf_upload on a sharded volume:
- * uploads D/W for the halo layers too (arrays cover [max(0,x0-halo), min(m,x1+halo)) ). */
+ * uploads D/W (colour) for the halo layers too (arrays cover [max(0,x0-halo), min(m,x1+halo)) ). */
 int tsdf_upload_with_halo(tsdf_handle *h, const float *D, const float *W);
+int tsdf_upload_color_with_halo(tsdf_handle *h, const float *Color_W, const float *R, const float *G, const float *B);
 int tsdf_reset(tsdf_handle *h);                                   /* back to the constructor state */
 /* Volume checkpoint (the reference keeps the volume only in RAM, sdf.cpp:52-54).
- * File = 72-byte little-endian header {"TSDFVOL1", int32 m, x0, x1, has_color, float width, height, depth,
- * delta, epsilon, int32 pad, double origin[3]} followed by the owned slab's D, W (and Color_W, R, G, B) float arrays in
- * reference index order.  tsdf_load checks the header against the handle (same m, slab, colour) and also
- * restores nothing but the voxel state: pose and intrinsics stay with the caller. */
+ * File = 80-byte little-endian header {"TSDFVOL2", int32 m, x0, x1, has_color, float width, height, depth, delta,
+ * epsilon, int32 xs, double origin[3], int32 xe, int32 reserved} followed by D, W (and Color_W, R, G, B) float arrays
+ * of the x layers [xs, xe) = the writer's slab AND its halo, in reference index order.
+ * tsdf_load restores every layer the handle stores (slab + halo) from a file that covers them -- the same shard's
+ * file, or the file of a whole (unsharded) volume -- so the halo layers of a restored shard are again bit-identical
+ * to the neighbour's interior.  It refuses (TSDF_E_BADARG) a file written for another m / extent / origin / delta /
+ * epsilon / colour setting and (TSDF_E_HALO) one that does not cover the stored layers.  Only the voxel state is
+ * restored: pose and intrinsics stay with the caller. */
 int tsdf_save(tsdf_handle *h, const char *path);
 int tsdf_load(tsdf_handle *h, const char *path);
 
@@ -218,10 +225,12 @@ int32_t tsdf_halo_for(const tsdf_config *cfg, float max_range);
  * (torch.distributed / MPI / a file), every rank calls tsdf_comm_init. */
 int tsdf_comm_unique_id(void *id128);
 int tsdf_comm_init(tsdf_handle *h, int32_t nranks, int32_t rank, const void *id128);
-/* Alternative for ranks on ONE node: every rank's final kernel writes its 34-double row + pass number into
- * its slot of a POSIX shared-memory segment (`name`, created on first use; pinned with hipHostRegister), and
- * every rank's host sums the slots in rank order.  No GPU collective, no stream synchronisation, bitwise
- * deterministic; costs one PCIe write per pass.  `name` must be unique per job (e.g. contain the master port). */
+/* Alternative for ranks on ONE node: every rank stores its 34-double row + {generation, pass number} into its slot of
+ * a POSIX shared-memory segment and every rank's host sums the slots in rank order.  No GPU collective, no stream
+ * synchronisation, bitwise deterministic.  The call is a rendezvous (bounded by 20 s): rank 0 replaces whatever
+ * carries `name`, creates and zero-fills the segment and picks a generation; the others attach and join; once all
+ * have joined rank 0 unlinks the name, so nothing is left behind in /dev/shm even if the job dies later.  `name`
+ * must be unique among jobs that initialise at the same time (e.g. contain the master port). */
 int tsdf_comm_init_shm(tsdf_handle *h, int32_t nranks, int32_t rank, const char *name);
 int tsdf_comm_finalize(tsdf_handle *h);                          /* drop the RCCL communicator (hook, if any, takes over) */
 /* Alternative: let the host do the 28-double sum (e.g. torch.distributed); fn = NULL removes it. */

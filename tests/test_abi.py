@@ -124,3 +124,25 @@ def test_host_gn_step_matches_oracle_bit_for_bit():
     # signed stop rule (camera_tracking.cpp:216-224)
     assert ts.host_gn_step(np.eye(3), np.zeros(3), np.eye(6), -np.ones(6))[3] is True
     assert ts.host_gn_step(np.eye(3), np.zeros(3), np.eye(6), np.array([0, 0, 0, 0, 0, 0.002]))[3] is False
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """A box where librccl cannot be loaded: tsdf_comm_unique_id must return TSDF_E_COMM with the loader's
+    message (the first version called dlerror() twice and built a std::string from NULL)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import tracking_sdf_amd as ts\n"
+        "L = ts.lib(); buf = C.create_string_buffer(128)\n"
+        "rc = L.tsdf_comm_unique_id(buf)\n"
+        "rc2 = L.tsdf_comm_unique_id(buf)\n"
+        "print(rc, rc2, L.tsdf_last_error(None).decode())\n"
+    )
+    env = dict(os.environ, TSDF_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rc, rc2, msg = r.stdout.strip().split(" ", 2)
+    assert int(rc) == ts.E_COMM and int(rc2) == ts.E_COMM
+    assert "cannot load librccl" in msg and "nonexistent" in msg

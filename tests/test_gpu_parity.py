@@ -16,7 +16,7 @@ import pytest
 
 import oracle as orc
 from tracking_sdf_amd import synth
-from util import make_gpu, make_oracle, scaled_K, sym_rel_err, ulp_diff
+from util import VOL, make_gpu, make_oracle, scaled_K, sym_rel_err, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -313,6 +313,46 @@ def test_error_paths_leave_pose_untouched():
         go.update()
 
 
+@pytest.mark.parametrize("fault,code", [("no_samples", "E_NO_SAMPLES"), ("singular", "E_SINGULAR"), ("comm", "E_COMM"),
+                                        ("halo", "E_HALO")])
+def test_failure_in_a_later_pass_restores_the_entry_pose(fault, code):
+    """tsdf.h: 'pose left unchanged' must also hold when pass g > 0 fails, after passes 0..g-1 moved the pose.
+    The per-pass all-reduce hook injects the failure at the second pass (first pass solved and applied)."""
+    import tracking_sdf_amd as ts
+    m = 64
+    seq, fr, oo, ot, go, gt = _fused_pair(m, noise=True)
+    xyz = fr[3][0]
+    gt.set_camera_transformation(seq.R[2], seq.t[2])
+    rot0, trans0 = gt.rot.copy(), gt.trans.copy()
+    st = gt.estimate_new_position(go, xyz)
+    assert st["iterations"] >= 2                           # otherwise the fault below would never be reached
+    assert not np.array_equal(gt.trans, trans0)
+    gt.set_camera_transformation(seq.R[2], seq.t[2])
+    calls = []
+
+    def hook(arr):
+        calls.append(1)
+        if len(calls) < 2:
+            return
+        if fault == "no_samples":
+            arr[:] = 0.0                                   # n_terms (entry 27) = 0
+        elif fault == "singular":
+            arr[:21] = 0.0                                 # A = 0, terms > 0
+        elif fault == "halo":
+            arr[28] = 3.0                                  # look-ups outside the stored layers, summed over ranks
+        else:
+            raise RuntimeError("collective failed")
+    go.set_allreduce_hook(hook)
+    with pytest.raises(ts.TsdfError) as ei:
+        gt.estimate_new_position(go, xyz)
+    assert ei.value.code == getattr(ts, code)
+    assert len(calls) == 2
+    assert np.array_equal(gt.rot, rot0) and np.array_equal(gt.trans, trans0)
+    go.set_allreduce_hook(None)
+    st2 = gt.estimate_new_position(go, xyz)                # and the handle is still usable: same result as before
+    assert st2["iterations"] == st["iterations"]
+
+
 def test_download_upload_roundtrip_and_reset():
     import tracking_sdf_amd as ts
     m = 32
@@ -421,7 +461,7 @@ def test_checkpoint_roundtrip(tmp_path):
     go.save(path)
     D, W = go.download()
     col = go.download_color()
-    assert os.path.getsize(path) == 72 + 6 * 4 * m ** 3
+    assert os.path.getsize(path) == 80 + 6 * 4 * m ** 3
     go2, gt2 = make_gpu(m, seq.K)
     go2.load(path)
     D2, W2 = go2.download()
@@ -438,6 +478,64 @@ def test_checkpoint_roundtrip(tmp_path):
         go3.load(path)
     with pytest.raises(ts.TsdfError):
         go2.load(str(tmp_path / "missing.tsdf"))
+
+
+def test_sharded_checkpoint_restores_halo_and_tracks_like_the_whole(tmp_path):
+    """A shard restored from a checkpoint must hold its halo layers too (they are the neighbour's interior), so that
+    its tracker partial sums add up to the whole volume's -- from the shard's own file and from a whole-volume file;
+    a file that does not cover the stored layers, or was written for another geometry, is refused."""
+    import tracking_sdf_amd as ts
+    m, halo = 48, 6
+    seq, fr = frames(4)
+    whole, wt = make_gpu(m, seq.K)
+    shards = [make_gpu(m, seq.K, slab=ts.slab_range(m, 2, r), halo=halo) for r in range(2)]
+    for k in range(3):                                     # the same frames into the whole volume and both shards
+        for s_, t_ in [(whole, wt)] + shards:
+            t_.set_camera_transformation(seq.R[k], seq.t[k])
+            s_.update(t_, *fr[k])
+    wpath = str(tmp_path / "whole.tsdf")
+    whole.save(wpath)
+    wt.set_camera_transformation(seq.R[2], seq.t[2])
+    whole.set_frame(fr[3][0])
+    A, b, st = wt.accumulate()
+    for source in ("own", "whole"):
+        As, bs, terms = 0.0, 0.0, 0
+        for r, (s_, t_) in enumerate(shards):
+            path = wpath if source == "whole" else str(tmp_path / f"shard{r}.tsdf")
+            if source == "own":
+                s_.save(path)
+                x0, x1 = ts.slab_range(m, 2, r)
+                xs, xe = max(0, x0 - halo), min(m, x1 + halo)
+                assert os.path.getsize(path) == 80 + 6 * 4 * (xe - xs) * m * m      # slab AND halo
+            fresh, ft = make_gpu(m, seq.K, slab=ts.slab_range(m, 2, r), halo=halo)
+            fresh.load(path)
+            assert all(np.array_equal(a_, b_) for a_, b_ in zip(fresh.download(), s_.download()))
+            assert all(np.array_equal(a_, b_) for a_, b_ in zip(fresh.download_color(), s_.download_color()))
+            ft.set_camera_transformation(seq.R[2], seq.t[2])
+            fresh.set_frame(fr[3][0])
+            Ar, br, sr = ft.accumulate()                  # would raise E_HALO or give other sums with a stale halo
+            As, bs, terms = As + Ar, bs + br, terms + sr["n_terms"]
+            # the halo layers came back as well: one more frame keeps the shard identical to the never-saved one
+            ft.set_camera_transformation(seq.R[3], seq.t[3]); t_.set_camera_transformation(seq.R[3], seq.t[3])
+            fresh.update(ft, *fr[3])
+            probe, pt = make_gpu(m, seq.K, slab=ts.slab_range(m, 2, r), halo=halo)
+            probe.load(path)
+            pt.set_camera_transformation(seq.R[3], seq.t[3])
+            probe.update(pt, *fr[3])
+            assert all(np.array_equal(a_, b_) for a_, b_ in zip(fresh.download(), probe.download()))
+        assert terms == st["n_terms"]
+        assert sym_rel_err(As, A) < 1e-12 and sym_rel_err(bs, b) < 1e-12
+    # shard 0's file does not cover shard 1's layers
+    other, _ = make_gpu(m, seq.K, slab=ts.slab_range(m, 2, 1), halo=halo)
+    with pytest.raises(ts.TsdfError) as ei:
+        other.load(str(tmp_path / "shard0.tsdf"))
+    assert ei.value.code == ts.E_HALO
+    # same m, other truncation distance: the stored distances would mean something else
+    vol2 = dict(VOL, delta=0.2)
+    alien, _ = make_gpu(m, seq.K, vol=vol2)
+    with pytest.raises(ts.TsdfError) as ei:
+        alien.load(wpath)
+    assert ei.value.code == ts.E_BADARG
 
 
 def test_track_and_integrate_equals_the_two_calls():

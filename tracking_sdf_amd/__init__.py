@@ -88,7 +88,7 @@ ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_set_frame_device", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
-    "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
+    "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
@@ -151,6 +151,7 @@ def lib():
         "tsdf_download_color": (C.c_int, [H, fp, fp, fp, fp]),
         "tsdf_upload_color": (C.c_int, [H, fp, fp, fp, fp]),
         "tsdf_upload_with_halo": (C.c_int, [H, fp, fp]),
+        "tsdf_upload_color_with_halo": (C.c_int, [H, fp, fp, fp, fp]),
         "tsdf_reset": (C.c_int, [H]),
         "tsdf_save": (C.c_int, [H, C.c_char_p]),
         "tsdf_load": (C.c_int, [H, C.c_char_p]),
@@ -416,6 +417,15 @@ class SDF:
         W = np.ascontiguousarray(np.asarray(W_full, dtype=np.float32).reshape(m, m, m)[xs:xe]).reshape(-1)
         self._check(lib().tsdf_upload_with_halo(self._h, _fptr(D), _fptr(W)))
 
+    def upload_color_with_halo(self, Color_W_full, R_full, G_full, B_full):
+        """Colour counterpart of upload_with_halo (full-volume host arrays in, this rank's stored layers up)."""
+        m = self.m
+        xs = max(0, self.cfg.slab_x0 - self.cfg.halo)
+        xe = min(m, self.cfg.slab_x1 + self.cfg.halo)
+        arrs = [np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(m, m, m)[xs:xe]).reshape(-1)
+                for a in (Color_W_full, R_full, G_full, B_full)]
+        self._check(lib().tsdf_upload_color_with_halo(self._h, *[_fptr(a) for a in arrs]))
+
     def download_color(self):
         n = (self.cfg.slab_x1 - self.cfg.slab_x0) * self.m * self.m
         out = [np.empty(n, dtype=np.float32) for _ in range(4)]
@@ -430,10 +440,11 @@ class SDF:
         self._check(lib().tsdf_reset(self._h))
 
     def save(self, path):
-        """Write the owned slab's D, W (and colour) as a TSDFVOL1 checkpoint."""
+        """Write this handle's stored layers (slab + halo): D, W (and colour) as a TSDFVOL2 checkpoint."""
         self._check(lib().tsdf_save(self._h, str(path).encode()))
 
     def load(self, path):
+        """Restore the stored layers from a TSDFVOL2 file that covers them (this shard's own file, or a whole-volume one)."""
         self._check(lib().tsdf_load(self._h, str(path).encode()))
 
     # -- multi-GPU plumbing

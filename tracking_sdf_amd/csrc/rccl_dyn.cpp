@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -34,10 +35,23 @@ Api& api() {
     static std::once_flag once;
     std::call_once(once, [] {
         // Prefer an RCCL the process already holds (torch ships its own), then the system one.
+        // TSDF_RCCL_LIBRARY names the library outright (a deployment whose RCCL lives elsewhere; the test-suite points
+        // it at a file that does not exist to exercise the failure path).
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-        for (size_t i = 0; !a.lib && i < sizeof(names) / sizeof(names[0]); ++i) a.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-        if (!a.lib) { a.load_error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        const char* forced = std::getenv("TSDF_RCCL_LIBRARY");
+        std::string why = "?";
+        auto try_open = [&](const char* name, int flags) {
+            void* l = dlopen(name, flags);
+            if (!l) { const char* e = dlerror(); if (e) why = e; }    // dlerror() clears the message: read it ONCE
+            return l;
+        };
+        if (forced && *forced) {
+            a.lib = try_open(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+            for (size_t i = 0; !a.lib && i < sizeof(names) / sizeof(names[0]); ++i) a.lib = try_open(names[i], RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!a.lib) { a.load_error = "cannot load librccl: " + why; return; }
         a.get_unique_id = (GetUniqueIdFn)dlsym(a.lib, "ncclGetUniqueId");
         a.comm_init_rank = (CommInitRankFn)dlsym(a.lib, "ncclCommInitRank");
         a.all_reduce = (AllReduceFn)dlsym(a.lib, "ncclAllReduce");

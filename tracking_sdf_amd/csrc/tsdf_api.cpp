@@ -11,11 +11,13 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <ctime>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -102,12 +104,16 @@ struct tsdf_handle {
     // shared-memory fan-in (ranks of one node): nranks x 2 slots (double-buffered by pass parity)
     struct Shm {
         int nranks = 0, rank = 0;
-        char* base = nullptr;        // host mapping
+        char* base = nullptr;        // host mapping (header, then the slots)
         char* dev_base = nullptr;    // device-visible alias (hipHostRegister)
-        size_t bytes = 0;
+        size_t bytes = 0, header = 0;
+        unsigned long long gen = 0;  // generation of this segment (chosen by rank 0 at init), part of every published word
         std::string name;
         bool active() const { return base != nullptr; }
     } shm;
+
+    // tsdf_sample scratch (grown on demand, kept between calls)
+    double* sample_vox = nullptr; float* sample_val = nullptr; int32_t* sample_ok = nullptr; size_t sample_cap = 0;
 
     // mesh extraction (grown on demand, kept between calls)
     unsigned* mesh_row_count = nullptr; unsigned* mesh_row_offset = nullptr; size_t mesh_rows_cap = 0;
@@ -334,14 +340,33 @@ void fill_track_params(const tsdf_handle* h, TrackParams& p) {
 }
 
 constexpr size_t kVolumePadFront = 16;   // voxels of {0,0} padding in front of the volume (128 bytes)
-constexpr size_t kShmSlot = 512;   // bytes per (rank, parity) slot: 34 doubles + the pass-number word, padded
+constexpr size_t kShmSlot = 512;   // bytes per (rank, parity) slot: 34 doubles + the pass word, padded
+
+// Segment = header, then nranks x 2 slots.  Header words (8 bytes each): magic, generation, nranks, go, joined[nranks].
+constexpr unsigned long long kShmMagic = 0x5453444653484d31ull;   // "TSDFSHM1"
+enum { kShmHdrMagic = 0, kShmHdrGen = 1, kShmHdrRanks = 2, kShmHdrGo = 3, kShmHdrJoined = 4 };
+inline size_t shm_header_bytes(int nranks) {
+    return (((size_t)kShmHdrJoined + (size_t)nranks) * 8 + kShmSlot - 1) / kShmSlot * kShmSlot;
+}
+inline volatile unsigned long long* shm_hdr(char* base, int word) {
+    return reinterpret_cast<volatile unsigned long long*>(base) + word;
+}
+inline size_t shm_slot_offset(const tsdf_handle* h, int rank, unsigned long long seq) {
+    return h->shm.header + ((size_t)rank * 2 + (seq & 1ull)) * kShmSlot;
+}
+// what a rank publishes behind its row: generation and pass number, so that a word left behind by another
+// run (or another initialisation) can never be taken for this pass
+inline unsigned long long shm_word(const tsdf_handle* h, unsigned long long seq) {
+    return (h->shm.gen << 32) | (seq & 0xFFFFFFFFull);
+}
 
 void shm_close(tsdf_handle* h) {
     if (!h->shm.active()) return;
     (void)hipStreamSynchronize(h->stream);
     if (h->shm.dev_base) (void)hipHostUnregister(h->shm.base);
     munmap(h->shm.base, h->shm.bytes);
-    if (h->shm.rank == 0) shm_unlink(h->shm.name.c_str());
+    // the name was unlinked by rank 0 as soon as every rank had joined (tsdf_comm_init_shm): nothing to remove
+    // here, and by now the name may belong to somebody else
     h->shm.base = h->shm.dev_base = nullptr;
     h->shm.nranks = 0;
 }
@@ -353,13 +378,14 @@ void shm_close(tsdf_handle* h) {
 int shm_fan_in(tsdf_handle* h, unsigned long long seq, int n) {
     double sum[kRedWidth];
     for (int e = 0; e < kRedWidth; ++e) sum[e] = 0.0;
+    const unsigned long long want = shm_word(h, seq);
     const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < h->shm.nranks; ++r) {
-        const char* slot = h->shm.base + ((size_t)r * 2 + (seq & 1ull)) * kShmSlot;
+        const char* slot = h->shm.base + shm_slot_offset(h, r, seq);
         const volatile unsigned long long* word =
             reinterpret_cast<const volatile unsigned long long*>(slot + kRedWidth * sizeof(double));
         for (unsigned spins = 0;; ++spins) {
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) break;
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
                 return fail(h, TSDF_E_COMM, "shared-memory fan-in: rank %d did not publish pass %llu within 20 s", r, seq);
         }
@@ -381,7 +407,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     const unsigned long long seq = ++h->pass_seq;
     double* host_row = h->red_host;          // where the final kernel publishes this rank's row
     if (use_shm && h->shm.dev_base)
-        host_row = reinterpret_cast<double*>(h->shm.dev_base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot);
+        host_row = reinterpret_cast<double*>(h->shm.dev_base + shm_slot_offset(h, h->shm.rank, seq));
     // polling + no RCCL: the folded rows come to the host directly (one dependent launch fewer); with the
     // shared-memory fan-in the host then publishes this rank's row itself (a host-memory store instead of a
     // device write over PCIe)
@@ -389,8 +415,11 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     if (use_shm && !host_fold && !h->shm.dev_base)
         return fail(h, TSDF_E_COMM, "shared-memory fan-in without the host fold needs the segment registered with HIP, which failed");
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
+    // the word the device publishes behind its row: the pass number, or (device-published shared-memory slot) the
+    // generation-tagged word the other ranks wait for
+    const unsigned long long dev_word = (use_shm && !host_fold) ? shm_word(h, seq) : seq;
     HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
-                            use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, seq));
+                            use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, dev_word));
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
     if (use_rccl) {
         std::string cerr;
@@ -433,9 +462,9 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         track_unpack_row(tot, h->red_host);
         arrived = true;
         if (use_shm) {
-            char* slot = h->shm.base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot;
+            char* slot = h->shm.base + shm_slot_offset(h, h->shm.rank, seq);
             std::memcpy(slot, h->red_host, kRedWidth * sizeof(double));
-            __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), seq, __ATOMIC_RELEASE);
+            __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), shm_word(h, seq), __ATOMIC_RELEASE);
             int rc2 = shm_fan_in(h, seq, kRedAllreduce);
             if (rc2) return rc2;
         }
@@ -679,6 +708,9 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->work_count) (void)hipFree(h->work_count);
     if (h->rowbase) (void)hipFree(h->rowbase);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
+    if (h->sample_vox) (void)hipFree(h->sample_vox);
+    if (h->sample_val) (void)hipFree(h->sample_val);
+    if (h->sample_ok) (void)hipFree(h->sample_ok);
     if (h->mesh_row_count) (void)hipFree(h->mesh_row_count);
     if (h->mesh_row_offset) (void)hipFree(h->mesh_row_offset);
     if (h->mesh_group_sum) (void)hipFree(h->mesh_group_sum);
@@ -920,14 +952,23 @@ int tsdf_track(tsdf_handle* h, tsdf_track_stats* stats) {
     double A[36], b[6], twist[6] = {0, 0, 0, 0, 0, 0};
     int64_t n_terms = 0;
     h->cnt.track_calls++;
+    // The pose advances in place pass by pass (camera_tracking.cpp:237-239).  Whatever goes wrong in a later pass,
+    // the caller gets the pose it came in with: a half-converged pose is never left behind (tsdf.h: TSDF_E_SINGULAR /
+    // TSDF_E_NO_SAMPLES / TSDF_E_HALO / TSDF_E_COMM / TSDF_E_HIP "pose left unchanged").
+    const hm::Pose entry = h->pose;
     for (g = 0; g < h->cfg.gn_max_iter && !stop; ++g) {            // camera_tracking.cpp:79
         rc = accumulate_pass(h, true);
-        if (rc) return rc;
+        if (rc) { h->pose = entry; return rc; }
         n_terms = (int64_t)h->red_host[27];
-        if (n_terms == 0) return fail(h, TSDF_E_NO_SAMPLES, "no valid tracking sample (iteration %d); pose left unchanged", g);
+        if (n_terms == 0) {
+            h->pose = entry;
+            return fail(h, TSDF_E_NO_SAMPLES, "no valid tracking sample (iteration %d); pose left unchanged", g);
+        }
         unpack_normal_equations(h->red_host, A, b);
-        if (!hm::gn_step(h->pose, A, b, h->cfg.max_twist_diff, twist, &stop))
+        if (!hm::gn_step(h->pose, A, b, h->cfg.max_twist_diff, twist, &stop)) {
+            h->pose = entry;
             return fail(h, TSDF_E_SINGULAR, "normal equations singular at iteration %d; pose left unchanged", g);
+        }
     }
     if (stats) {
         stats->iterations = g;
@@ -951,16 +992,32 @@ int tsdf_sample(tsdf_handle* h, const double* vox, int32_t n, float* val, int32_
     if (rc) return rc;
     if (!vox || !val || !ok || n < 0) return fail(h, TSDF_E_BADARG, "tsdf_sample: bad argument");
     if (n == 0) return TSDF_OK;
-    double* dv = nullptr; float* dval = nullptr; int32_t* dok = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&dv, (size_t)n * 3 * sizeof(double)));
-    HIP_TRY(h, hipMalloc((void**)&dval, (size_t)n * sizeof(float)));
-    HIP_TRY(h, hipMalloc((void**)&dok, (size_t)n * sizeof(int32_t)));
-    hipError_t e = hipMemcpyAsync(dv, vox, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = launch_sample(h->stream, h->grid, h->dw, dv, n, dval, dok);
-    if (e == hipSuccess) e = hipMemcpyAsync(val, dval, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ok, dok, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    // Scratch kept in the handle and grown on demand: the reference's callers ask for one point at a time
+    // (SDF::interpolate_distance), and a hipMalloc/hipFree pair per call would synchronise the whole device,
+    // frame side stream included.
+    if ((size_t)n > h->sample_cap) {
+        if (h->sample_vox) (void)hipFree(h->sample_vox);
+        if (h->sample_val) (void)hipFree(h->sample_val);
+        if (h->sample_ok) (void)hipFree(h->sample_ok);
+        h->sample_vox = nullptr; h->sample_val = nullptr; h->sample_ok = nullptr; h->sample_cap = 0;
+        const size_t cap = (size_t)n < 256 ? 256 : (size_t)n;
+        if (hipMalloc((void**)&h->sample_vox, cap * 3 * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&h->sample_val, cap * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&h->sample_ok, cap * sizeof(int32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->sample_vox) (void)hipFree(h->sample_vox);
+            if (h->sample_val) (void)hipFree(h->sample_val);
+            if (h->sample_ok) (void)hipFree(h->sample_ok);
+            h->sample_vox = nullptr; h->sample_val = nullptr; h->sample_ok = nullptr;
+            return fail(h, TSDF_E_NOMEM, "tsdf_sample: scratch for %d points", n);
+        }
+        h->sample_cap = cap;
+    }
+    hipError_t e = hipMemcpyAsync(h->sample_vox, vox, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_sample(h->stream, h->grid, h->dw, h->sample_vox, n, h->sample_val, h->sample_ok);
+    if (e == hipSuccess) e = hipMemcpyAsync(val, h->sample_val, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ok, h->sample_ok, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(dv); (void)hipFree(dval); (void)hipFree(dok);
     if (e != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_sample: %s", hipGetErrorString(e));
     for (int32_t i = 0; i < n; ++i)
         if (ok[i] < 0) return fail(h, TSDF_E_HALO, "tsdf_sample: point %d reads outside the stored layers", i);
@@ -1155,44 +1212,64 @@ int tsdf_upload_color(tsdf_handle* h, const float* Color_W, const float* R, cons
     return volume_io(h, false, true, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
 }
 
+int tsdf_upload_color_with_halo(tsdf_handle* h, const float* Color_W, const float* R, const float* G, const float* B) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!h->crgb) return fail(h, TSDF_E_BADARG, "volume was created with with_color=0");
+    if (!Color_W || !R || !G || !B) return fail(h, TSDF_E_BADARG, "tsdf_upload_color_with_halo: null input");
+    float* host[4] = {const_cast<float*>(Color_W), const_cast<float*>(R), const_cast<float*>(G), const_cast<float*>(B)};
+    return volume_io(h, false, true, 0, h->n_stored, host);
+}
+
 // ---- checkpoint ----------------------------------------------------------------------------------------
 
 namespace {
-struct VolHeader {
+struct VolHeader {                 // TSDFVOL2, little-endian, 80 bytes
     char magic[8];
-    int32_t m, x0, x1, has_color;
+    int32_t m, x0, x1, has_color;  // x0, x1: the slab the writer owned (informative)
     float width, height, depth, delta, epsilon;
-    int32_t pad;
+    int32_t xs;                    // the file holds the x layers [xs, xe): the writer's slab AND its halo
     double origin[3];
+    int32_t xe, reserved;
 };
-static_assert(sizeof(VolHeader) == 72, "checkpoint header layout");
+static_assert(sizeof(VolHeader) == 80, "checkpoint header layout");
+
+bool read_plane(FILE* f, long long plane_floats, int plane, long long first, float* dst, size_t n) {
+    const long long off = (long long)sizeof(VolHeader) + ((long long)plane * plane_floats + first) * (long long)sizeof(float);
+    if (fseeko(f, (off_t)off, SEEK_SET) != 0) return false;
+    return std::fread(dst, sizeof(float), n, f) == n;
+}
 }  // namespace
 
 int tsdf_save(tsdf_handle* h, const char* path) {
     int rc = check_ready(h, false);
     if (rc) return rc;
     if (!path) return fail(h, TSDF_E_BADARG, "tsdf_save: null path");
-    const size_t n = (size_t)(h->grid.own_x1 - h->grid.own_x0) * h->grid.m * h->grid.m;
-    const int planes = h->crgb ? 6 : 2;
+    const size_t n = (size_t)h->n_stored;              // slab + halo: a restored shard needs its halo layers too
     std::vector<float> buf;
-    try { buf.resize(n * planes); } catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_save: out of host memory"); }
-    rc = tsdf_download(h, buf.data(), buf.data() + n);
-    if (rc) return rc;
-    if (h->crgb) {
-        rc = tsdf_download_color(h, buf.data() + 2 * n, buf.data() + 3 * n, buf.data() + 4 * n, buf.data() + 5 * n);
-        if (rc) return rc;
-    }
+    try { buf.resize(n * 4); } catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_save: out of host memory"); }
     VolHeader hd;
     std::memset(&hd, 0, sizeof hd);
-    std::memcpy(hd.magic, "TSDFVOL1", 8);
+    std::memcpy(hd.magic, "TSDFVOL2", 8);
     hd.m = h->grid.m; hd.x0 = h->grid.own_x0; hd.x1 = h->grid.own_x1; hd.has_color = h->crgb ? 1 : 0;
+    hd.xs = h->grid.xs; hd.xe = h->grid.xe;
     hd.width = h->cfg.width; hd.height = h->cfg.height; hd.depth = h->cfg.depth;
     hd.delta = h->cfg.delta; hd.epsilon = h->cfg.epsilon;
     std::memcpy(hd.origin, h->cfg.origin, sizeof hd.origin);
     FILE* f = std::fopen(path, "wb");
     if (!f) return fail(h, TSDF_E_BADARG, "tsdf_save: cannot open %s", path);
-    const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(buf.data(), sizeof(float), buf.size(), f) == buf.size();
-    std::fclose(f);
+    bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1;
+    float* host[4] = {buf.data(), buf.data() + n, buf.data() + 2 * n, buf.data() + 3 * n};
+    if (ok) {
+        rc = volume_io(h, true, false, 0, (int64_t)n, host);
+        ok = rc == TSDF_OK && std::fwrite(buf.data(), sizeof(float), 2 * n, f) == 2 * n;
+    }
+    if (ok && h->crgb) {
+        rc = volume_io(h, true, true, 0, (int64_t)n, host);
+        ok = rc == TSDF_OK && std::fwrite(buf.data(), sizeof(float), 4 * n, f) == 4 * n;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (rc) return rc;
     if (!ok) return fail(h, TSDF_E_BADARG, "tsdf_save: short write to %s", path);
     return TSDF_OK;
 }
@@ -1204,25 +1281,45 @@ int tsdf_load(tsdf_handle* h, const char* path) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(h, TSDF_E_BADARG, "tsdf_load: cannot open %s", path);
     VolHeader hd;
-    if (std::fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, "TSDFVOL1", 8) != 0) {
+    if (std::fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, "TSDFVOL2", 8) != 0) {
         std::fclose(f);
-        return fail(h, TSDF_E_BADARG, "tsdf_load: %s is not a TSDFVOL1 file", path);
+        return fail(h, TSDF_E_BADARG, "tsdf_load: %s is not a TSDFVOL2 file", path);
     }
-    if (hd.m != h->grid.m || hd.x0 != h->grid.own_x0 || hd.x1 != h->grid.own_x1 || (hd.has_color != 0) != (h->crgb != nullptr)) {
+    const Grid& g = h->grid;
+    if (hd.m != g.m || (hd.has_color != 0) != (h->crgb != nullptr)) {
         std::fclose(f);
-        return fail(h, TSDF_E_BADARG, "tsdf_load: file holds m=%d slab [%d,%d) colour=%d, handle has m=%d slab [%d,%d) colour=%d",
-                    hd.m, hd.x0, hd.x1, hd.has_color, h->grid.m, h->grid.own_x0, h->grid.own_x1, h->crgb ? 1 : 0);
+        return fail(h, TSDF_E_BADARG, "tsdf_load: file holds m=%d colour=%d, handle has m=%d colour=%d", hd.m, hd.has_color,
+                    g.m, h->crgb ? 1 : 0);
     }
-    const size_t n = (size_t)(h->grid.own_x1 - h->grid.own_x0) * h->grid.m * h->grid.m;
-    const int planes = h->crgb ? 6 : 2;
+    // the geometry the voxel values were fused under must be the handle's (a D value means nothing under another delta)
+    if (hd.width != h->cfg.width || hd.height != h->cfg.height || hd.depth != h->cfg.depth || hd.delta != h->cfg.delta ||
+        hd.epsilon != h->cfg.epsilon || std::memcmp(hd.origin, h->cfg.origin, sizeof hd.origin) != 0) {
+        std::fclose(f);
+        return fail(h, TSDF_E_BADARG, "tsdf_load: %s was written for another volume (extent %gx%gx%g, origin %g %g %g, delta %g, epsilon %g)",
+                    path, (double)hd.width, (double)hd.height, (double)hd.depth, hd.origin[0], hd.origin[1], hd.origin[2],
+                    (double)hd.delta, (double)hd.epsilon);
+    }
+    // every STORED layer of this handle (slab and halo) must come from the file: a halo left at its old contents
+    // would silently break the 'halo == neighbour's interior' invariant the sharded tracker relies on
+    if (hd.xs > g.xs || hd.xe < g.xe || hd.xs < 0 || hd.xe > hd.m) {
+        std::fclose(f);
+        return fail(h, TSDF_E_HALO, "tsdf_load: file holds x layers [%d,%d), this handle stores [%d,%d) (slab [%d,%d) + halo %d)",
+                    hd.xs, hd.xe, g.xs, g.xe, g.own_x0, g.own_x1, h->cfg.halo);
+    }
+    const size_t n = (size_t)h->n_stored;
+    const long long mm = (long long)g.m * g.m;
+    const long long plane_floats = (long long)(hd.xe - hd.xs) * mm, first = (long long)(g.xs - hd.xs) * mm;
     std::vector<float> buf;
-    try { buf.resize(n * planes); } catch (...) { std::fclose(f); return fail(h, TSDF_E_NOMEM, "tsdf_load: out of host memory"); }
-    const bool ok = std::fread(buf.data(), sizeof(float), buf.size(), f) == buf.size();
+    try { buf.resize(n * 4); } catch (...) { std::fclose(f); return fail(h, TSDF_E_NOMEM, "tsdf_load: out of host memory"); }
+    float* host[4] = {buf.data(), buf.data() + n, buf.data() + 2 * n, buf.data() + 3 * n};
+    bool ok = read_plane(f, plane_floats, 0, first, host[0], n) && read_plane(f, plane_floats, 1, first, host[1], n);
+    if (ok) rc = volume_io(h, false, false, 0, (int64_t)n, host);
+    if (ok && rc == TSDF_OK && h->crgb) {
+        for (int q = 0; q < 4 && ok; ++q) ok = read_plane(f, plane_floats, 2 + q, first, host[q], n);
+        if (ok) rc = volume_io(h, false, true, 0, (int64_t)n, host);
+    }
     std::fclose(f);
     if (!ok) return fail(h, TSDF_E_BADARG, "tsdf_load: %s is truncated", path);
-    rc = tsdf_upload(h, buf.data(), buf.data() + n);
-    if (rc) return rc;
-    if (h->crgb) rc = tsdf_upload_color(h, buf.data() + 2 * n, buf.data() + 3 * n, buf.data() + 4 * n, buf.data() + 5 * n);
     return rc;
 }
 
@@ -1244,29 +1341,108 @@ int tsdf_comm_init(tsdf_handle* h, int32_t nranks, int32_t rank, const void* id1
     return TSDF_OK;
 }
 
+// Rendezvous on the named segment without help from the caller (all waits bounded by 20 s):
+//   rank 0    removes whatever carries the name, creates the segment exclusively, zero-fills it, writes
+//             {generation, nranks}, then the magic; waits until every other rank has written the generation into its
+//             `joined` word; UNLINKS the name; then sets `go`.
+//   rank r>0  opens the name (retrying while it does not exist or is still short), waits for the magic, writes the
+//             generation it read into joined[r], waits for `go`; whenever the name turns out to designate another
+//             object than the one mapped (a leftover of a crashed run that rank 0 has meanwhile replaced) it starts over.
+// A segment whose `go` is set has no name any more, so a crashed run can never leave a segment behind that a later
+// run could mistake for its own; what a crashed initialisation leaves has no `go`.  Every published word also carries the generation.
 int tsdf_comm_init_shm(tsdf_handle* h, int32_t nranks, int32_t rank, const char* name) {
     int rc = check_ready(h, false);
     if (rc) return rc;
-    if (!name || nranks <= 0 || rank < 0 || rank >= nranks) return fail(h, TSDF_E_BADARG, "tsdf_comm_init_shm: bad argument");
+    if (!name || nranks <= 0 || nranks > 4096 || rank < 0 || rank >= nranks) return fail(h, TSDF_E_BADARG, "tsdf_comm_init_shm: bad argument");
     shm_close(h);
-    const size_t bytes = (size_t)nranks * 2 * kShmSlot;
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) return fail(h, TSDF_E_COMM, "shm_open(%s) failed", name);
-    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return fail(h, TSDF_E_COMM, "ftruncate(%s) failed", name); }
-    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return fail(h, TSDF_E_COMM, "mmap(%s) failed", name);
+    const size_t header = shm_header_bytes(nranks);
+    const size_t bytes = header + (size_t)nranks * 2 * kShmSlot;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto expired = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20); };
+    auto nap = [] { struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); };
+    char* base = nullptr;
+    unsigned long long gen = 0;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail(h, TSDF_E_COMM, "shm_open(%s, O_EXCL) failed: %s", name, std::strerror(errno));
+        if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return fail(h, TSDF_E_COMM, "ftruncate(%s) failed", name); }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { shm_unlink(name); return fail(h, TSDF_E_COMM, "mmap(%s) failed", name); }
+        base = (char*)m;
+        std::memset(base, 0, bytes);
+        gen = ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)getpid() << 17)) & 0xFFFFFFFFull;
+        if (gen == 0) gen = 1;
+        *shm_hdr(base, kShmHdrGen) = gen;
+        *shm_hdr(base, kShmHdrRanks) = (unsigned long long)nranks;
+        __atomic_store_n(shm_hdr(base, kShmHdrJoined + 0), gen, __ATOMIC_RELAXED);
+        __atomic_store_n(shm_hdr(base, kShmHdrMagic), kShmMagic, __ATOMIC_RELEASE);
+        for (int r = 1; r < nranks; ++r) {
+            while (__atomic_load_n(shm_hdr(base, kShmHdrJoined + r), __ATOMIC_ACQUIRE) != gen) {
+                if (expired()) {
+                    munmap(base, bytes); shm_unlink(name);
+                    return fail(h, TSDF_E_COMM, "tsdf_comm_init_shm(%s): rank %d did not join within 20 s", name, r);
+                }
+                nap();
+            }
+        }
+        shm_unlink(name);
+        __atomic_store_n(shm_hdr(base, kShmHdrGo), gen, __ATOMIC_RELEASE);
+    } else {
+        for (;;) {
+            if (expired()) return fail(h, TSDF_E_COMM, "tsdf_comm_init_shm(%s): rank 0's segment did not appear within 20 s", name);
+            const int fd = shm_open(name, O_RDWR, 0600);
+            if (fd < 0) { nap(); continue; }
+            struct stat st;
+            if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) { close(fd); nap(); continue; }
+            void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (m == MAP_FAILED) return fail(h, TSDF_E_COMM, "mmap(%s) failed", name);
+            base = (char*)m;
+            // does the name still designate the object we mapped?  (false once rank 0 has replaced a leftover)
+            auto replaced = [&] {
+                struct stat now;
+                const int f2 = shm_open(name, O_RDWR, 0600);
+                if (f2 < 0) return false;              // no name: rank 0 unlinked it after the last join, `go` follows
+                const bool other = fstat(f2, &now) == 0 && (now.st_ino != st.st_ino || now.st_dev != st.st_dev);
+                close(f2);
+                return other;
+            };
+            bool restart = false, joined = false;
+            for (unsigned spins = 0;; ++spins) {
+                if (!joined && __atomic_load_n(shm_hdr(base, kShmHdrMagic), __ATOMIC_ACQUIRE) == kShmMagic) {
+                    if (*shm_hdr(base, kShmHdrRanks) != (unsigned long long)nranks) {
+                        munmap(base, bytes);
+                        return fail(h, TSDF_E_COMM, "tsdf_comm_init_shm(%s): segment was made for another number of ranks", name);
+                    }
+                    gen = *shm_hdr(base, kShmHdrGen);
+                    __atomic_store_n(shm_hdr(base, kShmHdrJoined + rank), gen, __ATOMIC_RELEASE);
+                    joined = true;
+                }
+                if (joined && __atomic_load_n(shm_hdr(base, kShmHdrGo), __ATOMIC_ACQUIRE) == gen) break;
+                if ((spins & 15u) == 15u) {
+                    if (replaced()) { restart = true; break; }
+                    if (expired()) { munmap(base, bytes); return fail(h, TSDF_E_COMM, "tsdf_comm_init_shm(%s): no go from rank 0 within 20 s", name); }
+                }
+                nap();
+            }
+            if (!restart) break;
+            munmap(base, bytes);
+            base = nullptr;
+        }
+    }
     // The device alias is only needed when a rank's final kernel writes its slot itself (host fold off); with the
     // default host fold the segment is touched by hosts only, so a failed registration is not fatal.
-    hipError_t e = hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    hipError_t e = hipHostRegister(base, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
     void* dptr = nullptr;
     if (e == hipSuccess) {
-        e = hipHostGetDevicePointer(&dptr, m, 0);
-        if (e != hipSuccess) { (void)hipHostUnregister(m); dptr = nullptr; }
+        e = hipHostGetDevicePointer(&dptr, base, 0);
+        if (e != hipSuccess) { (void)hipHostUnregister(base); dptr = nullptr; }
     }
     if (e != hipSuccess) { (void)hipGetLastError(); dptr = nullptr; }
-    h->shm.nranks = nranks; h->shm.rank = rank; h->shm.base = (char*)m; h->shm.dev_base = (char*)dptr;
-    h->shm.bytes = bytes; h->shm.name = name;
+    h->shm.nranks = nranks; h->shm.rank = rank; h->shm.base = base; h->shm.dev_base = (char*)dptr;
+    h->shm.bytes = bytes; h->shm.header = header; h->shm.gen = gen; h->shm.name = name;
     h->pass_seq = 0;               // every rank counts passes from the same origin
     return TSDF_OK;
 }
@@ -1302,11 +1478,11 @@ int tsdf_allreduce(tsdf_handle* h, double* buf, int32_t n) {
     if (h->shm.active()) {
         // host buffer in, host buffer out: publish with a host store (what a tracker pass does after its host fold)
         const unsigned long long seq = ++h->pass_seq;
-        char* slot = h->shm.base + ((size_t)h->shm.rank * 2 + (seq & 1ull)) * kShmSlot;
+        char* slot = h->shm.base + shm_slot_offset(h, h->shm.rank, seq);
         double row[kRedWidth];
         for (int e = 0; e < kRedWidth; ++e) row[e] = e < n ? buf[e] : 0.0;
         std::memcpy(slot, row, sizeof row);
-        __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), seq, __ATOMIC_RELEASE);
+        __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), shm_word(h, seq), __ATOMIC_RELEASE);
         int rc2 = shm_fan_in(h, seq, n);
         if (rc2) return rc2;
         std::memcpy(buf, h->red_host, (size_t)n * sizeof(double));
