@@ -52,3 +52,9 @@ rmw_probe:
 	@mkdir -p $(ROOT)build
 	$(HIPCC) --offload-arch=gfx950 -O3 -o $(ROOT)build/rmw_probe $(ROOT)tools/rmw_probe.hip
 .PHONY: rmw_probe
+
+# known-byte kernels for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/pmc_calibrate.py); run on the GPU box
+pmc_calibrate:
+	@mkdir -p $(ROOT)build
+	$(HIPCC) --offload-arch=gfx950 -O3 -o $(ROOT)build/pmc_calibrate $(ROOT)tools/pmc_calibrate.hip
+.PHONY: pmc_calibrate

@@ -2,20 +2,33 @@
 """bench.py -- frames/sec + ATE-RMSE of the tracking_sdf hot path on MI355X.
 
 A "step" is one frame of the reference's per-frame hot path (sdf_reconstruction.cpp:69-74):
-CameraTracking::estimate_new_position (<= 20 Gauss-Newton passes) followed by SDF::update, on
-a 640x480 synthetic depth stream rendered along the real fr1/plant ground-truth camera path
-(no TUM image data exists on the box), against a 512^3 TSDF with the reference's default volume.
-All input frames are resident in HBM before the timed region starts.
+CameraTracking::estimate_new_position (<= 20 Gauss-Newton passes) followed by SDF::update, on a synthetic
+depth stream rendered along the real fr1/plant ground-truth camera path (no TUM image data exists on the box).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; the volume is sharded into N
-   x-slabs + halo, one 30-double RCCL all-reduce of the normal equations per Gauss-Newton pass.)
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
-Prints ONE JSON line on rank 0.
+  --gpus N > 1 without WORLD_SIZE in the environment: this process starts N rank processes itself (before
+  anything touches a GPU), relays rank 0's JSON line and exits non-zero if any rank fails.  Under
+  torch.distributed.run (WORLD_SIZE set) it is one rank.  One rank per GPU; the volume is sharded into N x-slabs +
+  halo, one 30-double all-reduce of the normal equations per Gauss-Newton pass (in-library RCCL by default).
+
+  --config  3 (default) the metric's workload: 512^3, 640x480, fixed volume -> strong scaling over N
+            2           256^3, 640x480
+            4           weak-scaling shape of "1024^3 on 8 GPUs": m = 1024 (N/8)^(1/3), 640x480
+            5           weak-scaling shape of "2048^3 on 8 GPUs": m = 2048 (N/8)^(1/3), 1280x960
+            (the x extent of a rank's slab shrinks as m grows, its voxel count stays m^3/N = const)
+
+`value` times the hot path with every frame already resident in HBM.  The N = 1 default run adds, outside that
+timed region: the PCIe-inclusive rates (`value_h2d_inclusive`: xyz + normals + rgb handed over as host buffers every
+frame, SURVEY 8d's end-to-end definition; `value_depth_input_inclusive`: raw depth + rgb, pre-processed on the GPU),
+the ATE over the whole 1246-frame sequence at 256^3 and at the benchmark m, the HBM traffic of the integrate launch
+from two rocprofv3 --pmc child passes, a config-5-shaped leg, and the CPU baseline.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,33 +40,103 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+WORKLOADS = {     # config -> (m at the reference GPU count, reference GPU count, width, height, label)
+    2: (256, 1, 640, 480, "config 2: fr1/plant path, 256^3, 640x480"),
+    3: (512, 1, 640, 480, "config 3 / metric: fr1/plant path, 512^3, 640x480"),
+    4: (1024, 8, 640, 480, "config 4 shape: 1024^3 on 8 GPUs, 640x480 (weak: m = 1024 (N/8)^(1/3))"),
+    5: (2048, 8, 1280, 960, "config 5 shape: 2048^3 on 8 GPUs, 1280x960 (weak: m = 2048 (N/8)^(1/3))"),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--voxels", dest="m", type=int, default=512, help="voxels per axis m (BASELINE metric: 512)")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(WORKLOADS))
+    ap.add_argument("--voxels", dest="m", type=int, default=None, help="voxels per axis (overrides the config's m)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--no-color", action="store_true", help="drop the colour lanes (sdf.cpp:294-304)")
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--frame-step", type=int, default=1, help="use every n-th 30 Hz pose")
     ap.add_argument("--max-range", type=float, default=6.0, help="metres; sizes the slab halo")
     ap.add_argument("--cpu-baseline-frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allreduce", choices=["auto", "rccl", "shm", "torch"], default="auto",
-                    help="auto = self-test and time in-library RCCL and the shared-memory fan-in, keep the faster (torch hook if both fail)")
-    ap.add_argument("--host-frames", action="store_true", help="hand frames over as HOST buffers every step (PCIe-inclusive rate; not the headline value)")
-    ap.add_argument("--depth-input", action="store_true", help="hand over raw uint16 depth + rgb as HOST buffers; back-projection, bilateral filter and normals run on the GPU (tsdf_set_depth_frame); PCIe-inclusive, not the headline value")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="main timed region only: no PCIe-inclusive legs, full-sequence ATE, PMC passes, weak leg")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes")
+    ap.add_argument("--no-full-sequence", action="store_true")
+    ap.add_argument("--no-weak-leg", action="store_true")
+    ap.add_argument("--allreduce", choices=["rccl", "auto", "shm", "torch"], default="rccl",
+                    help="exchange step of a Gauss-Newton pass: rccl = in-library RCCL all-reduce (falls back to the "
+                         "shared-memory fan-in only if RCCL fails its self-test); auto = self-test and time both, keep the faster")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--timing-period", type=int, default=4, help="HIP events around every n-th integrate/pack launch")
     ap.add_argument("--trajectory-out", default=None, help="write the estimated trajectory (TUM format)")
-    return ap.parse_args()
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# launcher: N rank processes, started before anything here touches a GPU (torch is not even imported)
+
+def launch_ranks(args):
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    rc = 0
+    out0 = ""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lines = [ln for ln in out0.splitlines() if ln.startswith('{"metric"')]
+    for ln in out0.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if rc == 0 and not lines:
+        print("[bench] rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------
 
 def horn_rmse(est, gt):
-    """ATE-RMSE after the rigid (rotation + translation) least-squares alignment of est onto gt."""
+    """ATE-RMSE after the rigid (proper rotation + translation) least-squares alignment of est onto gt.  Both
+    trajectories live in the reference's mirrored world (synth.load_trajectory re-bases the ground truth onto the
+    reference's det = -1 initial pose), so no reflection is needed here; tools/evaluate_ate.py has the
+    reflection-tolerant form for files in the TUM frame."""
     if len(est) < 3:
         return float(np.sqrt(np.mean(np.sum((est - gt) ** 2, axis=1))))
     ce, cg = est.mean(0), gt.mean(0)
@@ -83,15 +166,15 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(args, seq, frames):
+def cpu_baseline(args, K, frames, m, width, height):
     """The reference's CPU path (the oracle restatement: same loop structure, 24 B/voxel
     global_coords table, AoS clouds, OpenMP) timed on this box's host cores on a bounded sample."""
     import oracle as orc
     cores = usable_cores()
     n = max(1, min(args.cpu_baseline_frames, len(frames) - 1))
-    oo = orc.SDF(args.m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025, with_global_coords=True)
+    oo = orc.SDF(m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025, with_global_coords=True)
     ot = orc.CameraTracking(oo)
-    ot.set_K(seq.K)
+    ot.set_K(K)
     xyz, nrm, rgb = frames[0]
     oo.update(ot, orc.Cloud(xyz, nrm, rgb), with_color=not args.no_color, threads=cores)
     t_track = t_upd = 0.0
@@ -121,14 +204,63 @@ def cpu_baseline(args, seq, frames):
     except OSError:
         pass
     return {"value": done / total, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{done} frames (track + update) of the same {args.width}x{args.height} stream at "
-                      f"{args.m}^3 after 1 fused frame; OpenMP on all {cores} host threads",
+            "sample": f"{done} frames (track + update) of the same {width}x{height} stream at "
+                      f"{m}^3 after 1 fused frame; OpenMP on all {cores} host threads",
             "track_ms_per_frame": 1e3 * t_track / done, "update_ms_per_frame": 1e3 * t_upd / done,
             "cpu_model": model}
 
 
+def pmc_traffic(args, wl_args):
+    """HBM bytes of one integrate launch pair (clip_rows_kernel + integrate_kernel) of THIS workload, measured now:
+    two child runs of this script under rocprofv3, one --pmc counter each (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass; never combined with a trace domain), program directly after `--`.  Returns a dict or a reason string."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return "rocprofv3 not found"
+    res = {}
+    work = tempfile.mkdtemp(prefix="tsdf_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--steps", "12", "--warmup", "2"] + wl_args
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                return f"rocprofv3 --pmc {counter} pass timed out"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return f"rocprofv3 --pmc {counter} pass failed (rc {p.returncode}): {p.stderr[-300:]}"
+            acc = {}
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] != counter:
+                        continue
+                    name = r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
+                    a = acc.setdefault(name, [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(r["Counter_Value"]) * 1024.0          # rocprofv3 reports these two in KB
+            for name, (cnt, tot) in acc.items():
+                res.setdefault(name, {})[counter] = {"launches": cnt, "mean_bytes": tot / cnt}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return res
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run(args)
+
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,6 +275,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py --gpus {world}: only {ndev} GPU(s) visible (one rank per GPU; --dist-backend gloo "
+                         f"lets ranks share a GPU for testing)")
     dev_index = local_rank if args.dist_backend == "nccl" else local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -152,209 +287,336 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend="gloo")
+    cpu_or_dev = dev if args.dist_backend == "nccl" else "cpu"
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # ---- synthetic input (identical on every rank), uploaded to HBM before anything is timed
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=cpu_or_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # ---- workload
+    def resolve(config, m_override=None, w_override=None, h_override=None):
+        m_ref, n_ref, w, h, label = WORKLOADS[config]
+        m = m_ref if n_ref == 1 else int(round(m_ref * (world / n_ref) ** (1.0 / 3.0) / 2.0)) * 2
+        return (m_override or m), (w_override or w), (h_override or h), label, ("strong" if n_ref == 1 else "weak")
+    m, width, height, wl_label, scaling = resolve(args.config, args.m, args.width, args.height)
+    noise = not args.no_noise
+
+    def render_frames(w, h, n_frames, step=1):
+        """Synthetic input, identical on every rank, rendered on this rank's GPU and left there."""
+        seq = synth.Sequence(n_frames=n_frames, width=w, height=h, noise=noise, holes=0.02 if noise else 0.0, step=step)
+        if len(seq) < n_frames:
+            raise SystemExit(f"trajectory has only {len(seq)} poses, need {n_frames}")
+        fr = [seq.frame_torch(k, dev) for k in range(n_frames)]
+        torch.cuda.synchronize()
+        return seq, fr
+
+    import ctypes as C
+    L = ts.lib()
+    f_set, f_step, f_pose = L.tsdf_set_frame_device, L.tsdf_track_and_integrate, L.tsdf_get_pose
+    perf = time.perf_counter
+
+    class Leg:
+        """One volume (this rank's slab) + the frame loop of sdf_reconstruction.cpp:69-74 over a list of frames."""
+
+        def __init__(self, m, w, h, K):
+            self.m, self.w, self.h = m, w, h
+            x0, x1 = ts.slab_range(m, world, rank)
+            cfg0 = ts.default_config(m=m)
+            self.halo = ts.halo_for(cfg0, args.max_range) if world > 1 else 0
+            self.sdf = ts.SDF(m, with_color=not args.no_color, slab=(x0, x1), halo=self.halo, device=dev_index)
+            self.trk = ts.CameraTracking(sdf=self.sdf)
+            self.trk.set_K(K)
+            self.pose_t = np.zeros(3)
+            self.pose_ptr = self.pose_t.ctypes.data_as(C.POINTER(C.c_double))
+            self.track_wall = 0.0
+            self.est = []
+
+        def first_frame(self, fr, mode="device", host=None, depth16=None):
+            """frame 1: integrate only at the reference's initial pose (sdf_reconstruction.cpp:69)"""
+            self.est = []
+            self.feed(0, fr, mode, host, depth16)
+            self.sdf.update(want_stats=False)
+            self.est.append(self.trk.trans.copy())
+
+        def feed(self, k, fr, mode, host, depth16):
+            if mode == "device":
+                dx, dn, dc = fr[k]
+                self.sdf._check(f_set(self.sdf._h, C.c_void_p(dx.data_ptr()), C.c_void_p(dn.data_ptr()),
+                                      C.c_void_p(dc.data_ptr()), self.w, self.h))
+            elif mode == "host":
+                self.sdf.set_frame(*host[k])
+            else:
+                self.sdf.set_depth_frame(depth16[k], host[k][2])
+
+        def step(self, k, fr, mode="device", host=None, depth16=None, timed=False):
+            self.feed(k, fr, mode, host, depth16)
+            tq = perf()
+            rc = f_step(self.sdf._h, 1, None, None)        # estimate_new_position + update, sdf_reconstruction.cpp:70,74
+            if timed:
+                self.track_wall += perf() - tq
+            self.sdf._check(rc)
+            f_pose(self.sdf._h, None, self.pose_ptr, None, None)      # host-side pose read while the integration runs
+            self.est.append(self.pose_t.copy())
+
+        def timed_region(self, fr, mode="device", host=None, depth16=None, events=True):
+            """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+            self.first_frame(fr, mode, host, depth16)
+            for k in range(1, 1 + args.warmup):
+                self.step(k, fr, mode, host, depth16)
+            self.sdf.synchronize()
+            # HIP events (on the library's own stream) around every n-th integrate / pack launch of the timed region:
+            # an event pair around every launch costs the loop ~6 % of its rate; the tracker is wall-timed
+            self.sdf.set_timing(events, track=False, period=args.timing_period)
+            self.sdf.read_timing(reset=True)
+            self.sdf.read_counters(reset=True)
+            self.track_wall = 0.0
+            barrier()
+            torch.cuda.synchronize()
+            t0 = perf()
+            for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
+                self.step(k, fr, mode, host, depth16, True)
+            self.sdf.synchronize()
+            torch.cuda.synchronize()
+            barrier()
+            elapsed = max_over_ranks(perf() - t0)
+            tm, cn = self.sdf.read_timing(), self.sdf.read_counters()
+            self.sdf.set_timing(False)
+            return elapsed, tm, cn
+
+        def restart(self):
+            self.sdf.reset()                                 # constructor state: volume and the reference's initial pose
+
+        def close(self):
+            self.sdf.close()
+
     n_frames = 1 + args.warmup + args.steps
-    seq = synth.Sequence(n_frames=n_frames, width=args.width, height=args.height, noise=not args.no_noise,
-                         holes=0.0 if args.no_noise else 0.02, step=args.frame_step)
-    if len(seq) < n_frames:
-        raise SystemExit(f"trajectory has only {len(seq)} poses, need {n_frames}")
-    frames = [seq.frame(k) for k in range(n_frames)]
-    d_frames = [(torch.from_numpy(x).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev))
-                for x, n, c in frames]
-    depth16 = [np.where(np.isnan(x[..., 2]), 0, np.round(x[..., 2] * 5000.0)).astype(np.uint16) for x, _, _ in frames] \
-        if args.depth_input else None
-    torch.cuda.synchronize()
+    seq, d_frames = render_frames(width, height, n_frames, args.frame_step)
+    leg = Leg(m, width, height, seq.K)
+    sdf = leg.sdf
+    halo_main = leg.halo
 
-    # ---- volume: x-slab of this rank (+ halo), colour lanes as in the reference
-    x0, x1 = ts.slab_range(args.m, world, rank)
-    cfg0 = ts.default_config(m=args.m)
-    halo = ts.halo_for(cfg0, args.max_range) if world > 1 else 0
-    sdf = ts.SDF(args.m, with_color=not args.no_color, slab=(x0, x1), halo=halo, device=dev_index)
-    trk = ts.CameraTracking(sdf=sdf)
-    trk.set_K(seq.K)
-
+    # ---- exchange step of a Gauss-Newton pass (N > 1)
     allreduce_kind = "none"
     exchange_us = {}
-    if world > 1:
-        cpu_or_dev = dev if args.dist_backend == "nccl" else "cpu"
+    comm_state = {"kind": "none"}
 
-        def all_agree(flag):
-            t = torch.tensor([1 if flag else 0], device=cpu_or_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t.item())
+    def all_agree(flag):
+        t = torch.tensor([1 if flag else 0], device=cpu_or_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
-        def probe(n=40):
-            """Self-test + time of one exchange step (sum of 30 doubles over the ranks), microseconds."""
-            got = sdf.allreduce(np.full(30, float(rank + 1)))
-            good = bool(np.all(got == world * (world + 1) / 2))
+    def probe(s, n=40):
+        """Self-test + time of one exchange step (sum of 30 doubles over the ranks), microseconds."""
+        got = s.allreduce(np.full(30, float(rank + 1)))
+        good = bool(np.all(got == world * (world + 1) / 2))
+        dist.barrier()
+        t0 = perf()
+        for _ in range(n):
+            s.allreduce(np.ones(30))
+        return good, 1e6 * (perf() - t0) / n
+
+    def init_rccl(s):
+        buf = C.create_string_buffer(128)
+        if not all_agree(ts.lib().tsdf_comm_unique_id(buf) == 0):      # can every rank bind librccl at all?
+            return False
+        uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device=cpu_or_dev)
+        dist.broadcast(uid, 0)
+        try:
+            s.comm_init(world, rank, bytes(uid.cpu().tolist()))
+            good = True
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] rank {rank}: in-library RCCL failed ({e})", file=sys.stderr)
+            good = False
+        return all_agree(good)
+
+    shm_serial = [0]
+
+    def init_shm(s):
+        shm_serial[0] += 1
+        names = [f"/tsdf_{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}_{shm_serial[0]}"]
+        dist.broadcast_object_list(names, 0)
+        try:
+            s.comm_init_shm(world, rank, names[0])
+            good = True
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] rank {rank}: shared-memory fan-in failed ({e})", file=sys.stderr)
+            good = False
+        return all_agree(good)
+
+    def torch_hook(s):
+        scratch = torch.zeros(30, dtype=torch.float64, device=cpu_or_dev)
+
+        def hook(arr):
+            scratch.copy_(torch.from_numpy(arr))
+            dist.all_reduce(scratch)
+            arr[:] = scratch.cpu().numpy()
+        s.set_allreduce_hook(hook)
+
+    def setup_exchange(s, want):
+        """Returns the kind in use.  `want`: rccl | shm | torch (a mode that fails its self-test falls through
+        rccl -> shm -> torch, except when it was asked for by name on the command line)."""
+        s.comm_finalize()
+        s.set_allreduce_hook(None)
+        order = {"rccl": ["rccl", "shm"], "shm": ["shm"], "torch": []}[want]
+        if args.dist_backend != "nccl" and "rccl" in order:
+            order.remove("rccl")               # ranks may share a GPU under gloo: RCCL refuses that
+        for mode in order:
+            ok = init_rccl(s) if mode == "rccl" else init_shm(s)
+            if ok:
+                good, _ = probe(s, 4)
+                if all_agree(good):
+                    return {"rccl": "rccl-in-library", "shm": "shared-memory fan-in"}[mode]
+            s.comm_finalize()
             dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                sdf.allreduce(np.ones(30))
-            return good, 1e6 * (time.perf_counter() - t0) / n
+        torch_hook(s)
+        return "torch.distributed-hook"
 
-        def init_rccl():
-            import ctypes
-            buf = ctypes.create_string_buffer(128)
-            if not all_agree(ts.lib().tsdf_comm_unique_id(buf) == 0):      # can every rank bind librccl at all?
-                return False
-            uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device=cpu_or_dev)
-            dist.broadcast(uid, 0)
-            try:
-                sdf.comm_init(world, rank, bytes(uid.cpu().tolist()))
-                good = True
-            except Exception as e:      # noqa: BLE001
-                print(f"[bench] rank {rank}: in-library RCCL failed ({e})", file=sys.stderr)
-                good = False
-            return all_agree(good)
-
-        def init_shm():
-            names = [f"/tsdf_{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}"]
-            dist.broadcast_object_list(names, 0)
-            try:
-                sdf.comm_init_shm(world, rank, names[0])
-                good = True
-            except Exception as e:      # noqa: BLE001
-                print(f"[bench] rank {rank}: shared-memory fan-in failed ({e})", file=sys.stderr)
-                good = False
-            return all_agree(good)
-
-        want = args.allreduce
-        candidates = {"auto": ["rccl", "shm"], "rccl": ["rccl"], "shm": ["shm"], "torch": []}[want]
-        if args.dist_backend != "nccl" and "rccl" in candidates:
-            candidates.remove("rccl")          # ranks may share a GPU under gloo: RCCL refuses that
-        for mode in candidates:
-            if (init_rccl() if mode == "rccl" else init_shm()):
-                good, us = probe()
+    if world > 1:
+        # time both in-library exchange steps on this machine (reported either way)
+        for mode in ("rccl", "shm"):
+            if mode == "rccl" and args.dist_backend != "nccl":
+                continue
+            if (init_rccl(sdf) if mode == "rccl" else init_shm(sdf)):
+                good, us = probe(sdf)
                 if all_agree(good):
                     exchange_us[mode] = us
             sdf.comm_finalize()
             dist.barrier()
-        # every rank must take the same decision: use rank 0's timings
-        choice = [min(exchange_us, key=exchange_us.get) if exchange_us else "torch"]
-        dist.broadcast_object_list(choice, 0)
-        if choice[0] == "rccl" and init_rccl():
-            allreduce_kind = "rccl-in-library"
-        elif choice[0] == "shm" and init_shm():
-            allreduce_kind = "shared-memory fan-in"
-        else:
-            if want in ("rccl", "shm"):
-                raise SystemExit(f"--allreduce {want} requested but it failed its self-test")
-            sdf.comm_finalize()
-            scratch = torch.zeros(30, dtype=torch.float64, device=cpu_or_dev)
-
-            def hook(arr):
-                scratch.copy_(torch.from_numpy(arr))
-                dist.all_reduce(scratch)
-                arr[:] = scratch.cpu().numpy()
-            sdf.set_allreduce_hook(hook)
-            allreduce_kind = "torch.distributed-hook"
+        want = args.allreduce
+        if want == "auto":
+            choice = [min(exchange_us, key=exchange_us.get) if exchange_us else "torch"]
+            dist.broadcast_object_list(choice, 0)           # every rank must take the same decision: rank 0's timings
+            want = choice[0]
+        allreduce_kind = setup_exchange(sdf, want)
+        if args.allreduce == "shm" and not allreduce_kind.startswith("shared"):
+            raise SystemExit("--allreduce shm requested but it failed its self-test")
+        if args.allreduce == "rccl" and args.dist_backend == "nccl" and not allreduce_kind.startswith("rccl") and rank == 0:
+            print(f"[bench] in-library RCCL failed its self-test; exchange step = {allreduce_kind}", file=sys.stderr)
+        comm_state["kind"] = allreduce_kind
         dist.barrier()
 
-    track_wall = [0.0]
-    est = []
-    # The timed loop calls the three C-ABI entry points directly (pre-bound ctypes functions, pre-built pointer
-    # arguments): the Python wrappers' dict/array conversions sit between tsdf_track returning and the integrate
-    # launch, i.e. on the GPU's idle time.  Same calls, same error checks.
-    import ctypes as C
-    L = ts.lib()
-    f_set, f_step, f_pose = L.tsdf_set_frame_device, L.tsdf_track_and_integrate, L.tsdf_get_pose
-    handle = sdf._h
-    dev_args = None
-    if not (args.depth_input or args.host_frames):
-        dev_args = [(C.c_void_p(dx.data_ptr()), C.c_void_p(dn.data_ptr()), C.c_void_p(dc.data_ptr())) for dx, dn, dc in d_frames]
-    pose_t = np.zeros(3)
-    pose_t_ptr = pose_t.ctypes.data_as(C.POINTER(C.c_double))
-    perf = time.perf_counter
+    # ---- the timed region: frames resident in HBM
+    elapsed, tm, cn = leg.timed_region(d_frames)
+    est_main = np.array(leg.est)
+    track_wall_main = leg.track_wall
 
-    def step(k, timed=False):
-        if args.depth_input:
-            sdf.set_depth_frame(depth16[k], frames[k][2])
-        elif args.host_frames:
-            sdf.set_frame(*frames[k])
-        else:
-            a = dev_args[k]
-            sdf._check(f_set(handle, a[0], a[1], a[2], args.width, args.height))
-        tq = perf()
-        rc = f_step(handle, 1, None, None)                  # estimate_new_position + update, sdf_reconstruction.cpp:70,74
-        if timed:
-            track_wall[0] += perf() - tq
-        sdf._check(rc)
-        f_pose(handle, None, pose_t_ptr, None, None)        # host-side pose read while the integration runs
-        est.append(pose_t.copy())
+    if args.pmc_child:                       # child of pmc_traffic(): the launches above are all that is wanted
+        print(json.dumps({"pmc_child": True, "steps": args.steps}))
+        sdf.close()
+        return
 
-    # frame 0: integrate only at the reference's initial pose (sdf_reconstruction.cpp:69-74)
-    if args.depth_input:
-        sdf.set_depth_frame(depth16[0], frames[0][2])
-    else:
-        dx, dn, dc = d_frames[0]
-        sdf.set_frame_device(dx.data_ptr(), dn.data_ptr(), dc.data_ptr(), args.width, args.height)
-    sdf.update(want_stats=False)
-    est.append(trk.trans.copy())
-    for k in range(1, 1 + args.warmup):
-        step(k)
+    extras = {}
+    n1_extras = world == 1 and not args.no_extras
+    host_frames = None
+    if n1_extras or (world == 1 and not args.no_cpu_baseline):
+        host_frames = [(x.cpu().numpy(), n.cpu().numpy(), c.cpu().numpy()) for x, n, c in d_frames]
 
-    sdf.synchronize()
-    # HIP events around every 4th integrate / pack launch of the timed region (an event pair around every launch costs
-    # the loop ~6 % of its rate: measured 3800 vs 4050 frames/s); the tracker is wall-timed
-    sdf.set_timing(True, track=False, period=args.timing_period)
-    sdf.read_timing(reset=True)
-    sdf.read_counters(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(1 + args.warmup, n_frames):
-        step(k, True)
-    sdf.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    tm = sdf.read_timing()
-    cn = sdf.read_counters()
-    sdf.set_timing(False)
+    # ---- PCIe-inclusive rates (SURVEY 8d: H2D of the images + track + integrate), same frames, volume restarted
+    if n1_extras:
+        leg.restart()
+        e2, _, _ = leg.timed_region(d_frames, "host", host_frames, events=False)
+        extras["value_h2d_inclusive"] = args.steps / e2
+        extras["h2d_inclusive_note"] = ("xyz + normals + rgb (27 B/pixel) handed over as HOST buffers every frame through "
+                                        "tsdf_set_frame: staging copy + H2D + pack on the frame side stream, overlapping the "
+                                        "previous integration")
+        depth16 = [np.where(np.isnan(x[..., 2]), 0, np.round(x[..., 2] * 5000.0)).astype(np.uint16) for x, _, _ in host_frames]
+        leg.restart()
+        e3, _, _ = leg.timed_region(d_frames, "depth", host_frames, depth16, events=False)
+        extras["value_depth_input_inclusive"] = args.steps / e3
+        extras["depth_input_note"] = ("raw uint16 depth + rgb (5 B/pixel) as host buffers; back-projection, bilateral filter "
+                                      "and normals on the GPU (tsdf_set_depth_frame; PCL parity of that stage is unpinned)")
+        del depth16
+
+    # ---- N > 1: the same timed region with the other exchange step, for comparison
+    if world > 1 and not args.no_extras and args.dist_backend == "nccl" and allreduce_kind == "rccl-in-library" \
+            and "shm" in exchange_us:
+        kind2 = setup_exchange(sdf, "shm")
+        if kind2.startswith("shared"):
+            leg.restart()
+            e4, _, _ = leg.timed_region(d_frames, events=False)
+            extras["value_with_shared_memory_fan_in"] = args.steps / e4
+        allreduce_kind = setup_exchange(sdf, "rccl")
+        dist.barrier()
+
+    # ---- full fr1/plant sequence (1246 frames): ATE-RMSE and tracking failures at 256^3 and at the benchmark m
+    if n1_extras and not args.no_full_sequence and args.config in (2, 3) and args.frame_step == 1:
+        leg.close()
+        torch.cuda.empty_cache()
+        extras["full_sequence"] = full_sequence(ts, synth, torch, dev, dev_index, sorted({256, m}), width, height, noise,
+                                                not args.no_color)
+        extras["ate_full_sequence_m"] = extras["full_sequence"][str(m)]["ate_rmse_m"]
+        leg = None
+
+    # ---- a config-5-shaped leg (weak scaling: m = 2048 (N/8)^(1/3), 1280x960), a few frames
+    if not args.no_extras and not args.no_weak_leg and args.config == 3 and (world > 1 or n1_extras):
+        if leg is not None:
+            leg.close()
+            leg = None
+        del d_frames
+        d_frames = None
+        torch.cuda.empty_cache()
+        m5, w5, h5, label5, _ = resolve(5)
+        keep = (args.steps, args.warmup)
+        args.steps, args.warmup = min(keep[0], 12), min(keep[1], 2)
+        seq5, fr5 = render_frames(w5, h5, 1 + args.warmup + args.steps, 1)
+        leg5 = Leg(m5, w5, h5, seq5.K)
+        if world > 1:
+            setup_exchange(leg5.sdf, "rccl" if allreduce_kind.startswith("rccl") else ("shm" if allreduce_kind.startswith("shared") else "torch"))
+        e5, tm5, cn5 = leg5.timed_region(fr5)
+        l5 = max(1, cn5["integrate_calls"])
+        t5 = max(1, tm5["integrate_launches"])
+        ms5 = tm5["integrate_ms"] / t5
+        bpv = 16 if args.no_color else 48
+        upd5 = (cn5["n_updated"] + cn5["n_updated_halo"]) / l5
+        extras["weak_leg"] = {"workload": label5, "m": m5, "image": [w5, h5], "n_gpus": world, "scaling": "weak",
+                              "halo": leg5.halo, "steps": args.steps, "value": args.steps / e5, "unit": "frames/s",
+                              "ms_per_step": 1e3 * e5 / args.steps, "integrate_launch_ms_rank0": ms5,
+                              "updated_voxels_per_launch_rank0": upd5,
+                              "integrate_GBs_rank0": (bpv * upd5 + w5 * h5 * 32) / (ms5 * 1e-3) / 1e9 if ms5 > 0 else None,
+                              "gn_iterations_per_frame": cn5["track_iterations"] / max(1, cn5["track_calls"])}
+        args.steps, args.warmup = keep
+        leg5.close()
+        del fr5
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        est = np.array(est)
-        gt = seq.t[:len(est)]
-        ate = horn_rmse(est[1:], gt[1:])
-        raw = float(np.sqrt(np.mean(np.sum((est[1:] - gt[1:]) ** 2, axis=1))))
+        gt = seq.t[:len(est_main)]
+        ate = horn_rmse(est_main[1:], gt[1:])
+        raw = float(np.sqrt(np.mean(np.sum((est_main[1:] - gt[1:]) ** 2, axis=1))))
         bpv = 16 if args.no_color else 48
-        img_bytes = args.width * args.height * 32          # packed 32-byte pixel records read by the kernel
-        launches = max(1, cn["integrate_calls"])                 # all launches of the timed region (counters)
-        timed = max(1, tm["integrate_launches"])                 # the ones bracketed by HIP events (every n-th)
+        img_bytes = width * height * 32                            # packed 32-byte pixel records read by the kernel
+        launches = max(1, cn["integrate_calls"])                   # all launches of the timed region (counters)
+        timed = max(1, tm["integrate_launches"])                   # the ones bracketed by HIP events (every n-th)
         upd_per_launch = (cn["n_updated"] + cn["n_updated_halo"]) / launches
         alg_bytes = bpv * upd_per_launch + img_bytes
         avg_ms = tm["integrate_ms"] / timed
         pack_ms = tm["pack_ms"] / max(1, tm["pack_launches"])
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
-            "metric": f"frames/sec (track + integrate per frame), synthetic fr1/plant stream, {args.m}^3 TSDF",
+            "metric": f"frames/sec (track + integrate per frame), synthetic fr1/plant stream, {m}^3 TSDF",
             "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32/f64",
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32/f64",
             "dtype_note": "f32 voxel state and SDF samples, f64 geometry and normal equations (the reference's own mix)",
-            "data": "synthetic" + (" (frames handed over as host buffers: PCIe-inclusive)" if args.host_frames else "")
-                    + (" (raw uint16 depth + rgb handed over as host buffers, pre-processed on the GPU: PCIe-inclusive)" if args.depth_input else ""),
-            "config": {"workload": f"fr1/plant ground-truth camera path at 30 Hz (re-based to the reference's initial "
-                                   f"pose), analytic room+sphere+boxes scene, {args.width}x{args.height} depth with "
-                                   f"Kinect noise + 2% holes, {args.m}^3 voxels, 6x6x3.5 m volume, "
-                                   f"colour lanes {'off' if args.no_color else 'on'}; TUM fr1/plant images are not "
-                                   f"available on the box",
-                       "m": args.m, "image": [args.width, args.height], "parallelism": f"x-slab x{world}",
-                       "halo": halo, "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us},
-            "ate_rmse_m": ate, "abs_trajectory_rmse_m": raw,
+            "data": "synthetic (frames resident in HBM before the timed region)",
+            "config": {"workload": f"{wl_label}: fr1/plant ground-truth camera path at 30 Hz (re-based to the reference's "
+                                   f"initial pose), analytic scene (plant on a pedestal at the path's focus, room with "
+                                   f"pillars/domes/furniture), {width}x{height} depth with Kinect noise + 2% holes, "
+                                   f"{m}^3 voxels, 6x6x3.5 m volume, colour lanes {'off' if args.no_color else 'on'}; "
+                                   f"TUM images are not available on the box",
+                       "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}",
+                       "halo": halo_main,
+                       "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us},
+            "ate_rmse_m": ate, "ate_frames": len(est_main) - 1, "abs_trajectory_rmse_m": raw,
             "gn_iterations_per_frame": cn["track_iterations"] / max(1, cn["track_calls"]),
-            "stage_ms_per_frame": {"track_wall": 1e3 * track_wall[0] / args.steps,
+            "stage_ms_per_frame": {"track_wall": 1e3 * track_wall_main / args.steps,
                                    "integrate_launch": avg_ms, "pack_kernel": pack_ms},
             "roofline": {"kernel": "integrate (clip_rows_kernel + integrate_kernel, one launch pair per frame)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -367,42 +629,112 @@ def main():
             "tracker_gather": {"in_grid_samples_per_pass": cn["track_in_grid"] / max(1, cn["track_iterations"]),
                                "passes": cn["track_iterations"],
                                "avg_pass_wall_ms": max(0.0, 1e3 * elapsed - args.steps * (avg_ms + pack_ms)) / max(1, cn["track_iterations"]),
-                               "track_call_wall_ms_incl_wait_for_integrate": 1e3 * track_wall[0] / max(1, cn["track_iterations"]),
+                               "track_call_wall_ms_incl_wait_for_integrate": 1e3 * track_wall_main / max(1, cn["track_iterations"]),
                                "achieved_GBs_on_832B_per_sample": 832.0 * cn["track_in_grid"]
                                    / max(1e-9, 1e-3 * max(0.0, 1e3 * elapsed - args.steps * (avg_ms + pack_ms))) / 1e9},
         }
-        # HBM traffic of the integrate launch from the committed rocprofv3 --pmc passes (bench.py cannot collect
-        # PMC counters itself); only meaningful for the default workload
-        pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
-        if os.path.exists(pmc) and args.m == 512 and (args.width, args.height) == (640, 480) and not args.no_color \
-                and world == 1:
-            with open(pmc) as f:
-                out["roofline"]["traffic"] = json.load(f)["integrate_launch_traffic_bytes"]
-            out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        out.update(extras)
+        if leg is not None:
+            leg.close()
+            leg = None
         # measured ceiling for this access pattern (streaming 48 B/voxel RMW in 64-voxel items; tools/rmw_probe.hip)
-        probe = os.path.join(ROOT, "profiles", "r01_rmw_probe.json")
-        if os.path.exists(probe):
-            with open(probe) as f:
+        probe_f = os.path.join(ROOT, "profiles", "r01_rmw_probe.json")
+        if os.path.exists(probe_f):
+            with open(probe_f) as f:
                 pj = json.load(f)
             ceil_gbs = pj["item_granular_rows_rmw_GBs"] if not args.no_color else pj["float2_rmw_GBs"]
             out["roofline"]["measured_rmw_ceiling_GBs"] = ceil_gbs
             out["roofline"]["frac_of_measured_ceiling"] = achieved / ceil_gbs
             out["roofline"]["ceiling_source"] = "profiles/r01_rmw_probe.json (build/rmw_probe on MI355X)"
+        # HBM traffic of the integrate launch pair, measured now by two rocprofv3 --pmc child passes of this workload
+        if n1_extras and not args.no_pmc:
+            wl = ["--config", str(args.config), "--voxels", str(m), "--width", str(width), "--height", str(height),
+                  "--frame-step", str(args.frame_step), "--timing-period", str(args.timing_period)]
+            wl += (["--no-color"] if args.no_color else []) + (["--no-noise"] if args.no_noise else [])
+            torch.cuda.empty_cache()
+            got = pmc_traffic(args, wl)
+            if isinstance(got, dict):
+                def tot(prefix, counter):
+                    return sum(v.get(counter, {}).get("mean_bytes", 0.0) for k, v in got.items() if k.startswith(prefix))
+                fetch = tot("tsdf::integrate_kernel", "FETCH_SIZE") + tot("tsdf::clip_rows_kernel", "FETCH_SIZE")
+                write = tot("tsdf::integrate_kernel", "WRITE_SIZE") + tot("tsdf::clip_rows_kernel", "WRITE_SIZE")
+                out["roofline"]["traffic"] = fetch + write
+                out["roofline"]["traffic_detail"] = {
+                    "FETCH_SIZE_bytes": fetch, "WRITE_SIZE_bytes": write,
+                    "source": "two rocprofv3 --pmc child passes of this command's workload run by bench.py itself "
+                              "(one counter per pass, 12 timed steps), bytes per launch pair",
+                    "correction": PMC_CORRECTION_NOTE, "ratio_to_algorithmic": (fetch + write) / alg_bytes}
+            else:
+                out["roofline"]["traffic_detail"] = {"source": "unavailable: " + str(got)}
         if args.trajectory_out:
             with open(args.trajectory_out, "w") as f:
-                for k in range(1, len(est)):
-                    f.write("%.4f %.4f %.4f %.4f 0.0000 0.0000 0.0000 1.0000\n" % (seq.stamps[k], *est[k]))
+                for k in range(1, len(est_main)):
+                    f.write("%.4f %.4f %.4f %.4f 0.0000 0.0000 0.0000 1.0000\n" % (seq.stamps[k], *est_main[k]))
         if world == 1 and not args.no_cpu_baseline:
-            sdf.close()
-            del d_frames
+            d_frames = None
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args, seq, frames)
+            out["cpu_baseline"] = cpu_baseline(args, seq.K, host_frames, m, width, height)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+PMC_CORRECTION_NOTE = ("none applied; see profiles/r02_fetch_calibration.json for the calibration of FETCH_SIZE / WRITE_SIZE "
+                       "against known byte counts in this kernel's access widths")
+
+
+def full_sequence(ts, synth, torch, dev, dev_index, ms, width, height, noise, with_color):
+    """All 1246 frames of the fr1/plant path, rendered on the GPU one at a time and fed to one handle per m
+    (frame 1 integrate only, then track -> integrate, sdf_reconstruction.cpp:69-74).  A tracking error leaves the
+    pose where it was (tsdf_track's contract) and the frame is fused there, as tools/run_sequence.py does."""
+    import ctypes as C
+    seq = synth.Sequence(n_frames=None, width=width, height=height, noise=noise, holes=0.02 if noise else 0.0)
+    n = len(seq)
+    L = ts.lib()
+    runs = []
+    for m in ms:
+        s = ts.SDF(m, with_color=with_color, device=dev_index)
+        t = ts.CameraTracking(sdf=s)
+        t.set_K(seq.K)
+        runs.append({"m": m, "sdf": s, "trk": t, "est": np.zeros((n, 3)), "errors": 0, "first_error": None, "iters": 0})
+    pose = np.zeros(3)
+    pptr = pose.ctypes.data_as(C.POINTER(C.c_double))
+    t0 = time.perf_counter()
+    hot = 0.0
+    for k in range(n):
+        dx, dn, dc = seq.frame_torch(k, dev)
+        torch.cuda.current_stream().synchronize()          # the library's stream borrows finished buffers
+        th = time.perf_counter()
+        for r in runs:
+            s = r["sdf"]
+            s._check(L.tsdf_set_frame_device(s._h, C.c_void_p(dx.data_ptr()), C.c_void_p(dn.data_ptr()),
+                                             C.c_void_p(dc.data_ptr()), width, height))
+            if k > 0:
+                rc = L.tsdf_track(s._h, None)
+                if rc != 0:
+                    r["errors"] += 1
+                    if r["first_error"] is None:
+                        r["first_error"] = {"frame": k, "status": int(rc), "message": L.tsdf_last_error(s._h).decode()}
+            s._check(L.tsdf_integrate(s._h, None))
+            L.tsdf_get_pose(s._h, None, pptr, None, None)
+            r["est"][k] = pose
+        for r in runs:
+            r["sdf"].synchronize()                         # the frame's buffers are reused by the next render
+        hot += time.perf_counter() - th
+    wall = time.perf_counter() - t0
+    out = {"frames": n, "wall_s_incl_rendering": wall, "hot_path_s_all_volumes": hot}
+    for r in runs:
+        cn = r["sdf"].read_counters()
+        est = r["est"]
+        err = np.linalg.norm(est - seq.t, axis=1)
+        out[str(r["m"])] = {"ate_rmse_m": horn_rmse(est[1:], seq.t[1:]), "abs_trajectory_rmse_m": float(np.sqrt(np.mean(err[1:] ** 2))),
+                            "max_abs_error_m": float(err.max()), "track_errors": r["errors"], "first_error": r["first_error"],
+                            "gn_iterations_per_frame": cn["track_iterations"] / max(1, cn["track_calls"])}
+        r["sdf"].close()
+    return out
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--voxels", "128", "--width", "320", "--height", "240", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-          "--frame-step", "3"]
+          "--frame-step", "3", "--no-extras"]
 
 
 def run_bench(extra, nproc, traj, port, env=None):
@@ -40,6 +40,36 @@ def test_sharded_bench_reproduces_single_rank_trajectory(tmp_path, mode, nproc):
     assert t1.shape == tn.shape and np.array_equal(t1, tn)          # 4-decimal TUM lines, identical
     assert abs(jn["ate_rmse_m"] - j1["ate_rmse_m"]) < 1e-9
     assert jn["gn_iterations_per_frame"] == j1["gn_iterations_per_frame"]
+
+
+def test_gpus_flag_starts_that_many_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) must run TWO ranks: it used to read WORLD_SIZE
+    only and silently ran one.  gloo plumbing so that the two ranks may share this box's GPU."""
+    traj = str(tmp_path / "t2.txt")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--trajectory-out", traj] + COMMON
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "x-slab x2" and j["config"]["halo"] > 0
+    assert "shared-memory" in j["config"]["allreduce"] and "shm" in j["config"]["exchange_step_us_measured"]
+    j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
+    assert np.array_equal(np.loadtxt(traj), t1)
+
+
+def test_a_failing_rank_fails_the_launcher(tmp_path):
+    """RCCL plumbing needs one GPU per rank: with more ranks than GPUs the surplus rank refuses, and the launcher
+    must stop the others and exit non-zero without a result line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + COMMON
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "GPU(s) visible" in p.stderr and "stopping the other ranks" in p.stderr
 
 
 def test_device_published_rows_give_the_same_trajectory(tmp_path):

@@ -3,6 +3,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -52,3 +53,19 @@ def test_quaternion_of_pose_file_matches_scipy_for_proper_rotations():
         q = quat_from_rot(R)
         want = Rotation.from_matrix(R).as_quat()
         assert np.allclose(q, want, atol=1e-12) or np.allclose(q, -want, atol=1e-12)
+
+
+def test_bench_launcher_reports_a_failed_rank_without_a_gpu():
+    """bench.py --gpus 2 starts two rank processes itself; here (no GPU) both refuse to run, and the launcher must
+    come back non-zero with no result line instead of pretending a one-rank run."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
+    assert "no GPU visible" in p.stderr and "[bench] rank" in p.stderr
