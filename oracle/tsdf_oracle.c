@@ -3,7 +3,8 @@
  *
  * TEST INFRASTRUCTURE ONLY (see tsdf_oracle.h).  PARITY UNPINNED vs the real
  * reference binary (no reference golden vectors exist; reference unbuildable
- * here); pinned by hand-derived KATs and an independent NumPy restatement.
+ * here); pinned by hand-derived KATs and a second restatement in NumPy
+ * (oracle/np_oracle.py, cross-checked in tests/test_np_oracle.py).
  *
  * Build:  gcc -O2 -fopenmp -ffp-contract=off -fno-fast-math -shared -fPIC
  * (x86-64 SSE2: float expressions are evaluated in float, no FMA contraction,

@@ -10,8 +10,11 @@
  * compiled here (every hot-path translation unit pulls in ROS, PCL, Eigen and
  * boost, none of which exist in this image).  The restatement is therefore
  * pinned only by known-answer tests derived by hand from the cited reference
- * lines (tests/test_oracle_kat.py) and by an
- * independent NumPy restatement (oracle/np_oracle.py).
+ * lines (tests/test_oracle_kat.py) and by a
+ * second restatement in NumPy (oracle/np_oracle.py: written from the reference's
+ * lines, whole-array operations instead of these loops; tests/test_np_oracle.py
+ * and tools/make_golden.py require the two to agree bit for bit on volume,
+ * interpolation and normal equations, to 1e-11 on the tracked pose).
  *
  * Eigen evaluation orders restated by hand (Eigen 3.2.x, the version of the
  * reference's Ubuntu 12.04/14.04 era; the reference does not pin one):

@@ -3,8 +3,10 @@
 
 The reference ships no tests or golden vectors and cannot be built here (it needs ROS/PCL/Eigen/boost),
 so these vectors come from the CPU oracle (oracle/tsdf_oracle.c, itself pinned by the hand-derived KATs
-of tests/test_oracle_kat.py).  They serve two purposes: they freeze the oracle against regressions
-(CPU test) and they let the GPU parity test check the HIP path against committed data.
+of tests/test_oracle_kat.py).  Before anything is written, the second restatement (oracle/np_oracle.py, NumPy,
+written from the reference's lines independently of the C file) must reproduce every vector: volume, probes,
+normal equations bit for bit, the tracked pose to 1e-11.  The vectors serve two purposes: they freeze the oracles
+against regressions (CPU tests) and they let the GPU parity test check the HIP path against committed data.
 
 Run from the repo root:  python tools/make_golden.py          (hot path)
                          python tools/make_golden.py mesh     (mesh of the golden volume -> mesh_m24.npz)
@@ -18,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import oracle as orc                       # noqa: E402
+from oracle import np_oracle as npo        # noqa: E402
 from tracking_sdf_amd import synth         # noqa: E402
 
 M, W, H = 24, 48, 36
@@ -64,10 +67,35 @@ def main():
     out["track_iterations"] = np.int32(st["iterations"])
     out["track_stopped"] = np.int32(st["stopped"])
     out["track_rot"], out["track_trans"], out["track_twist"] = t.rot, t.trans, st["last_twist"]
+    cross_check(out)
     dst = os.path.join(ROOT, "tests", "golden", "hotpath_m24.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes;", "updated", n_upd, "iterations", st["iterations"],
           "terms", out["acc_stats_stale1"][-1], out["acc_stats_stale0"][-1])
+
+
+def cross_check(out):
+    """C oracle == NumPy restatement on everything about to be written (raises otherwise)."""
+    vol = npo.Volume(M, VOL["width"], VOL["height"], VOL["depth"], VOL["origin"], VOL["delta"], VOL["epsilon"])
+    trk = npo.Tracker(vol, 20, 0.001, 1.0, 0.01)
+    trk.K = np.array(out["K"], dtype=np.float64)
+    for k in range(2):
+        trk.set_camera_transformation(out["R"][k], out["t"][k])
+        n = npo.update(vol, trk, out[f"xyz{k}"], out[f"nrm{k}"], out[f"rgb{k}"])
+        assert n == out["n_updated"][k], ("n_updated", k, n, out["n_updated"][k])
+    for name in ("D", "W", "Color_W", "R", "G", "B"):
+        assert np.array_equal(getattr(vol, name).view(np.uint32), out["vol_" + name].view(np.uint32)), name
+    val, ok = vol.interpolate_distance(out["probe_pts"])
+    assert np.array_equal(ok, out["probe_ok"]) and np.array_equal(val[ok].view(np.uint32), out["probe_val"][ok].view(np.uint32))
+    trk.set_camera_transformation(out["R"][1], out["t"][1])
+    for flag in (1, 0):
+        A, b, st = npo.accumulate(vol, trk, out["xyz2"], stale_carry=bool(flag))
+        assert np.array_equal(A, out[f"A_stale{flag}"]) and np.array_equal(b, out[f"b_stale{flag}"]), flag
+        assert [st[k] for k in ("n_samples", "n_nan", "n_oog", "n_fail", "n_ok", "n_terms")] == out[f"acc_stats_stale{flag}"].tolist()
+    st = npo.estimate_new_position(vol, trk, out["xyz2"], stale_carry=True)
+    assert st["iterations"] == int(out["track_iterations"]) and st["stopped"] == int(out["track_stopped"])
+    assert np.max(np.abs(trk.rot - out["track_rot"])) < 1e-11 and np.max(np.abs(trk.trans - out["track_trans"])) < 1e-11
+    print("cross-check: NumPy restatement reproduces every vector")
 
 
 def mesh_golden():
