@@ -58,3 +58,11 @@ pmc_calibrate:
 	@mkdir -p $(ROOT)build
 	$(HIPCC) --offload-arch=gfx950 -O3 -o $(ROOT)build/pmc_calibrate $(ROOT)tools/pmc_calibrate.hip
 .PHONY: pmc_calibrate
+
+# the reference's exact call signatures (hotpath.hpp -DTSDF_WITH_EIGEN_PCL -DTSDF_WITH_ROS) against the mock Eigen /
+# PCL / ROS headers of tests/mock: test infrastructure (tests/test_cpp_shim.py)
+refcall_demo: $(LIB)
+	@mkdir -p $(ROOT)build
+	g++ -std=c++11 -O2 -Wall -Wextra -DTSDF_WITH_EIGEN_PCL -DTSDF_WITH_ROS -I$(ROOT)tests/mock -I$(ROOT)include \
+	    -o $(ROOT)build/refcall_demo $(ROOT)tests/mock/refcall_demo.cpp -L$(LIBDIR) -ltsdf_hip -Wl,-rpath,$(LIBDIR)
+.PHONY: refcall_demo

@@ -5,7 +5,10 @@
 // sdf.h / camera_tracking.h to run the per-frame hot path on an MI355X.  Eigen and
 // PCL are not required: matrices are plain row-major arrays (`Mat3`, `Vec3`), clouds are the small
 // `OrganizedCloud` / `NormalCloud` views below.  With -DTSDF_WITH_EIGEN_PCL (and those headers on the
-// include path) overloads taking the reference's exact types are compiled as well.
+// include path) the block at the end of this file adds `SDF` / `CameraTracking` classes with the reference's exact
+// signatures (Eigen::Vector3d& origin, pcl::PointCloud<...>::Ptr clouds, Eigen-typed public rot / trans / K) at
+// global scope, so that the reference's call sites compile unchanged (tests/test_cpp_shim.py compiles them against
+// minimal mock headers).
 //
 // Reference interfaces mirrored (paths relative to the reference's src/):
 //   SDF::SDF(m, width, height, depth, origin, delta, epsilon)           include/sdf_3d_reconstruction/sdf.h:78-79
@@ -38,10 +41,14 @@ struct OrganizedCloud {
     const float* xyz = nullptr;      // height*width*3, NaN = no depth
     const uint8_t* rgb = nullptr;    // height*width*3 (r,g,b), may be null
     int32_t width = 0, height = 0;
+    OrganizedCloud() {}
+    OrganizedCloud(const float* xyz_, const uint8_t* rgb_, int32_t w, int32_t h) : xyz(xyz_), rgb(rgb_), width(w), height(h) {}
 };
 struct NormalCloud {
     const float* normal = nullptr;   // height*width*3, NaN = undefined
     int32_t width = 0, height = 0;
+    NormalCloud() {}
+    NormalCloud(const float* n, int32_t w, int32_t h) : normal(n), width(w), height(h) {}
 };
 
 struct Error : std::runtime_error {
@@ -199,11 +206,21 @@ inline void SDF::update(CameraTracking* camera_tracking) {
 }  // namespace tsdf_shim
 
 #ifdef TSDF_WITH_EIGEN_PCL
-// Adapters for the reference's exact argument types.  Compiled only where Eigen and PCL exist (they do
-// not in the build container): they repack PCL's 32-byte AoS points into the planes the C ABI takes.
+// The reference's exact argument types.  Compiled only where Eigen and PCL exist (they do not in the build
+// container; tests/mock/ holds minimal stand-ins of the few declarations used, for a compile-only test).
+// `SDF` and `CameraTracking` below have the reference's constructor / method signatures and Eigen-typed public
+// fields, so that the hot-path call sites of sdf_reconstruction.cpp (:70 estimate_new_position, :71 writePoseToFile
+// reading trans / rot, :65 set_camera_transformation, :74 update, :83-88 the two constructors) compile unchanged
+// once sdf_reconstruction.h includes this header instead of sdf.h / camera_tracking.h.  PCL's 32-byte AoS points are
+// repacked into the planes the C ABI takes.  With TSDF_WITH_ROS also camera_info_cb and the cam_info subscriber
+// (camera_tracking.cpp:22-36, sdf_reconstruction.cpp:90-91).
 #include <Eigen/Core>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
+#ifdef TSDF_WITH_ROS
+#include <ros/ros.h>
+#include <sensor_msgs/CameraInfo.h>
+#endif
 namespace tsdf_shim {
 struct PclFrame {
     std::vector<float> xyz, nrm;
@@ -214,19 +231,112 @@ struct PclFrame {
         const size_t np = (size_t)c.width * c.height;
         xyz.resize(np * 3); rgb.resize(np * 3);
         for (size_t i = 0; i < np; ++i) {
-            const auto& p = c.points[i];
+            const pcl::PointXYZRGB& p = c.points[i];
             xyz[3 * i] = p.x; xyz[3 * i + 1] = p.y; xyz[3 * i + 2] = p.z;
             rgb[3 * i] = p.r; rgb[3 * i + 1] = p.g; rgb[3 * i + 2] = p.b;
         }
-        cloud = {xyz.data(), rgb.data(), (int32_t)c.width, (int32_t)c.height};
+        cloud.xyz = xyz.data(); cloud.rgb = rgb.data(); cloud.width = (int32_t)c.width; cloud.height = (int32_t)c.height;
         if (n) {
             nrm.resize(np * 3);
             for (size_t i = 0; i < np; ++i) {
                 nrm[3 * i] = n->points[i].normal_x; nrm[3 * i + 1] = n->points[i].normal_y; nrm[3 * i + 2] = n->points[i].normal_z;
             }
-            normals = {nrm.data(), (int32_t)c.width, (int32_t)c.height};
+            normals.normal = nrm.data(); normals.width = (int32_t)c.width; normals.height = (int32_t)c.height;
         }
     }
 };
-}  // namespace tsdf_shim
+
+namespace ref_types {
+
+inline Mat3 to_rows(const Eigen::Matrix3d& M) {
+    Mat3 a;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a[3 * r + c] = M(r, c);
+    return a;
+}
+inline void from_rows(const Mat3& a, Eigen::Matrix3d& M) {
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M(r, c) = a[3 * r + c];
+}
+
+class CameraTracking;
+
+class SDF : public tsdf_shim::SDF {
+public:
+    // sdf.h:78-79
+    SDF(int m_, float width, float height, float depth, Eigen::Vector3d& sdf_origin, float distance_delta,
+        float distance_epsilon, const tsdf_config* base = nullptr)
+        : tsdf_shim::SDF(m_, width, height, depth, Vec3{{sdf_origin(0), sdf_origin(1), sdf_origin(2)}}, distance_delta,
+                         distance_epsilon, base) {}
+    // sdf.h:161-163
+    inline void update(CameraTracking* camera_tracking, pcl::PointCloud<pcl::PointXYZRGB>::Ptr cloud_filtered,
+                       pcl::PointCloud<pcl::Normal>::Ptr normals);
+    // sdf.h:86
+    float interpolate_distance(const Eigen::Vector3d& voxel_coordinates, bool& is_interpolated) const {
+        return tsdf_shim::SDF::interpolate_distance(Vec3{{voxel_coordinates(0), voxel_coordinates(1), voxel_coordinates(2)}},
+                                                    is_interpolated);
+    }
+    using tsdf_shim::SDF::update;
+    using tsdf_shim::SDF::interpolate_distance;
+};
+
+class CameraTracking {
+public:
+    Eigen::Matrix3d rot;                 // camera_tracking.h:43-59
+    Eigen::Matrix3d rot_inv;
+    Eigen::Vector3d trans;
+    Eigen::Vector3d rot_inv_trans;
+    Eigen::Matrix3d K;
+    bool isKFilled;
+#ifdef TSDF_WITH_ROS
+    ros::Subscriber cam_info;
+    void camera_info_cb(const sensor_msgs::CameraInfoConstPtr& rgbd_camera_info) {       // camera_tracking.cpp:22-36
+        Eigen::Matrix3d k;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) k(r, c) = rgbd_camera_info->K[3 * r + c];
+        set_K(k);
+        this->cam_info.shutdown();
+    }
 #endif
+    // camera_tracking.cpp:3-4 (the definition's order: max_iter, max_twist_diff, v_h, w_h -- the declaration in
+    // camera_tracking.h:63 swaps the names of the last two floats, the call site passes 1.0, 0.01)
+    CameraTracking(int gauss_newton_max_iteration, float maximum_twist_diff, float v_h, float w_h, SDF* sdf)
+        : isKFilled(false), impl_(gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf) { pull(); }
+    virtual ~CameraTracking() {}
+
+    void set_K(const Eigen::Matrix3d& k) { impl_.set_K(to_rows(k)); K = k; isKFilled = true; }
+    // camera_tracking.h:84
+    void set_camera_transformation(Eigen::Matrix3d& r, Eigen::Vector3d& t) {
+        impl_.set_camera_transformation(to_rows(r), Vec3{{t(0), t(1), t(2)}});
+        pull();
+    }
+    // camera_tracking.h:101
+    void estimate_new_position(const SDF* sdf, const pcl::PointCloud<pcl::PointXYZRGB>::Ptr& point_cloud) {
+        const PclFrame f(*point_cloud, nullptr);
+        try { impl_.estimate_new_position(sdf, f.cloud); } catch (...) { pull(); throw; }
+        pull();
+    }
+    tsdf_shim::CameraTracking* impl() { return &impl_; }
+    void pull() {                          // native handle -> the public Eigen fields
+        impl_.sync();
+        from_rows(impl_.rot, rot); from_rows(impl_.rot_inv, rot_inv);
+        for (int a = 0; a < 3; ++a) { trans(a) = impl_.trans[a]; rot_inv_trans(a) = impl_.rot_inv_trans[a]; }
+    }
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+private:
+    tsdf_shim::CameraTracking impl_;
+};
+
+inline void SDF::update(CameraTracking* camera_tracking, pcl::PointCloud<pcl::PointXYZRGB>::Ptr cloud_filtered,
+                        pcl::PointCloud<pcl::Normal>::Ptr normals) {
+    const PclFrame f(*cloud_filtered, normals.get());
+    tsdf_shim::SDF::update(camera_tracking ? camera_tracking->impl() : nullptr, f.cloud, f.normals);
+}
+
+}  // namespace ref_types
+}  // namespace tsdf_shim
+
+#ifndef TSDF_SHIM_NO_GLOBAL_NAMES
+// the reference declares both classes at global scope (sdf.h:35, camera_tracking.h:12)
+using tsdf_shim::ref_types::SDF;
+using tsdf_shim::ref_types::CameraTracking;
+#endif
+#endif  // TSDF_WITH_EIGEN_PCL

@@ -30,6 +30,42 @@ def test_shim_demo_compiles_with_plain_gxx():
     assert p.returncode == 0, p.stderr
 
 
+def test_reference_call_sites_compile_unchanged_against_the_shim():
+    """sdf_reconstruction.cpp:65,70-71,74,83-88,90-91 -- the reference's own statements with the reference's own
+    types (Eigen::Vector3d&, pcl::PointCloud<...>::Ptr, Eigen-typed public trans / rot, camera_info_cb) -- compile
+    against hotpath.hpp with -DTSDF_WITH_EIGEN_PCL -DTSDF_WITH_ROS.  Eigen / PCL / ROS are not in the image:
+    tests/mock holds minimal stand-ins of the declarations touched (test infrastructure)."""
+    src = os.path.join(ROOT, "tests", "mock", "callsite_compile.cpp")
+    for std in ("c++11", "c++17"):          # the reference builds with -std=c++0x
+        p = subprocess.run(["g++", "-std=" + std, "-fsyntax-only", "-Wall", "-Wextra", "-DTSDF_WITH_EIGEN_PCL", "-DTSDF_WITH_ROS",
+                            "-I", os.path.join(ROOT, "tests", "mock"), "-I", os.path.join(ROOT, "include"), src],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+    # and links: header-only on top of the C ABI
+    subprocess.check_call(["make", "-C", ROOT, "-s", "refcall_demo"])
+    assert os.access(os.path.join(ROOT, "build", "refcall_demo"), os.X_OK)
+    # without the macro nothing of Eigen / PCL is needed
+    p = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++", "-"],
+                       input='#include "sdf_3d_reconstruction/hotpath.hpp"\nint main(){return 0;}\n', text=True, capture_output=True)
+    assert p.returncode == 0, p.stderr
+
+
+@pytest.mark.gpu
+def test_exact_type_call_sites_give_the_same_trajectory_as_the_plain_shim(tmp_path):
+    from dump_frames import dump
+    exe_plain = build_demo()
+    subprocess.check_call(["make", "-C", ROOT, "-s", "refcall_demo"])
+    exe_ref = os.path.join(ROOT, "build", "refcall_demo")
+    frames_bin = str(tmp_path / "frames.bin")
+    dump(frames_bin, n=4, width=160, height=120, step=2)
+    outs = []
+    for exe, name in ((exe_plain, "a.txt"), (exe_ref, "b.txt")):
+        p = subprocess.run([exe, frames_bin, "64", str(tmp_path / name)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        outs.append((np.loadtxt(str(tmp_path / name))[:, :4], [float(x) for x in p.stdout.split("=")[1].split()[:3]]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
 @pytest.mark.gpu
 def test_shim_demo_frame_loop_matches_oracle(tmp_path):
     import oracle as orc
