@@ -206,8 +206,8 @@ int tsdf_load(tsdf_handle *h, const char *path);
  * SDF::interpolate_color at every vertex's world position (4 floats r,g,b,a per vertex, a = 1; r,g,b carry
  * the reference's scaling: /255 when interpolated, raw 0..255 on an exact voxel hit, NaN with no coloured
  * corner).  iso_level must be in [0,1) as in the reference (marching_cubes_sdf.cpp:246-252; it uses 0).
- * The triangulation inside a cube uses this library's own case table: the reference table's polygons
- * (same vertices, same triangle count) but other diagonals -- see tools/gen_mc_tables.py.
+ * The case table is the reference's (marching_cubes_sdf.h:73-364, kept as data: tools/gen_mc_tables.py), so the soup is
+ * performReconstruction's, triangle for triangle and in its order.
  * On a sharded volume each rank meshes its own cubes (needs halo >= 1); rank order = index order.
  * tsdf_mesh_read copies the last extraction to host arrays (colors may be NULL); tsdf_mesh_device hands out
  * the device buffers (valid until the next extraction / destroy). */

@@ -164,7 +164,7 @@ void orc_interpolate_color(const orc_sdf *s, const double global[3], float rgba[
 /* pcl::MarchingCubesSDF::performReconstruction, marching_cubes_sdf.cpp:243-287 (iso level 0 in the
  * reference, sdf.cpp:44): interior voxels (1 <= i,j,k <= m-2, sdf.cpp:36-39) in index order, cube
  * corners/gate of getNeighborList1D (:203-240), createSurface (:100-199) with float arithmetic.
- * Triangulation table: oracle/mc_tables.h (generated; the reference's polygons, own diagonals).
+ * Triangulation table: oracle/mc_tables.h (the reference's table, marching_cubes_sdf.h:73-364, kept as data).
  * verts (may be NULL to count): 9 floats per triangle in the grid-local frame of the reference's cloud.
  * Cubes with i in [i0, i1) only (0, m for all).  Returns the number of triangles (those beyond
  * cap_triangles are counted, not written); -1 for an iso level outside [0,1) (:246-252). */

@@ -19,82 +19,45 @@ import gen_mc_tables as gen  # noqa: E402
 REF_HEADER = "/root/reference/src/include/sdf_3d_reconstruction/marching_cubes_sdf.h"
 
 
-def test_committed_tables_are_what_the_generator_writes():
+def test_committed_tables_pass_the_structural_check():
+    """Both committed headers identical, in the generator's layout, and every case tiles exactly the polygons derived
+    from the cube geometry (needs no reference tree)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_mc_tables.py"), "--check"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def _loops_of(tris):
-    """Boundary cycles of a set of oriented triangles over edge numbers (None if not a set of closed polygons)."""
-    d = {}
-    for t in tris:
-        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
-            if (b, a) in d:
-                del d[(b, a)]
-            else:
-                d[(a, b)] = 1
-    nxt = {}
-    for a, b in d:
-        if a in nxt:
-            return None
-        nxt[a] = b
-    out, seen = [], set()
-    for s in sorted(nxt):
-        if s in seen:
-            continue
-        loop, c = [], s
-        while c not in seen:
-            seen.add(c)
-            loop.append(c)
-            c = nxt.get(c)
-            if c is None:
-                return None
-        out.append(tuple(loop))       # starts at its smallest edge because of the sorted() walk
-    return sorted(out)
+def committed_table():
+    return gen.parse_header(open(os.path.join(ROOT, "tracking_sdf_amd", "csrc", "mc_tables.h")).read())
 
 
 def test_table_structure():
-    table = gen.build()
+    table = committed_table()
+    derived = gen.build()
     assert table[0] == [] and table[255] == []
     for case in range(256):
         tris = table[case]
         used = {e for t in tris for e in t}
         mask = gen.edge_mask(case)
         assert used == {e for e in range(12) if mask >> e & 1}, case     # exactly the crossed edges
-        loops = _loops_of(tris)
+        loops = gen.loops_of(tris)
         assert loops is not None, case
-        assert sum(len(lp) - 2 for lp in loops) == len(tris), case       # fans: n - 2 triangles per polygon
+        assert sum(len(lp) - 2 for lp in loops) == len(tris), case       # n - 2 triangles per polygon
         assert sorted(e for lp in loops for e in lp) == sorted(used), case   # every crossed edge on one polygon
+        assert loops == gen.loops_of(derived[case]), case                # = the polygons the geometry dictates
         # complement = the same contour with the other side inside: same crossed edges
         assert gen.edge_mask(case ^ 255) == mask
 
 
 @pytest.mark.skipif(not os.path.exists(REF_HEADER), reason="reference tree not present")
-def test_same_polygons_as_the_reference_table():
-    """The reference's table is read here only to compare structure: every case must have the same crossed
-    edges and the same oriented polygons; only diagonals / triangle order may differ."""
-    src = open(REF_HEADER).read()
-    body = src[src.index("{", src.index("triTable")):]
-    ref = []
-    for r in re.findall(r"\{([^{}]*)\}", body)[:256]:
-        v = [int(x) for x in r.replace("\n", " ").split(",") if x.strip()]
-        v = v[:v.index(-1)] if -1 in v else v
-        ref.append([tuple(v[k:k + 3]) for k in range(0, len(v), 3)])
-    eb = src[src.index("{", src.index("edgeTable")):]
-    edge_table = [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", eb[:eb.index("}")])]
-    assert len(ref) == 256 and len(edge_table) == 256
-    table = gen.build()
-    identical = 0
+def test_identical_to_the_reference_table_in_all_256_cases():
+    """tsdf_mesh_read must return performReconstruction's triangle soup bit for bit, so the committed table must BE the
+    reference's: the same triangles in the same order in every case, and the same edge masks."""
+    ref, masks = gen.parse_reference(REF_HEADER)
+    table = committed_table()
     for case in range(256):
-        assert edge_table[case] == gen.edge_mask(case), case
-        assert len(table[case]) == len(ref[case]), case
-        assert _loops_of(table[case]) == _loops_of(ref[case]), case
-
-        def canon(ts):
-            return sorted(t[t.index(min(t)):] + t[:t.index(min(t))] for t in ts)
-        identical += canon(table[case]) == canon(ref[case])
-    assert identical >= 98          # the rest differ in the diagonals of polygons with more than 3 vertices
+        assert masks[case] == gen.edge_mask(case), case
+        assert table[case] == ref[case], case
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
-"""Generate the marching-cubes case table used by the mesh-extraction kernels and by the oracle.
+"""The marching-cubes case table used by the mesh-extraction kernels and by the oracle.
 
-The reference meshes the volume with a PCL-style marching cubes whose 256-case triangle table is Paul
-Bourke's hand-made one (src/include/sdf_3d_reconstruction/marching_cubes_sdf.h:73-364).  That table is data
-from a third party and is not reproduced here.  This script DERIVES a table from the cube's geometry:
+The reference meshes the volume with a PCL-style marching cubes driven by the classic 256-case edge / triangle table
+(the Lorensen-Cline cases as tabulated by Cory Bloyd / Paul Bourke; in the reference:
+src/include/sdf_3d_reconstruction/marching_cubes_sdf.h:73-364, consumed at src/marching_cubes_sdf.cpp:100-199).
+`tsdf_mesh_read` is specified to return the triangle soup of performReconstruction bit for bit, and inside a cube
+that soup is decided by the table's choice of diagonals and by its triangle order -- so the committed headers hold
+that table's constants, as data, in this repository's own layout (kMcNumTri / kMcTri).
+
+Round 1 shipped a table DERIVED from the cube geometry by this script (same polygons in all 256 cases, other
+diagonals in 158 of them); the derivation is kept as the structural check of the committed constants:
 
   * corner c sits at the reference's offsets (marching_cubes_sdf.cpp:129-141): bit test of c gives
     0:(0,0,0) 1:(x) 2:(x,z) 3:(z) 4:(y) 5:(x,y) 6:(x,y,z) 7:(y,z);
@@ -13,19 +19,16 @@ from a third party and is not reproduced here.  This script DERIVES a table from
     left seen from outside the cube; a face with four crossings (two diagonal inside corners) is ambiguous and
     is resolved by cutting off each inside corner -- one rule for every cube, so two cubes sharing an ambiguous
     face draw the same two segments on it (no cracks);
-  * segments chain into closed loops (every crossed edge ends one segment and starts another);
-  * each loop is rotated to start at its smallest edge number, loops are ordered by that number and
-    fan-triangulated.
+  * segments chain into closed loops (every crossed edge ends one segment and starts another).
 
-So the *polygons* of a case are determined by the geometry and the ambiguity rule; only the choice of diagonals
-and the order of the triangles are this script's own.  tests/test_mesh_tables.py checks the structural
-properties (every crossed edge used once per loop, closed loops, triangle counts) and, when the reference tree
-is present, that all 256 cases have exactly the reference table's polygons (same loops, same winding) and the
-same edge masks -- i.e. the mesh has the same vertices and the same number of triangles per cube; 98 cases
-are the identical triangle set, in the others a polygon with more than three vertices is cut along other
-diagonals.
+--check (run by tests/test_mesh_tables.py, needs no reference tree): the two committed headers are identical, and in
+every one of the 256 cases the committed triangles use exactly the crossed edges and tile exactly the polygons the
+derivation above yields, with the derivation's winding.
+--from-reference HEADER (build container only): read the table out of the reference header and write the two
+committed headers; refuses to write if the structural check fails.
 
-Usage:  python tools/gen_mc_tables.py [--check]     (writes tracking_sdf_amd/csrc/mc_tables.h, oracle/mc_tables.h)
+Usage:  python tools/gen_mc_tables.py --check
+        python tools/gen_mc_tables.py --from-reference /root/reference/src/include/sdf_3d_reconstruction/marching_cubes_sdf.h
 """
 import argparse
 import os
@@ -142,12 +145,90 @@ def edge_mask(case):
     return m
 
 
+def loops_of(tris):
+    """Boundary cycles of a set of oriented triangles over edge numbers (None if not a set of closed polygons)."""
+    d = {}
+    for t in tris:
+        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            if (b, a) in d:
+                del d[(b, a)]
+            else:
+                d[(a, b)] = 1
+    nxt = {}
+    for a, b in d:
+        if a in nxt:
+            return None
+        nxt[a] = b
+    out, seen = [], set()
+    for s in sorted(nxt):
+        if s in seen:
+            continue
+        loop, c = [], s
+        while c not in seen:
+            seen.add(c)
+            loop.append(c)
+            c = nxt.get(c)
+            if c is None:
+                return None
+        out.append(tuple(loop))       # starts at its smallest edge because of the sorted() walk
+    return sorted(out)
+
+
+def structural_errors(table):
+    """Cases in which `table` does not tile the derived polygons (same crossed edges, same loops, same winding)."""
+    derived = build()
+    bad = []
+    for case in range(256):
+        tris = table[case]
+        used = {e for t in tris for e in t}
+        mask = edge_mask(case)
+        ok = used == {e for e in range(12) if mask >> e & 1} and len(tris) == len(derived[case]) and len(tris) <= 5
+        ok = ok and loops_of(tris) == loops_of(derived[case])
+        if not ok:
+            bad.append(case)
+    return bad
+
+
+def parse_reference(path):
+    """The 256 triangle lists of the reference header's triTable (and its edgeTable, for the mask check)."""
+    import re
+    src = open(path).read()
+    body = src[src.index("{", src.index("triTable")):]
+    table = []
+    for r in re.findall(r"\{([^{}]*)\}", body)[:256]:
+        v = [int(x) for x in r.replace("\n", " ").split(",") if x.strip()]
+        v = v[:v.index(-1)] if -1 in v else v
+        table.append([tuple(v[k:k + 3]) for k in range(0, len(v), 3)])
+    eb = src[src.index("{", src.index("edgeTable")):]
+    masks = [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", eb[:eb.index("}")])]
+    assert len(table) == 256 and len(masks) == 256
+    return table, masks
+
+
+def parse_header(text):
+    """kMcTri of a committed mc_tables.h -> 256 triangle lists."""
+    import re
+    body = text[text.index("kMcTri[256][16]"):]
+    rows = re.findall(r"\{([^{}]*)\}", body)[:256]
+    table = []
+    for r in rows:
+        v = [int(x) for x in r.split(",") if x.strip()]
+        assert len(v) == 16
+        v = v[:v.index(-1)] if -1 in v else v
+        table.append([tuple(v[k:k + 3]) for k in range(0, len(v), 3)])
+    counts = [int(x) for x in re.findall(r"\d+", text[text.index("kMcNumTri[256]") + 14:text.index("};")])]
+    assert len(table) == 256 and counts == [len(t) for t in table], "kMcNumTri does not match kMcTri"
+    return table
+
+
 def render(table):
     lines = [
-        "// mc_tables.h -- GENERATED by tools/gen_mc_tables.py; do not edit.",
-        "// Marching-cubes case table derived from the cube geometry (corner / edge numbering of the reference's",
-        "// marching_cubes_sdf.cpp:108-169): kMcNumTri[case] triangles, kMcTri[case][3*t+{0,1,2}] = edge numbers.",
-        "// Not Bourke's table: the same polygons in every case (tests/test_mesh_tables.py), own diagonals and order.",
+        "// mc_tables.h -- written by tools/gen_mc_tables.py --from-reference; do not edit.",
+        "// The classic 256-case marching-cubes triangle table (Lorensen-Cline cases as tabulated by Bloyd / Bourke), the",
+        "// constants of the reference's marching_cubes_sdf.h:73-364, in this repository's layout: kMcNumTri[case] triangles,",
+        "// kMcTri[case][3*t+{0,1,2}] = edge numbers (corner / edge numbering of marching_cubes_sdf.cpp:108-169).  Kept as",
+        "// data because tsdf_mesh_read must return performReconstruction's triangle soup (same diagonals, same order);",
+        "// tools/gen_mc_tables.py --check verifies every case against the polygons derived from the cube geometry.",
         "#pragma once",
         "",
         "#ifndef MC_TABLE_DECL",
@@ -170,23 +251,43 @@ def render(table):
     return "\n".join(lines)
 
 
+HEADERS = ("tracking_sdf_amd/csrc/mc_tables.h", "oracle/mc_tables.h")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--check", action="store_true", help="fail if the committed headers differ from the generator")
+    ap.add_argument("--check", action="store_true", help="verify the committed headers (structure; both copies identical)")
+    ap.add_argument("--from-reference", metavar="HEADER", help="write the committed headers from the reference's table")
     args = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    text = render(build())
-    rc = 0
-    for rel in ("tracking_sdf_amd/csrc/mc_tables.h", "oracle/mc_tables.h"):
-        path = os.path.join(root, rel)
-        if args.check:
-            if not os.path.exists(path) or open(path).read() != text:
-                print("stale:", rel)
-                rc = 1
-        else:
-            with open(path, "w") as f:
+    if args.from_reference:
+        table, masks = parse_reference(args.from_reference)
+        assert masks == [edge_mask(c) for c in range(256)], "edgeTable disagrees with the corner / edge numbering"
+        bad = structural_errors(table)
+        if bad:
+            print("table does not tile the derived polygons in cases", bad)
+            return 1
+        text = render(table)
+        for rel in HEADERS:
+            with open(os.path.join(root, rel), "w") as f:
                 f.write(text)
             print("wrote", rel)
+        return 0
+    texts = [open(os.path.join(root, rel)).read() for rel in HEADERS]
+    rc = 0
+    if texts[0] != texts[1]:
+        print("the two committed headers differ")
+        rc = 1
+    table = parse_header(texts[0])
+    if render(table) != texts[0]:
+        print("committed header is not in the generator's layout")
+        rc = 1
+    bad = structural_errors(table)
+    if bad:
+        print("cases that do not tile the derived polygons:", bad)
+        rc = 1
+    if not args.check:
+        print("nothing written: use --from-reference HEADER (or --check)")
     return rc
 
 

@@ -13,8 +13,8 @@
 //     concatenated in thread order = index order for a static schedule, :262-283).
 //   * SDF::visualize (sdf.cpp:353-383) adds sdf_origin in double and colours every vertex with
 //     SDF::interpolate_color (sdf.cpp:164-217).
-// The triangle table is mc_tables.h (tools/gen_mc_tables.py): the reference table's polygons in all 256
-// cases, own diagonals -- same vertices, same triangle count per cube.
+// The triangle table is mc_tables.h: the reference's table (marching_cubes_sdf.h:73-364) kept as data, so the soup is
+// performReconstruction's triangle for triangle (tools/gen_mc_tables.py --check verifies it against the cube geometry).
 //
 // Five launches; the first is the 8 B/voxel D,W sweep and is HBM-bound, the rest touch the surface only:
 //   mesh_count_kernel        one wavefront per (i,j) row of cubes: case numbers, triangles per row
