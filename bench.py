@@ -210,10 +210,18 @@ def cpu_baseline(args, K, frames, m, width, height):
             "cpu_model": model}
 
 
+PMC_GROUPS = (("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum"), ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+PMC_CORRECTION_NOTE = ("bytes from the L2's memory-side request counters by request size: read = 32 n32 + 128 n128 + 64 (RDREQ - n32 - n128), "
+                       "write = 64 n64 + 32 (WRREQ - n64).  Calibrated on this chip with known-byte kernels in this kernel's access "
+                       "widths (tools/pmc_calibrate.py, profiles/r02_fetch_calibration.json): the derived bytes equal the known bytes "
+                       "(ratio 1.000 for 8 B and 16 B per lane, plain and non-temporal, reads and writes), while FETCH_SIZE itself "
+                       "reports exactly 1/2 of them (every streaming read leaves L2 as a 128-byte request tallied as 64 B)")
+
+
 def pmc_traffic(args, wl_args):
     """HBM bytes of one integrate launch pair (clip_rows_kernel + integrate_kernel) of THIS workload, measured now:
-    two child runs of this script under rocprofv3, one --pmc counter each (FETCH_SIZE and WRITE_SIZE do not fit one
-    pass; never combined with a trace domain), program directly after `--`.  Returns a dict or a reason string."""
+    two child runs of this script under rocprofv3 --pmc, one counter group each (read requests by size, write
+    requests by size; never combined with a trace domain), program directly after `--`.  Returns a dict or a reason."""
     import csv
     import glob
     import shutil
@@ -223,9 +231,9 @@ def pmc_traffic(args, wl_args):
     res = {}
     work = tempfile.mkdtemp(prefix="tsdf_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(work, counter)
-            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+        for gi, group in enumerate(PMC_GROUPS):
+            d = os.path.join(work, "g%d" % gi)
+            cmd = ["rocprofv3", "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-child", "--steps", "12", "--warmup", "2"] + wl_args
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -233,24 +241,30 @@ def pmc_traffic(args, wl_args):
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
             except subprocess.TimeoutExpired:
-                return f"rocprofv3 --pmc {counter} pass timed out"
+                return f"rocprofv3 --pmc {group[0]} pass timed out"
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
-                return f"rocprofv3 --pmc {counter} pass failed (rc {p.returncode}): {p.stderr[-300:]}"
+                return f"rocprofv3 --pmc {group[0]} pass failed (rc {p.returncode}): {p.stderr[-300:]}"
             acc = {}
             with open(files[0]) as f:
                 for r in csv.DictReader(f):
-                    if r["Counter_Name"] != counter:
+                    if r["Counter_Name"] not in group:
                         continue
                     name = r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
-                    a = acc.setdefault(name, [0, 0.0])
+                    a = acc.setdefault((name, r["Counter_Name"]), [0, 0.0])
                     a[0] += 1
-                    a[1] += float(r["Counter_Value"]) * 1024.0          # rocprofv3 reports these two in KB
-            for name, (cnt, tot) in acc.items():
-                res.setdefault(name, {})[counter] = {"launches": cnt, "mean_bytes": tot / cnt}
+                    a[1] += float(r["Counter_Value"])
+            for (name, counter), (cnt, tot) in acc.items():
+                res.setdefault(name, {})[counter] = tot / cnt
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    return res
+    out = {}
+    for name, c in res.items():
+        n, n32, n128 = c.get("TCC_EA0_RDREQ_sum", 0.0), c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        w, w64 = c.get("TCC_EA0_WRREQ_sum", 0.0), c.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+        out[name] = {"read_bytes": 32.0 * n32 + 128.0 * n128 + 64.0 * (n - n32 - n128), "write_bytes": 64.0 * w64 + 32.0 * (w - w64),
+                     "requests": c}
+    return out
 
 
 def main():
@@ -623,6 +637,8 @@ def run(args):
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_updated_voxel": bpv,
                          "updated_voxels_per_launch": upd_per_launch, "avg_launch_ms": avg_ms,
                          "timed_launches": tm["integrate_launches"], "launches": cn["integrate_calls"],
+                         "work_items_per_launch": cn["integrate_items"] / launches,
+                         "live_fraction_of_listed_lanes": upd_per_launch / max(1.0, 64.0 * cn["integrate_items"] / launches),
                          "sweep_equiv_GBs": bpv * cn["n_voxels_swept"] / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0},
             # the tsdf_track call also waits for the previous frame's integration (same stream), so a pass is priced
             # on what is left of the frame after the integrate and pack launches
@@ -654,16 +670,17 @@ def run(args):
             torch.cuda.empty_cache()
             got = pmc_traffic(args, wl)
             if isinstance(got, dict):
-                def tot(prefix, counter):
-                    return sum(v.get(counter, {}).get("mean_bytes", 0.0) for k, v in got.items() if k.startswith(prefix))
-                fetch = tot("tsdf::integrate_kernel", "FETCH_SIZE") + tot("tsdf::clip_rows_kernel", "FETCH_SIZE")
-                write = tot("tsdf::integrate_kernel", "WRITE_SIZE") + tot("tsdf::clip_rows_kernel", "WRITE_SIZE")
+                def tot(prefix, field):
+                    return sum(v[field] for k, v in got.items() if k.startswith(prefix))
+                fetch = tot("tsdf::integrate_kernel", "read_bytes") + tot("tsdf::clip_rows_kernel", "read_bytes")
+                write = tot("tsdf::integrate_kernel", "write_bytes") + tot("tsdf::clip_rows_kernel", "write_bytes")
                 out["roofline"]["traffic"] = fetch + write
                 out["roofline"]["traffic_detail"] = {
-                    "FETCH_SIZE_bytes": fetch, "WRITE_SIZE_bytes": write,
+                    "read_bytes": fetch, "write_bytes": write,
                     "source": "two rocprofv3 --pmc child passes of this command's workload run by bench.py itself "
-                              "(one counter per pass, 12 timed steps), bytes per launch pair",
-                    "correction": PMC_CORRECTION_NOTE, "ratio_to_algorithmic": (fetch + write) / alg_bytes}
+                              "(one counter group per pass, 12 timed steps), bytes per launch pair",
+                    "correction": PMC_CORRECTION_NOTE, "ratio_to_algorithmic": (fetch + write) / alg_bytes,
+                    "requests_integrate_kernel": {k: v["requests"] for k, v in got.items() if k.startswith("tsdf::integrate_kernel")}}
             else:
                 out["roofline"]["traffic_detail"] = {"source": "unavailable: " + str(got)}
         if args.trajectory_out:
@@ -680,10 +697,6 @@ def run(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-PMC_CORRECTION_NOTE = ("none applied; see profiles/r02_fetch_calibration.json for the calibration of FETCH_SIZE / WRITE_SIZE "
-                       "against known byte counts in this kernel's access widths")
 
 
 def full_sequence(ts, synth, torch, dev, dev_index, ms, width, height, noise, with_color):

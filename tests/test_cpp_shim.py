@@ -154,7 +154,7 @@ def test_offline_tum_driver_matches_python_binding(tmp_path):
         s.update()
     want = np.array(want)
     assert np.max(np.abs(got[:, 1:4] - want)) <= 5.1e-5                  # 4 decimals in the pose file
-    assert np.max(np.abs(want - seq.t[1:n])) < 0.05                      # and it follows the true path
+    assert np.max(np.abs(want - seq.t[1:n])) < 0.08                      # and it follows the true path (9.4 cm voxels, 160x120)
     assert '"track_errors": 0' in p.stdout
     # the mesh the driver wrote = the binding's mesh of the same volume, moved to the world frame
     v = s.mesh()

@@ -41,6 +41,22 @@ def test_odd_sizes_match_oracle(m, w, h):
     compare_update_and_accumulate(m, w, h)
 
 
+@pytest.mark.parametrize("w,h,n_wg", [(24, 18, 1), (36, 36, 3), (63, 48, 7), (72, 48, 8), (75, 48, 9), (120, 96, 27)])
+def test_tracker_fan_in_with_few_workgroups(w, h, n_wg):
+    """The in-launch fan-in of the tracker rows shards the workgroups 8 ways: fewer workgroups than shards, exactly
+    8, one more, and an uneven split must all give the oracle's sums -- and the same bits on every repetition,
+    whichever workgroup happens to arrive last."""
+    assert -(-(((w + 2) // 3) * ((h + 2) // 3)) // 48) == n_wg          # 48 samples per workgroup
+    compare_update_and_accumulate(48, w, h)
+    seq, (xyz, nrm, rgb) = render(w, h)
+    go, gt = make_gpu(48, seq.K)
+    go.update(gt, xyz, nrm, rgb)
+    A0, b0, st0 = gt.accumulate()
+    for _ in range(25):
+        A, b, st = gt.accumulate()
+        assert np.array_equal(A, A0) and np.array_equal(b, b0) and st == st0
+
+
 def test_single_pixel_and_2x2_images():
     for w, h in ((1, 1), (2, 2), (4, 1)):
         compare_update_and_accumulate(32, w, h)

@@ -71,8 +71,9 @@ def test_tracker_properties_at_512():
     assert st["n_samples"] == 214 * 160 and st["n_oog"] == 0 and st["n_terms"] == st["n_ok"] > 25000
     assert np.array_equal(A, A.T) and np.all(np.linalg.eigvalsh(A) > -1e-6 * np.abs(A).max())
     # repeated passes are bitwise reproducible (fixed-order reduction, no float atomics)
-    A2, b2, _ = t.accumulate()
-    assert np.array_equal(A, A2) and np.array_equal(b, b2)
+    for _ in range(40):                      # 714 workgroups race to be the last arriver of their shard: same bits every time
+        A2, b2, _ = t.accumulate()
+        assert np.array_equal(A, A2) and np.array_equal(b, b2)
     # tracking frame 1 from its true pose stays put (sub-centimetre), frame 2 from pose 1 moves toward pose 2
     st = t.estimate_new_position(s, fr[1][0])
     assert np.linalg.norm(t.trans - seq.t[1]) < 0.01

@@ -43,7 +43,6 @@ def main():
         a = np.deg2rad(args.roll)
         Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
         seq.R = np.array([R @ Rz for R in seq.R])
-    frames = [seq.frame(k) for k in range(args.frames)]
     if args.look_along_k:
         # the images stay what they are (camera frame); only the world pose changes: world -y (the viewing direction
         # of the reference's initial pose) is mapped to world +z, the camera moved to the bottom of the volume
@@ -51,7 +50,12 @@ def main():
         c = np.array([0.0, 1.0, -0.3])
         seq.t = np.array([Q @ t + c for t in seq.t])
         seq.R = np.array([Q @ R for R in seq.R])
-    d = [(torch.from_numpy(x).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev)) for x, n, c in frames]
+    # frames are rendered at the ORIGINAL poses (camera-frame images do not change with --look-along-k), on the GPU
+    render_seq = synth.Sequence(n_frames=args.frames, width=args.width, height=args.height, noise=True, holes=0.02,
+                                step=args.frame_step)
+    if args.roll:
+        render_seq.R = np.array([R @ Rz for R in render_seq.R])
+    d = [render_seq.frame_torch(k, dev) for k in range(args.frames)]
     torch.cuda.synchronize()
     sdf = ts.SDF(args.m, with_color=not args.no_color)
     trk = ts.CameraTracking(sdf=sdf)

@@ -17,7 +17,8 @@ __all__ = ["SDF", "CameraTracking", "TsdfError", "Config", "lib", "lib_path", "b
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+# TSDF_HIP_LIB: another build of the same library (tuning experiments: tools/build_variants.sh); default = the in-tree one
+_LIB_PATH = os.environ.get("TSDF_HIP_LIB") or os.path.join(_HERE, "lib", "libtsdf_hip.so")
 
 # status codes of include/tsdf.h
 OK, E_BADARG, E_NO_DEVICE, E_HIP, E_NO_INTRINSICS, E_NO_FRAME, E_SINGULAR, E_NO_SAMPLES, E_HALO, E_COMM, E_NOMEM = \

@@ -93,7 +93,9 @@ struct tsdf_handle {
     double* red_host = nullptr;    // pinned, kRedWidth doubles + the pass-number word the host polls
     unsigned long long pass_seq = 0;
     double* fold_host = nullptr;   // pinned: kFoldBlocks slots of kFoldSlotDoubles (single-rank host fold)
-    bool host_fold = true;         // single rank: folded rows go to the host (TSDF_HOST_FOLD=0 keeps the device final kernel; +1 %)
+    bool host_fold = true;         // shared-memory fan-in: the host publishes this rank's row (TSDF_HOST_FOLD=0: the device writes the slot)
+    bool fold_in_launch = true;    // fan-in of the per-workgroup rows inside track_kernel (TSDF_TRACK_FOLD=launches: extra launches)
+    unsigned* fold_ctr = nullptr;  // its arrival counters
     unsigned integrate_launches = 0;
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
 
@@ -407,19 +409,27 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     const unsigned long long seq = ++h->pass_seq;
     double* host_row = h->red_host;          // where the final kernel publishes this rank's row
     if (use_shm && h->shm.dev_base)
-        host_row = reinterpret_cast<double*>(h->shm.dev_base + shm_slot_offset(h, h->shm.rank, seq));
+        host_row = reinterpret_cast<double*>(h->shm.dev_base + shm_slot_offset(h, h->shm.rank, seq));   // used when the device publishes
     // polling + no RCCL: the folded rows come to the host directly (one dependent launch fewer); with the
     // shared-memory fan-in the host then publishes this rank's row itself (a host-memory store instead of a
     // device write over PCIe)
-    const bool host_fold = h->host_fold && !use_rccl && h->poll && !h->timing_track;
-    if (use_shm && !host_fold && !h->shm.dev_base)
-        return fail(h, TSDF_E_COMM, "shared-memory fan-in without the host fold needs the segment registered with HIP, which failed");
+    // Legacy path (TSDF_TRACK_FOLD=launches, for A/B measurements): rows folded by a second launch and, single rank,
+    // on the host.  Default: the fan-in runs inside track_kernel and the finished row arrives in `host_row`.
+    const bool host_fold = !h->fold_in_launch && h->host_fold && !use_rccl && h->poll && !h->timing_track;
+    const bool dev_publish_shm = use_shm && h->shm.dev_base && (h->fold_in_launch ? !h->host_fold : !host_fold);
+    if (use_shm && !h->shm.dev_base && (h->fold_in_launch ? !h->host_fold : !host_fold))
+        return fail(h, TSDF_E_COMM, "shared-memory fan-in without the host publishing needs the segment registered with HIP, which failed");
+    if (!dev_publish_shm) host_row = h->red_host;
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
     // the word the device publishes behind its row: the pass number, or (device-published shared-memory slot) the
     // generation-tagged word the other ranks wait for
-    const unsigned long long dev_word = (use_shm && !host_fold) ? shm_word(h, seq) : seq;
-    HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
-                            use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, dev_word));
+    const unsigned long long dev_word = dev_publish_shm ? shm_word(h, seq) : seq;
+    if (h->fold_in_launch)
+        HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
+                                       use_rccl ? nullptr : host_row, dev_word, seq));
+    else
+        HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
+                                use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, dev_word));
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
     if (use_rccl) {
         std::string cerr;
@@ -468,7 +478,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
             int rc2 = shm_fan_in(h, seq, kRedAllreduce);
             if (rc2) return rc2;
         }
-    } else if (use_shm) {
+    } else if (dev_publish_shm) {
         int rc2 = shm_fan_in(h, seq, kRedAllreduce);
         if (rc2) return rc2;
         arrived = true;
@@ -484,6 +494,16 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         }
     }
     if (!arrived) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (use_shm && !dev_publish_shm && !host_fold) {
+        // this rank's finished row is in red_host: publish it with a host store, then add everybody's rows
+        char* slot = h->shm.base + shm_slot_offset(h, h->shm.rank, seq);
+        std::memcpy(slot, h->red_host, kRedWidth * sizeof(double));
+        __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), shm_word(h, seq), __ATOMIC_RELEASE);
+        int rc2 = shm_fan_in(h, seq, kRedAllreduce);
+        if (rc2) return rc2;
+    }
+    if (h->red_host[27] != h->red_host[27])
+        return fail(h, TSDF_E_HIP, "tracker fan-in: a partial row stayed stale through two cache invalidations (hand-off protocol violated)");
     if (h->timing_track) {
         float ms = 0.f;
         hipError_t te = hipEventElapsedTime(&ms, h->ev_track.a, h->ev_track.b);
@@ -675,6 +695,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
     { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
     { const char* ev = std::getenv("TSDF_HOST_FOLD"); h->host_fold = !(ev && std::atoi(ev) == 0); }
+    { const char* ev = std::getenv("TSDF_TRACK_FOLD"); h->fold_in_launch = !(ev && std::strcmp(ev, "launches") == 0); }
+    CREATE_TRY(hipMalloc((void**)&h->fold_ctr, track_fold_counter_words() * sizeof(unsigned)));
+    CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, track_fold_counter_words() * sizeof(unsigned), h->stream));
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
     CREATE_TRY(hipEventCreate(&h->ev_track.b));
     CREATE_TRY(launch_fill(h->stream, g, h->dw, h->crgb, cfg->width + cfg->height + cfg->depth));   // sdf.cpp:29
@@ -703,6 +726,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
     if (h->fold_host) (void)hipHostFree(h->fold_host);
+    if (h->fold_ctr) (void)hipFree(h->fold_ctr);
     if (h->counters) (void)hipFree(h->counters);
     if (h->worklist) (void)hipFree(h->worklist);
     if (h->work_count) (void)hipFree(h->work_count);

@@ -45,6 +45,7 @@ inline void track_unpack_row(const double* tot, double* red) {
 #endif
 constexpr int kTrackBlock = TSDF_TRACK_BLOCK;    // threads per tracker workgroup
 constexpr int kIntegrateBlock = 256;
+constexpr int kTrackShards = 8;                  // fan-in shards of the in-launch fold (blockIdx % 8: one per XCD)
 
 // Geometry of the stored part of the volume.  Device layout: one float2 {D,W} per voxel
 // (and one float4 {Color_W,R,G,B} when colour is kept), reference index order
@@ -113,6 +114,10 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
 hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                         double* partials, double* red_dev, double* red_host, double* fold_host,
                         unsigned long long seq);
+hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
+                               double* partials, unsigned* ctr, double* red_dev, double* host_row,
+                               unsigned long long word, unsigned long long pass);
+size_t track_fold_counter_words();
 int track_fold_blocks(int32_t n_samples);
 hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);

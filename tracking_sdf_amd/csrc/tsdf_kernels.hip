@@ -284,6 +284,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+#ifndef TSDF_INTEGRATE_DEPTH
+#define TSDF_INTEGRATE_DEPTH 1      // volume reads in flight per wavefront, in items (see the pipeline loop)
+#endif
 #ifndef TSDF_INTEGRATE_NT
 #define TSDF_INTEGRATE_NT 1          // non-temporal colour loads/stores (colour is streamed once and never re-read by the tracker)
 #endif
@@ -481,22 +484,36 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         // Wait for them HERE (vmcnt(0) only): otherwise hipcc puts a vmcnt(0) at their first use inside the
         // pipelined loop, where it would drain the pipeline on every step.
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        // Three-stage software pipeline over the items of this block, unrolled by two so that the
-        // in-flight registers never have to be copied (a copy would force the wait):
-        //   step j:  S1(j) request pixel record | S3(j-2) average + store | S2(j-1) request {D,W}/colour
-        GatherState GA, GB;
-        UpdateState UA, UB;
-        GA.live = GB.live = false; GA.owned = GB.owned = false; GA.idx = GB.idx = 0; GA.pix = GB.pix = 0;
-        GA.pcx = GA.pcy = GA.pcz = GB.pcx = GB.pcy = GB.pcz = 0.0;
-        GA.P = GB.P = make_float4(0.f, 0.f, 0.f, 0.f); GA.N = GB.N = GA.P;
-        UA.live = UB.live = false; UA.owned = UB.owned = false; UA.idx = UB.idx = 0;
-        UA.d_new = UB.d_new = 0.f; UA.w_new = UB.w_new = 1.f; UA.wc = UB.wc = 0.f; UA.rgb = UB.rgb = 0u;
-        UA.old = UB.old = make_float2(0.f, 1.f); UA.col = UB.col = make_float4(1.f, 0.f, 0.f, 0.f);
-        for (int j = 0; j < cnt + 2; j += 2) {
-            step(j, GA, GB, UA, UB);          // S1(j)->GA   S2(j-1): GB->UA   S3(j-2): UB
-            step(j + 1, GB, GA, UB, UA);      // S1(j+1)->GB S2(j):   GA->UB   S3(j-1): UA
+        // Software pipeline over the items of this block, unrolled over one full rotation of the state registers so
+        // that in-flight registers never have to be copied (a copy would force the wait):
+        //   step j:  S1(j) request pixel record | S2(j-1) request {D,W}/colour | S3(j-1-DEPTH) average + store
+        // DEPTH = steps between the volume request of an item and its use: DEPTH + 1 update states rotate, i.e.
+        // DEPTH items' worth of HBM reads (1.5 KB each) stay in flight per wavefront.  The launch is bound by
+        // bytes in flight (Little's law: ~2 us loaded HBM latency x 5 TB/s = 10 MB chip-wide = 2.4 KB per wavefront at
+        // 4 waves per SIMD), which one item per wavefront does not supply.
+        constexpr int NU = TSDF_INTEGRATE_DEPTH + 1, NG = 2;
+        constexpr int PERIOD = (NU % 2 == 0) ? NU : 2 * NU;
+        GatherState G[NG];
+        UpdateState U[NU];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            G[q].live = false; G[q].owned = false; G[q].idx = 0; G[q].pix = 0;
+            G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
+            G[q].P = make_float4(0.f, 0.f, 0.f, 0.f); G[q].N = G[q].P;
         }
-        // (steps run up to j >= cnt+1, so S3 has retired item cnt-1 inside the loop: nothing to drain)
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            U[q].live = false; U[q].owned = false; U[q].idx = 0;
+            U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].wc = 0.f; U[q].rgb = 0u;
+            U[q].old = make_float2(0.f, 1.f); U[q].col = make_float4(1.f, 0.f, 0.f, 0.f);
+        }
+        for (int j = 0; j < cnt + 1 + TSDF_INTEGRATE_DEPTH; j += PERIOD) {
+#pragma unroll
+            for (int q = 0; q < PERIOD; ++q)
+                // S1(j+q) -> G[q%2];  S2(j+q-1): G[(q+1)%2] -> U[q%NU];  S3(j+q-1-DEPTH): U[(q+1)%NU] (the oldest)
+                step(j + q, G[q % NG], G[(q + 1) % NG], U[q % NU], U[(q + 1) % NU]);
+        }
+        // (steps run up to j >= cnt + DEPTH, so S3 has retired item cnt-1 inside the loop: nothing to drain)
     }
 
     // one atomic per counter per workgroup that updated anything: wave shuffle, then LDS across the 4 waves
@@ -763,9 +780,28 @@ __device__ __forceinline__ void voxel_of(const TrackParams& p, const double* R, 
     vz = (wz - p.g.origin[2]) * (double)p.g.m_div_d - 0.5;
 }
 
+struct TrackFold {               // in-launch fan-in of the per-workgroup rows (null ctr = rows only, folded by later launches)
+    unsigned* ctr;               // kTrackShards shard counters + 1 top counter, one 128-byte line each, zero between passes
+    double* shard_rows;          // kTrackShards x kPartWidth
+    double* red_dev;             // kRedWidth: result row for an in-stream all-reduce (may be null)
+    double* host_row;            // pinned host (or shared-segment alias): kRedWidth doubles + the word (may be null)
+    unsigned long long word;     // what is released behind host_row once it is complete
+    double tag;                  // pass number carried by every row (last column): a stale row cannot pass for a fresh one
+};
+
+// sc1 (device-scope, L1-bypassing, write-through) accesses for data handed from one workgroup to another inside a
+// launch: the per-CU vector L1 is never refreshed by other CUs' stores and the per-XCD L2s are not coherent
+// (MI355X_MICROARCH.md, inter-workgroup visibility).
+__device__ __forceinline__ void store_sc1(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_sc1(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const float2* __restrict__ dw,
                                                              const float4* __restrict__ samples,
-                                                             double* __restrict__ partials) {
+                                                             double* __restrict__ partials, TrackFold fold) {
     constexpr int NW = kTrackBlock / 64;
     __shared__ unsigned long long s_in[1], s_oog[1];       // the 64-sample window of this workgroup
     __shared__ unsigned long long s_in2[NW], s_oog2[NW];   // look-ahead windows
@@ -957,7 +993,149 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         else if (qq == 2 && e == 5) slot = kPartOog;
         else if (qq == 3 && e == 5) slot = kPartNan;
         else if (qq == 4 && e == 5) slot = kPartSamples;
-        if (slot >= 0) partials[(long long)blockIdx.x * kPartWidth + slot] = v;
+        if (fold.ctr == nullptr) {
+            if (slot >= 0) partials[(long long)blockIdx.x * kPartWidth + slot] = v;
+        } else {
+            if (qq == 7 && e == 7) { slot = kPartWidth - 1; v = fold.tag; }
+            if (slot >= 0) store_sc1(&partials[(long long)blockIdx.x * kPartWidth + slot], v);
+        }
+    }
+    if (fold.ctr == nullptr) return;
+
+    // ---- in-launch fan-in (no second launch, no host-side fold): every workgroup has written its row write-through;
+    // one lane arrives on the counter of its shard (blockIdx % 8: workgroups b and b + 8 share an XCD, so a shard's
+    // arrivals stay on one L2 -- speed only, nothing depends on the placement); the workgroup whose arrival completes a
+    // shard folds that shard's rows in row order and arrives on the top counter; the workgroup that completes the top
+    // counter adds the shard rows in shard order and hands the result out.  Every sum has a fixed order: the result
+    // does not depend on which workgroups happen to arrive last.  Protocol (MI355X_MICROARCH.md, valid forms): sc1
+    // stores -> the storing wave's s_waitcnt vmcnt(0) -> ONE lane's device-scope atomic add; the reader is told by the
+    // value its own add returned and loads (sc1) only after that.
+    __shared__ int s_role;
+    __shared__ double s_fold[kTrackBlock / kPartWidth][kPartWidth];
+    const unsigned n_wg = gridDim.x;
+    const unsigned n_shards = n_wg < (unsigned)kTrackShards ? n_wg : (unsigned)kTrackShards;
+    const unsigned shard = blockIdx.x % kTrackShards;
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave wrote the row: drained before the arrival
+        if (tid == 0) {
+            const unsigned in_shard = (n_wg - shard + kTrackShards - 1) / kTrackShards;
+            const unsigned old = __hip_atomic_fetch_add(&fold.ctr[32 * shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_role = (old == in_shard - 1u) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (s_role == 0) return;
+
+    constexpr int RG = kTrackBlock / kPartWidth;                      // row groups of kPartWidth columns
+    const int col = tid % kPartWidth, rg = tid / kPartWidth;
+    bool stale = false;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        double v = 0.0;
+        bool bad = false;
+        if (rg < RG) {
+            // rows shard, shard + 8, ...: this thread adds every RG-th of them, in order
+            double part[8];
+            unsigned r = shard + (unsigned)kTrackShards * (unsigned)rg;
+            while (r < n_wg) {
+                int nld = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {                         // 8 loads in flight, summed in row order
+                    const unsigned ru = r + (unsigned)(kTrackShards * RG) * (unsigned)u;
+                    part[u] = ru < n_wg ? load_sc1(&partials[(long long)ru * kPartWidth + col]) : 0.0;
+                    nld += ru < n_wg ? 1 : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u < nld) {
+                        if (col == kPartWidth - 1) bad |= part[u] != fold.tag;
+                        v += part[u];
+                    }
+                }
+                r += (unsigned)(kTrackShards * RG) * 8u;
+            }
+            s_fold[rg][col] = v;
+        }
+        stale = __syncthreads_or(bad ? 1 : 0) != 0;
+        if (!stale) break;
+        // a row of another pass: not expected with the protocol above; invalidate this CU's L1 and read again
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (tid < kPartWidth) {
+        double v = s_fold[0][tid];
+        for (int g2 = 1; g2 < RG; ++g2) v += s_fold[g2][tid];
+        if (tid == kPartWidth - 1) v = stale ? -1.0 : fold.tag;       // the shard row's own tag
+        store_sc1(&fold.shard_rows[shard * kPartWidth + tid], v);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&fold.ctr[32 * kTrackShards], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_role = (old == n_shards - 1u) ? 2 : 0;
+        }
+    }
+    __syncthreads();
+    if (s_role != 2) return;
+
+    // ---- the last shard: add the shard rows in shard order, convert to the result row, hand it out
+    __shared__ double s_tot[kPartWidth];
+    __shared__ double s_res[kRedWidth];
+    stale = false;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        bool bad = false;
+        if (rg < (int)n_shards && rg < RG) {
+            const double v = load_sc1(&fold.shard_rows[rg * kPartWidth + col]);
+            if (col == kPartWidth - 1) bad = v != fold.tag;
+            s_fold[rg][col] = v;
+        }
+        stale = __syncthreads_or(bad ? 1 : 0) != 0;
+        if (!stale) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    static_assert(kTrackShards <= kTrackBlock / kPartWidth, "one row group per shard in the final sum");
+    if (tid < kPartWidth) {
+        double v = s_fold[0][tid];
+        for (unsigned g2 = 1; g2 < n_shards; ++g2) v += s_fold[g2][tid];
+        s_tot[tid] = v;
+    }
+    __syncthreads();
+    if (tid < kRedWidth) {
+        double v = 0.0;
+        if (tid < 21) {
+            // upper triangle, row-major: (a,b) with a <= b  ->  product slot of q = a or q = b
+            int a = 0, e = tid;
+            while (e >= 6 - a) { e -= 6 - a; ++a; }
+            const int b = a + e, d = b - a;
+            v = (d <= 3) ? s_tot[5 * a + d] : s_tot[5 * b + (6 - d)];  // (a,b) = (q,(q+d')%6) with q = b, d' = 6-d
+        } else if (tid < 27) v = s_tot[5 * (tid - 21) + 4];
+        else if (tid == 27) v = s_tot[kPartTerms];
+        else if (tid == 28) v = s_tot[kPartViol];
+        else if (tid == 29) v = s_tot[kPartOk];
+        else if (tid == 30) v = s_tot[kPartInOwned];
+        else if (tid == 31) v = s_tot[kPartOog];
+        else if (tid == 32) v = s_tot[kPartNan];
+        else if (tid == 33) v = s_tot[kPartSamples];
+        // a row that stayed stale through two L1 invalidations: the hand-off protocol is broken; poison the term
+        // count so that the host refuses the pass instead of solving with an old row
+        if (stale && tid == 27) v = __longlong_as_double(0x7ff8000000000000ll);
+        if (fold.red_dev) fold.red_dev[tid] = v;
+        s_res[tid] = v;
+    }
+    // the counters go back to zero for the next pass (launches of one stream are ordered; nobody else is left in this one)
+    if (tid <= kTrackShards) __hip_atomic_store(&fold.ctr[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // host hand-off without a stream synchronisation: one wave writes the row to pinned host memory, fences at system
+    // scope, then releases the word the host spins on
+    if (fold.host_row && tid < 64) {
+        if (tid < kRedWidth) fold.host_row[tid] = s_res[tid];
+        __threadfence_system();
+        if (tid == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(fold.host_row + kRedWidth), fold.word, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1078,7 +1256,8 @@ hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, c
                         unsigned long long seq) {
     const int nb = track_num_blocks(p.n_samples);
     if (nb <= 0) return hipErrorInvalidValue;
-    track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials);
+    TrackFold none{};
+    track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, none);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // unwritten counter slots of the rows (37..39) are never read into a result; terms/counters are all written
@@ -1090,6 +1269,26 @@ hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, c
     track_final_kernel<<<dim3(1), dim3(256), 0, s>>>(folded, fb, red_dev, red_host, seq);
     return hipGetLastError();
 }
+
+// One launch per pass: rows, fan-in and result row inside track_kernel.  ctr: track_fold_counter_words() unsigned, zero
+// before the first pass (the kernel re-zeroes them); shard rows live behind the per-workgroup rows in `partials`.
+hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
+                               double* partials, unsigned* ctr, double* red_dev, double* host_row,
+                               unsigned long long word, unsigned long long pass) {
+    const int nb = track_num_blocks(p.n_samples);
+    if (nb <= 0) return hipErrorInvalidValue;
+    TrackFold f;
+    f.ctr = ctr;
+    f.shard_rows = partials + (size_t)nb * kPartWidth;
+    f.red_dev = red_dev;
+    f.host_row = host_row;
+    f.word = word;
+    f.tag = (double)(pass & 0xFFFFFFFFFFFFull);
+    track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, f);
+    return hipGetLastError();
+}
+
+size_t track_fold_counter_words() { return 32 * (size_t)(kTrackShards + 1); }
 
 // ------------------------------------------------------------------------------------------------
 // (de)interleave helpers for tsdf_download / tsdf_upload (reference-order host mirrors)
