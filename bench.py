@@ -233,7 +233,7 @@ def pmc_traffic(args, wl_args):
     try:
         for gi, group in enumerate(PMC_GROUPS):
             d = os.path.join(work, "g%d" % gi)
-            cmd = ["rocprofv3", "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "--", sys.executable,
+            cmd = ["rocprofv3", "--pmc"] + list(group) + ["--kernel-include-regex", "tsdf::(integrate|clip_rows)", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-child", "--steps", "12", "--warmup", "2"] + wl_args
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -532,73 +532,107 @@ def run(args):
     if n1_extras or (world == 1 and not args.no_cpu_baseline):
         host_frames = [(x.cpu().numpy(), n.cpu().numpy(), c.cpu().numpy()) for x, n, c in d_frames]
 
+    # Everything below is extra to the timed region above: a leg that fails must not take the result line with it.
+    # Every rank runs the same legs; after each one the ranks agree on whether all of them got through, and skip the
+    # rest together otherwise (a rank alone in a collective would hang the job).
+    state = {"leg": leg, "frames": d_frames, "kind": allreduce_kind, "go": True}
+
+    def guarded(name, fn):
+        if not state["go"]:
+            return
+        ok = True
+        try:
+            fn()
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            extras[name + "_error"] = f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: extra leg '{name}' failed: {e}", file=sys.stderr)
+        if world > 1:
+            ok = all_agree(ok)
+        state["go"] = ok
+
     # ---- PCIe-inclusive rates (H2D of the images + track + integrate), same frames, volume restarted
-    if n1_extras:
-        leg.restart()
-        e2, _, _ = leg.timed_region(d_frames, "host", host_frames, events=False)
+    def leg_h2d():
+        lg = state["leg"]
+        lg.restart()
+        e2, _, _ = lg.timed_region(d_frames, "host", host_frames, events=False)
         extras["value_h2d_inclusive"] = args.steps / e2
         extras["h2d_inclusive_note"] = ("xyz + normals + rgb (27 B/pixel) handed over as HOST buffers every frame through "
                                         "tsdf_set_frame: staging copy + H2D + pack on the frame side stream, overlapping the "
                                         "previous integration")
         depth16 = [np.where(np.isnan(x[..., 2]), 0, np.round(x[..., 2] * 5000.0)).astype(np.uint16) for x, _, _ in host_frames]
-        leg.restart()
-        e3, _, _ = leg.timed_region(d_frames, "depth", host_frames, depth16, events=False)
+        lg.restart()
+        e3, _, _ = lg.timed_region(d_frames, "depth", host_frames, depth16, events=False)
         extras["value_depth_input_inclusive"] = args.steps / e3
         extras["depth_input_note"] = ("raw uint16 depth + rgb (5 B/pixel) as host buffers; back-projection, bilateral filter "
                                       "and normals on the GPU (tsdf_set_depth_frame; PCL parity of that stage is unpinned)")
-        del depth16
+    if n1_extras:
+        guarded("h2d_inclusive", leg_h2d)
 
     # ---- N > 1: the same timed region with the other exchange step, for comparison
+    def leg_other_exchange():
+        lg = state["leg"]
+        kind2 = setup_exchange(lg.sdf, "shm")
+        if kind2.startswith("shared"):
+            lg.restart()
+            e4, _, _ = lg.timed_region(d_frames, events=False)
+            extras["value_with_shared_memory_fan_in"] = args.steps / e4
+        state["kind"] = setup_exchange(lg.sdf, "rccl")
+        dist.barrier()
     if world > 1 and not args.no_extras and args.dist_backend == "nccl" and allreduce_kind == "rccl-in-library" \
             and "shm" in exchange_us:
-        kind2 = setup_exchange(sdf, "shm")
-        if kind2.startswith("shared"):
-            leg.restart()
-            e4, _, _ = leg.timed_region(d_frames, events=False)
-            extras["value_with_shared_memory_fan_in"] = args.steps / e4
-        allreduce_kind = setup_exchange(sdf, "rccl")
-        dist.barrier()
+        guarded("other_exchange", leg_other_exchange)
 
     # ---- full fr1/plant sequence (1246 frames): ATE-RMSE and tracking failures at 256^3 and at the benchmark m
-    if n1_extras and not args.no_full_sequence and args.config in (2, 3) and args.frame_step == 1:
-        leg.close()
+    def leg_full_sequence():
+        state["leg"].close()
+        state["leg"] = None
         torch.cuda.empty_cache()
         extras["full_sequence"] = full_sequence(ts, synth, torch, dev, dev_index, sorted({256, m}), width, height, noise,
                                                 not args.no_color)
         extras["ate_full_sequence_m"] = extras["full_sequence"][str(m)]["ate_rmse_m"]
-        leg = None
+    if n1_extras and not args.no_full_sequence and args.config in (2, 3) and args.frame_step == 1:
+        guarded("full_sequence", leg_full_sequence)
 
     # ---- a config-5-shaped leg (weak scaling: m = 2048 (N/8)^(1/3), 1280x960), a few frames
-    if not args.no_extras and not args.no_weak_leg and args.config == 3 and (world > 1 or n1_extras):
-        if leg is not None:
-            leg.close()
-            leg = None
-        del d_frames
-        d_frames = None
+    def leg_weak():
+        if state["leg"] is not None:
+            state["leg"].close()
+            state["leg"] = None
+        state["frames"] = None
         torch.cuda.empty_cache()
         m5, w5, h5, label5, _ = resolve(5)
         keep = (args.steps, args.warmup)
         args.steps, args.warmup = min(keep[0], 12), min(keep[1], 2)
-        seq5, fr5 = render_frames(w5, h5, 1 + args.warmup + args.steps, 1)
-        leg5 = Leg(m5, w5, h5, seq5.K)
-        if world > 1:
-            setup_exchange(leg5.sdf, "rccl" if allreduce_kind.startswith("rccl") else ("shm" if allreduce_kind.startswith("shared") else "torch"))
-        e5, tm5, cn5 = leg5.timed_region(fr5)
-        l5 = max(1, cn5["integrate_calls"])
-        t5 = max(1, tm5["integrate_launches"])
-        ms5 = tm5["integrate_ms"] / t5
-        bpv = 16 if args.no_color else 48
-        upd5 = (cn5["n_updated"] + cn5["n_updated_halo"]) / l5
-        extras["weak_leg"] = {"workload": label5, "m": m5, "image": [w5, h5], "n_gpus": world, "scaling": "weak",
-                              "halo": leg5.halo, "steps": args.steps, "value": args.steps / e5, "unit": "frames/s",
-                              "ms_per_step": 1e3 * e5 / args.steps, "integrate_launch_ms_rank0": ms5,
-                              "updated_voxels_per_launch_rank0": upd5,
-                              "integrate_GBs_rank0": (bpv * upd5 + w5 * h5 * 32) / (ms5 * 1e-3) / 1e9 if ms5 > 0 else None,
-                              "gn_iterations_per_frame": cn5["track_iterations"] / max(1, cn5["track_calls"])}
-        args.steps, args.warmup = keep
-        leg5.close()
-        del fr5
-        torch.cuda.empty_cache()
+        leg5 = None
+        try:
+            seq5, fr5 = render_frames(w5, h5, 1 + args.warmup + args.steps, 1)
+            leg5 = Leg(m5, w5, h5, seq5.K)
+            if world > 1:
+                k = state["kind"]
+                setup_exchange(leg5.sdf, "rccl" if k.startswith("rccl") else ("shm" if k.startswith("shared") else "torch"))
+            e5, tm5, cn5 = leg5.timed_region(fr5)
+            l5 = max(1, cn5["integrate_calls"])
+            t5 = max(1, tm5["integrate_launches"])
+            ms5 = tm5["integrate_ms"] / t5
+            bpv5 = 16 if args.no_color else 48
+            upd5 = (cn5["n_updated"] + cn5["n_updated_halo"]) / l5
+            extras["weak_leg"] = {"workload": label5, "m": m5, "image": [w5, h5], "n_gpus": world, "scaling": "weak",
+                                  "halo": leg5.halo, "steps": args.steps, "value": args.steps / e5, "unit": "frames/s",
+                                  "ms_per_step": 1e3 * e5 / args.steps, "integrate_launch_ms_rank0": ms5,
+                                  "updated_voxels_per_launch_rank0": upd5,
+                                  "integrate_GBs_rank0": (bpv5 * upd5 + w5 * h5 * 32) / (ms5 * 1e-3) / 1e9 if ms5 > 0 else None,
+                                  "gn_iterations_per_frame": cn5["track_iterations"] / max(1, cn5["track_calls"])}
+        finally:
+            args.steps, args.warmup = keep
+            if leg5 is not None:
+                leg5.close()
+            torch.cuda.empty_cache()
+    if not args.no_extras and not args.no_weak_leg and args.config == 3 and (world > 1 or n1_extras):
+        d_frames = None
+        guarded("weak_leg", leg_weak)
+    leg = state["leg"]
+    allreduce_kind = state["kind"]
 
     if rank == 0:
         gt = seq.t[:len(est_main)]

@@ -18,6 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "build", "pmc_calibrate")
+KERNELS = "cal_"      # counters are collected for these kernels only (every profiled dispatch is serialised)
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
           ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum"],
           ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]]
@@ -30,7 +31,7 @@ def collect(cmd_tail, out, tag):
     for i, counters in enumerate(PASSES):
         d = os.path.join(out, "%s_pass%d" % (tag, i))
         shutil.rmtree(d, ignore_errors=True)
-        p = subprocess.run(["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--"] + cmd_tail,
+        p = subprocess.run(["rocprofv3", "--pmc"] + counters + ["--kernel-include-regex", KERNELS, "--output-format", "csv", "-d", d, "--"] + cmd_tail,
                            cwd="/tmp", env=env, capture_output=True, text=True)
         if p.returncode != 0:
             sys.exit("pass %s failed: %s" % (counters, p.stderr[-2000:]))

@@ -22,6 +22,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CMD = [sys.executable, os.path.join(ROOT, "tools", "bench_kernels.py"), "--frames", "12", "--passes", "8", "--no-track-timing"]
+PASS_TIMEOUT = 75
+KERNELS = "tsdf::"      # counters are collected for these kernels only (every profiled dispatch is serialised)
 PASSES = [
     ["GRBM_GUI_ACTIVE", "TCP_GATE_EN1_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum"],
     ["TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCR_TCP_STALL_CYCLES_sum"],
@@ -37,10 +39,20 @@ PASSES = [
 ]
 
 
+QUICK = [4, 5, 6]      # L2 hit rate + memory-side read / write requests by size: the traffic of a launch
+
+
 def main():
     out = os.path.abspath(sys.argv[1])
     tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
     extra = sys.argv[3:]
+    global PASSES
+    if extra and extra[0] == "--quick":
+        extra = extra[1:]
+        PASSES = [PASSES[i] for i in QUICK]
+    elif extra and extra[0].startswith("--passes="):
+        PASSES = [PASSES[int(i)] for i in extra[0].split("=")[1].split(",")]
+        extra = extra[1:]
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     kern = {}
@@ -48,12 +60,19 @@ def main():
     for i, counters in enumerate(PASSES):
         d = os.path.join(out, "%s_ms_pass%d" % (tag, i))
         shutil.rmtree(d, ignore_errors=True)
-        p = subprocess.run(["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--"] + CMD + extra,
-                           cwd="/tmp", env=env, capture_output=True, text=True)
+        try:      # a counter group the profiler cannot schedule can take forever: give every pass a bounded time
+            p = subprocess.run(["rocprofv3", "--pmc"] + counters + ["--kernel-include-regex", KERNELS, "--output-format", "csv", "-d", d, "--"] + CMD + extra,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=PASS_TIMEOUT)
+        except subprocess.TimeoutExpired:
+            failed.append({"counters": counters, "stderr": "timed out after %d s" % PASS_TIMEOUT})
+            print("pass", i, counters, "TIMED OUT", flush=True)
+            continue
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if p.returncode != 0 or not files:
             failed.append({"counters": counters, "stderr": p.stderr[-400:]})
+            print("pass", i, counters, "FAILED", flush=True)
             continue
+        print("pass", i, "ok", flush=True)
         with open(files[0]) as f:
             for r in csv.DictReader(f):
                 if r["Counter_Name"] not in counters:

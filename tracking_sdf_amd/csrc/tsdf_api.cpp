@@ -56,7 +56,8 @@ struct tsdf_handle {
     unsigned long long* counters = nullptr;     // device, kNumCounters
     unsigned long long* counters_host = nullptr;  // pinned
     unsigned* worklist = nullptr;  // integrate work items (row << 6 | chunk)
-    unsigned* work_count = nullptr;
+    unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
+    unsigned* rowinfo = nullptr;      // per voxel row: first chunk, chunk count, image band
     int integrate_blocks = 0;      // persistent grid of integrate_kernel
     double* rowbase = nullptr;     // per-row share of rot_inv * g (3 doubles per row)
     int integrate_debug = 0;       // timing experiments; only honoured by builds with -DTSDF_INTEGRATE_DEBUG=1
@@ -92,10 +93,8 @@ struct tsdf_handle {
     double* red_dev = nullptr;     // kRedWidth
     double* red_host = nullptr;    // pinned, kRedWidth doubles + the pass-number word the host polls
     unsigned long long pass_seq = 0;
-    double* fold_host = nullptr;   // pinned: kFoldBlocks slots of kFoldSlotDoubles (single-rank host fold)
-    bool host_fold = true;         // shared-memory fan-in: the host publishes this rank's row (TSDF_HOST_FOLD=0: the device writes the slot)
-    bool fold_in_launch = true;    // fan-in of the per-workgroup rows inside track_kernel (TSDF_TRACK_FOLD=launches: extra launches)
-    unsigned* fold_ctr = nullptr;  // its arrival counters
+    bool host_fold = true;         // shared-memory fan-in: the host publishes this rank's row (TSDF_HOST_FOLD=0: the device writes the slot itself)
+    unsigned* fold_ctr = nullptr;  // arrival counters of the in-launch fan-in of track_kernel
     unsigned integrate_launches = 0;
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
 
@@ -407,29 +406,18 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     const bool use_rccl = reduce_ranks && h->comm.active();
     const bool use_shm = reduce_ranks && !use_rccl && h->shm.active();
     const unsigned long long seq = ++h->pass_seq;
-    double* host_row = h->red_host;          // where the final kernel publishes this rank's row
-    if (use_shm && h->shm.dev_base)
-        host_row = reinterpret_cast<double*>(h->shm.dev_base + shm_slot_offset(h, h->shm.rank, seq));   // used when the device publishes
-    // polling + no RCCL: the folded rows come to the host directly (one dependent launch fewer); with the
-    // shared-memory fan-in the host then publishes this rank's row itself (a host-memory store instead of a
-    // device write over PCIe)
-    // Legacy path (TSDF_TRACK_FOLD=launches, for A/B measurements): rows folded by a second launch and, single rank,
-    // on the host.  Default: the fan-in runs inside track_kernel and the finished row arrives in `host_row`.
-    const bool host_fold = !h->fold_in_launch && h->host_fold && !use_rccl && h->poll && !h->timing_track;
-    const bool dev_publish_shm = use_shm && h->shm.dev_base && (h->fold_in_launch ? !h->host_fold : !host_fold);
-    if (use_shm && !h->shm.dev_base && (h->fold_in_launch ? !h->host_fold : !host_fold))
-        return fail(h, TSDF_E_COMM, "shared-memory fan-in without the host publishing needs the segment registered with HIP, which failed");
-    if (!dev_publish_shm) host_row = h->red_host;
-    if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
-    // the word the device publishes behind its row: the pass number, or (device-published shared-memory slot) the
-    // generation-tagged word the other ranks wait for
+    // Where the last workgroup of track_kernel publishes this rank's finished row: pinned host memory (the host then
+    // also publishes it into the shared segment with a host store), or -- TSDF_HOST_FOLD=0 -- straight into this rank's
+    // slot of the shared segment through its device alias, tagged with the generation the other ranks wait for.
+    const bool dev_publish_shm = use_shm && !h->host_fold;
+    if (dev_publish_shm && !h->shm.dev_base)
+        return fail(h, TSDF_E_COMM, "shared-memory fan-in with device publishing needs the segment registered with HIP, which failed");
+    double* host_row = dev_publish_shm
+        ? reinterpret_cast<double*>(h->shm.dev_base + shm_slot_offset(h, h->shm.rank, seq)) : h->red_host;
     const unsigned long long dev_word = dev_publish_shm ? shm_word(h, seq) : seq;
-    if (h->fold_in_launch)
-        HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
-                                       use_rccl ? nullptr : host_row, dev_word, seq));
-    else
-        HIP_TRY(h, launch_track(h->stream, p, h->dw, h->samples, h->partials, h->red_dev,
-                                use_rccl ? nullptr : host_row, host_fold ? h->fold_host : nullptr, dev_word));
+    if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
+    HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
+                                   use_rccl ? nullptr : host_row, dev_word, seq));
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
     if (use_rccl) {
         std::string cerr;
@@ -440,50 +428,12 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
                                        h->stream));
     }
     bool arrived = false;
-    if (host_fold) {
-        const int fb = track_fold_blocks(h->n_samples);
-        double tot[kPartWidth];
-        for (int e = 0; e < kPartWidth; ++e) tot[e] = 0.0;
-        const auto t0 = std::chrono::steady_clock::now();
-        bool all = true;
-        for (int b = 0; b < fb && all; ++b) {
-            const double* slot = h->fold_host + (size_t)b * kFoldSlotDoubles;
-            const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(slot + kPartWidth);
-            for (unsigned spins = 0;; ++spins) {
-                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
-                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { all = false; break; }
-            }
-        }
-        if (!all) HIP_TRY(h, hipStreamSynchronize(h->stream));   // a row did not show up in time: synchronise for real
-        // the summation order of the device-side final kernel (6 interleaved row groups, then the groups), so
-        // that every exchange mode produces the same bits
-        constexpr int RG = 256 / kPartWidth;
-        for (int e = 0; e < kPartWidth; ++e) {
-            double sg[RG];
-            for (int g = 0; g < RG; ++g) {
-                double v = 0.0;
-                for (int b = g; b < fb; b += RG) v += h->fold_host[(size_t)b * kFoldSlotDoubles + e];
-                sg[g] = v;
-            }
-            double v = sg[0];
-            for (int g = 1; g < RG; ++g) v += sg[g];
-            tot[e] = v;
-        }
-        track_unpack_row(tot, h->red_host);
-        arrived = true;
-        if (use_shm) {
-            char* slot = h->shm.base + shm_slot_offset(h, h->shm.rank, seq);
-            std::memcpy(slot, h->red_host, kRedWidth * sizeof(double));
-            __atomic_store_n(reinterpret_cast<unsigned long long*>(slot + kRedWidth * sizeof(double)), shm_word(h, seq), __ATOMIC_RELEASE);
-            int rc2 = shm_fan_in(h, seq, kRedAllreduce);
-            if (rc2) return rc2;
-        }
-    } else if (dev_publish_shm) {
+    if (dev_publish_shm) {
         int rc2 = shm_fan_in(h, seq, kRedAllreduce);
         if (rc2) return rc2;
         arrived = true;
     } else if (h->poll) {
-        // The final (or publish) kernel releases the pass number after the row (system scope); spinning on
+        // The last workgroup (or the publish kernel) releases the pass number after the row (system scope); spinning on
         // it saves the runtime's completion-signal path.  Bounded: fall back to a real synchronisation.
         volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(h->red_host + kRedWidth);
         const auto t0 = std::chrono::steady_clock::now();
@@ -494,7 +444,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         }
     }
     if (!arrived) HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (use_shm && !dev_publish_shm && !host_fold) {
+    if (use_shm && !dev_publish_shm) {
         // this rank's finished row is in red_host: publish it with a host store, then add everybody's rows
         char* slot = h->shm.base + shm_slot_offset(h, h->shm.rank, seq);
         std::memcpy(slot, h->red_host, kRedWidth * sizeof(double));
@@ -677,10 +627,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMemsetAsync(h->counters, 0, kNumCounters * sizeof(unsigned long long), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->counters_host, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
     CREATE_TRY(hipMalloc((void**)&h->worklist, integrate_worklist_entries(g) * sizeof(unsigned)));
-    CREATE_TRY(hipMalloc((void**)&h->work_count, 2 * sizeof(unsigned)));
-    CREATE_TRY(hipMemsetAsync(h->work_count, 0, 2 * sizeof(unsigned), h->stream));
-    CREATE_TRY(hipHostMalloc((void**)&h->fold_host, (size_t)kFoldBlocks * kFoldSlotDoubles * sizeof(double), hipHostMallocDefault));
-    std::memset(h->fold_host, 0, (size_t)kFoldBlocks * kFoldSlotDoubles * sizeof(double));
+    CREATE_TRY(hipMalloc((void**)&h->work_count, integrate_bookkeeping_words() * sizeof(unsigned)));
+    CREATE_TRY(hipMemsetAsync(h->work_count, 0, integrate_bookkeeping_words() * sizeof(unsigned), h->stream));
+    CREATE_TRY(hipMalloc((void**)&h->rowinfo, (integrate_rowbase_entries(g) / 3) * sizeof(unsigned)));
     CREATE_TRY(hipMalloc((void**)&h->rowbase, integrate_rowbase_entries(g) * sizeof(double)));
     {
         hipDeviceProp_t prop;
@@ -695,7 +644,6 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
     { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
     { const char* ev = std::getenv("TSDF_HOST_FOLD"); h->host_fold = !(ev && std::atoi(ev) == 0); }
-    { const char* ev = std::getenv("TSDF_TRACK_FOLD"); h->fold_in_launch = !(ev && std::strcmp(ev, "launches") == 0); }
     CREATE_TRY(hipMalloc((void**)&h->fold_ctr, track_fold_counter_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, track_fold_counter_words() * sizeof(unsigned), h->stream));
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
@@ -725,11 +673,11 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
-    if (h->fold_host) (void)hipHostFree(h->fold_host);
     if (h->fold_ctr) (void)hipFree(h->fold_ctr);
     if (h->counters) (void)hipFree(h->counters);
     if (h->worklist) (void)hipFree(h->worklist);
     if (h->work_count) (void)hipFree(h->work_count);
+    if (h->rowinfo) (void)hipFree(h->rowinfo);
     if (h->rowbase) (void)hipFree(h->rowbase);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->sample_vox) (void)hipFree(h->sample_vox);
@@ -916,7 +864,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     EventPair* ep;
     rc = timed_begin(h, 0, &ep, h->stream);
     if (rc) return rc;
-    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
+    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count, h->rowinfo,
                                 h->rowbase, h->integrate_blocks, h->integrate_launches++));
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;

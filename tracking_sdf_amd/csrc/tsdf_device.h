@@ -21,30 +21,14 @@ constexpr int kRedAllreduce = 30;   // the leading part that is summed over rank
 // d <= 3 and r*J[q] for d = 4, then counters
 constexpr int kPartTerms = 30, kPartViol = 31, kPartOk = 32, kPartInOwned = 33, kPartOog = 34, kPartNan = 35,
               kPartSamples = 36, kPartWidth = 40;
-#ifndef TSDF_FOLD_BLOCKS
-#define TSDF_FOLD_BLOCKS 32   // measured: 64 rows 3373, 32 rows 3432, 16 rows 3380, 8 rows 3285 frames/s
-#endif
-constexpr int kFoldBlocks = TSDF_FOLD_BLOCKS;          // rows left after track_fold_kernel
-constexpr int kFoldSlotDoubles = 48;     // pinned host slot per folded row: 40 values + pass-number word + pad
-
-// partial row (kPartWidth) -> result row (kRedWidth); shared by track_final_kernel's logic and the host fold
-inline void track_unpack_row(const double* tot, double* red) {
-    int e = 0;
-    for (int a = 0; a < 6; ++a)
-        for (int b = a; b < 6; ++b) {
-            const int d = b - a;
-            red[e++] = (d <= 3) ? tot[5 * a + d] : tot[5 * b + (6 - d)];
-        }
-    for (int a = 0; a < 6; ++a) red[21 + a] = tot[5 * a + 4];
-    red[27] = tot[kPartTerms]; red[28] = tot[kPartViol]; red[29] = tot[kPartOk]; red[30] = tot[kPartInOwned];
-    red[31] = tot[kPartOog]; red[32] = tot[kPartNan]; red[33] = tot[kPartSamples];
-}
-
 #ifndef TSDF_TRACK_BLOCK
 #define TSDF_TRACK_BLOCK 384   // 640x480: 714 workgroups = 2.8 per CU (256 threads: 4.2 per CU, i.e. a fifth one on some); measured 13.5 -> 13.1 us, fold 4.8 -> 4.2 us
 #endif
 constexpr int kTrackBlock = TSDF_TRACK_BLOCK;    // threads per tracker workgroup
-constexpr int kIntegrateBlock = 256;
+#ifndef TSDF_INTEGRATE_BLOCK
+#define TSDF_INTEGRATE_BLOCK 256
+#endif
+constexpr int kIntegrateBlock = TSDF_INTEGRATE_BLOCK;   // threads per integrate workgroup
 constexpr int kTrackShards = 8;                  // fan-in shards of the in-launch fold (blockIdx % 8: one per XCD)
 
 // Geometry of the stored part of the volume.  Device layout: one float2 {D,W} per voxel
@@ -98,27 +82,25 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
                        int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
                        float4* pn, float4* samples, int32_t ncols, int32_t nrows);
-// worklist: integrate_worklist_entries(g) unsigned; work_count: 1 unsigned; rowbase:
-// integrate_rowbase_entries(g) doubles; n_blocks: persistent grid size (CUs x integrate_blocks_per_cu()).
+// worklist: integrate_worklist_entries(g) unsigned; work_count: integrate_bookkeeping_words() unsigned, zero before the
+// first launch; rowinfo: one unsigned per row (integrate_rowbase_entries(g) / 3); rowbase: integrate_rowbase_entries(g)
+// doubles; n_blocks: persistent grid size (CUs x integrate_blocks_per_cu()).
 size_t integrate_worklist_entries(const Grid& g);
 size_t integrate_rowbase_entries(const Grid& g);
+size_t integrate_bookkeeping_words();
 int integrate_blocks_per_cu();
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            unsigned* worklist, unsigned* work_count /*two counters*/, double* rowbase, int n_blocks,
+                            unsigned* worklist, unsigned* work_count, unsigned* rowinfo, double* rowbase, int n_blocks,
                             unsigned launch_parity);
-// partials: track_partials_doubles(n_samples) doubles; red_dev: kRedWidth doubles; red_host (pinned, may
-// be null): kRedWidth doubles + one 64-bit word that receives `seq` after the row is complete.
-// fold_host (pinned, kFoldBlocks x kFoldSlotDoubles doubles, may be null): when given, the folded rows go to
-// the host and the final kernel is skipped (single-rank mode; the host adds the rows).
-hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                        double* partials, double* red_dev, double* red_host, double* fold_host,
-                        unsigned long long seq);
+// One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
+// ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
+// in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit
+// word that receives `word` after the row is complete; `pass` tags the rows of this pass.
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row,
                                unsigned long long word, unsigned long long pass);
 size_t track_fold_counter_words();
-int track_fold_blocks(int32_t n_samples);
 hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);
 size_t track_partials_doubles(int32_t n_samples);

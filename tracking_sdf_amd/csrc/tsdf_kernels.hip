@@ -4,7 +4,7 @@
 //   integrate_kernel   SDF::update over that list          (reference src/sdf.cpp:224-315)
 //   track_kernel       one Gauss-Newton accumulation pass    (reference src/camera_tracking.cpp:146-189,
 //                      + get_partial_derivative :246-363, SDF::interpolate_distance sdf.cpp:127-163)
-//   track_fold_kernel / track_final_kernel   fixed-order sum of the per-workgroup partial normal equations
+//                      incl. the fixed-order fan-in of the per-workgroup partial normal equations (one launch per pass)
 //   pack_kernel        per-frame image packing (xyz|nrm|rgb planes -> 32-byte pixel records + the
 //                      tracker's column-major stride-3 sample list, camera_tracking.cpp:162-163)
 //   sample_kernel, fill_kernel, split/merge kernels: interpolate_distance batches, constructor fill, host mirrors
@@ -158,17 +158,27 @@ __device__ __forceinline__ void clip_affine(double a, double b, double& lo, doub
     // (b == 0 and a within rounding of 0: leave it to the exact per-voxel test)
 }
 
+// Work-list bookkeeping of one launch: [0] = number of items, [1 .. kBins] = items per image band, [kBins + 1 ..
+// 2 kBins] = scatter cursors.  Two such sets are used alternately: the clip kernel of a launch re-zeroes the set the
+// NEXT launch will use (nobody touches it during this launch), which saves a memset per frame.
+constexpr int kBins = 64;
+constexpr int kBinSetWords = 2 * kBins + 2;
+
+// rowinfo word: bit 31 = the row has items, bits 16..21 = band, bits 8..15 = number of chunks, bits 0..7 = first chunk
 __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
-                                                                unsigned* __restrict__ list,
-                                                                unsigned* __restrict__ count,
-                                                                unsigned* __restrict__ next_count,
+                                                                unsigned* __restrict__ rowinfo,
+                                                                unsigned* __restrict__ set,
+                                                                unsigned* __restrict__ next_set,
                                                                 double* __restrict__ rowbase,
                                                                 unsigned long long* __restrict__ counters) {
     const int m = p.g.m;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
-    if (blockIdx.x == 0 && tid == 0) *next_count = 0u;
-    int c0 = 0, n = 0;
+    if (blockIdx.x == 0 && tid < kBinSetWords) next_set[tid] = 0u;
+    __shared__ unsigned s_hist[kBins];
+    if (tid < kBins) s_hist[tid] = 0u;
+    __syncthreads();
+    int c0 = 0, n = 0, bin = 0;
     if (row < tl.n_rows) {
         int il, j;
         if (tl.log2m >= 0) { il = (int)(row >> tl.log2m); j = (int)(row & (m - 1)); }
@@ -205,35 +215,73 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
                 const double l2 = floor(lo) - 1.0, h2 = ceil(hi) + 1.0;   // one voxel of slack per side
                 klo = l2 < 0.0 ? 0 : (l2 > (double)(m - 1) ? m : (int)l2);
                 khi = h2 > (double)(m - 1) ? m - 1 : (h2 < 0.0 ? -1 : (int)h2);
+                // Image band of the row = where the middle of its interval projects, along the image axis in which
+                // the pixel records are NOT contiguous (columns for column-major records).  Only ordering depends on
+                // it (which XCD integrates the row, next to which other rows), never a result.
+                const double km = 0.5 * ((double)klo + (double)khi);
+                const double den = a2 + km * b2;
+                const double coord = p.pix_sv == 1 ? (a0 + km * b0) / den : (a1 + km * b1) / den;
+                const double ext = p.pix_sv == 1 ? (double)p.width : (double)p.height;
+                const double fb = coord * ((double)kBins / ext);
+                bin = fb >= 0.0 ? (fb < (double)(kBins - 1) ? (int)fb : kBins - 1) : 0;       // NaN -> 0
             }
         }
         if (klo <= khi) {
             c0 = klo >> 6; n = (khi >> 6) - c0 + 1;
             rowbase[3 * row + 0] = S[0]; rowbase[3 * row + 1] = S[1]; rowbase[3 * row + 2] = S[2];
         }
+        rowinfo[row] = n ? (0x80000000u | ((unsigned)bin << 16) | ((unsigned)n << 8) | (unsigned)c0) : 0u;
     }
-    // exclusive scan of n over the workgroup: wave scan by shuffles, then the 4 wave totals through LDS
-    int incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    __shared__ int s_tot[kClipBlock / 64];
-    __shared__ unsigned s_base;
-    if (lane == 63) s_tot[wv] = incl;
+    if (n) atomicAdd(&s_hist[bin], (unsigned)n);
     __syncthreads();
-    int wave_off = 0, total = 0;
+    if (tid < kBins) {
+        unsigned hcnt = s_hist[tid];
+        if (hcnt) atomicAdd(&set[1 + tid], hcnt);
+        // workgroup total by a wave reduction over the 64 bands
+        for (int off = 32; off > 0; off >>= 1) hcnt += __shfl_xor(hcnt, off);
+        if (tid == 0 && hcnt) {
+            atomicAdd(&set[0], hcnt);
+            atomicAdd(&counters[kCntItems], (unsigned long long)hcnt);
+        }
+    }
+}
+
+// Second pass: the items of every row go to the part of the list that belongs to the row's image band (counting
+// sort by band; the order inside a band is whatever the atomics give -- every voxel belongs to exactly one item, so
+// no result depends on the order).  integrate_kernel hands each XCD one contiguous eighth of the list = a band of
+// the image whose pixel records (about 1.2 MB) then live in that XCD's L2: with the list in row order every XCD
+// gathered from the whole image, and 63 % of the launch's fabric reads were pixel records fetched again and again
+// (296 MB for a 9.8 MB image).
+__global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(long long n_rows, const unsigned* __restrict__ rowinfo,
+                                                                   unsigned* __restrict__ set, unsigned* __restrict__ list) {
+    static_assert(kBins == 64, "one wavefront scans the bands");
+    __shared__ unsigned s_start[kBins], s_wg[kBins], s_base[kBins];
+    const int tid = threadIdx.x;
+    const long long row = (long long)blockIdx.x * kClipBlock + tid;
+    if (tid < kBins) {
+        const unsigned hcnt = set[1 + tid];
+        unsigned incl = hcnt;
 #pragma unroll
-    for (int q = 0; q < kClipBlock / 64; ++q) { if (q < wv) wave_off += s_tot[q]; total += s_tot[q]; }
-    if (tid == 0) {
-        s_base = total ? atomicAdd(count, (unsigned)total) : 0u;
-        if (total) atomicAdd(&counters[kCntItems], (unsigned long long)total);
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off);
+            if (tid >= off) incl += t;
+        }
+        s_start[tid] = incl - hcnt;
+        s_wg[tid] = 0u;
     }
     __syncthreads();
-    unsigned at = s_base + (unsigned)(wave_off + incl - n);
-    const unsigned code = (unsigned)row << 6;
-    for (int q = 0; q < n; ++q) list[at + q] = code | (unsigned)(c0 + q);
+    const unsigned info = row < n_rows ? rowinfo[row] : 0u;
+    const unsigned n = (info >> 8) & 0xFFu, c0 = info & 0xFFu, bin = (info >> 16) & 0x3Fu;
+    unsigned rank = 0u;
+    if (info) rank = atomicAdd(&s_wg[bin], n);
+    __syncthreads();
+    if (tid < kBins) s_base[tid] = s_wg[tid] ? atomicAdd(&set[1 + kBins + tid], s_wg[tid]) : 0u;
+    __syncthreads();
+    if (info) {
+        const unsigned at = s_start[bin] + s_base[bin] + rank;
+        const unsigned code = (unsigned)row << 6;
+        for (unsigned q = 0; q < n; ++q) list[at + q] = code | (c0 + q);
+    }
 }
 
 // exp(x) for the weight of sdf.cpp:278.  x = -(d-eps)^2/2 lies in [-(delta-eps)^2/2, 0]; for
@@ -258,19 +306,16 @@ __device__ __forceinline__ double exp_taylor10(double x) {
     return r;
 }
 
-// Per-item state between the pipeline stages of integrate_kernel.
+// Per-item state between the pipeline stages of integrate_kernel.  Only what is per LANE lives here: the item code
+// (row, chunk) is wave-uniform and every stage reads it again from the block's code register with v_readlane, so
+// voxel addresses are a scalar base + the lane number (no 64-bit per-lane index is carried through the pipeline).
 struct GatherState {        // stage 1 done: pixel record requested
     bool live;
-    bool owned;
-    long long idx;          // voxel index inside the stored slab
-    long long pix;          // pixel record index
     double pcx, pcy, pcz;   // camera-frame voxel centre
     float4 P, N;            // pixel record (in flight until stage 2 reads it)
 };
 struct UpdateState {        // stage 2 done: volume reads requested
     bool live;
-    bool owned;
-    long long idx;
     float d_new, w_new;
     unsigned rgb;
     float2 old;             // {D, W}            (in flight until stage 3)
@@ -290,6 +335,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 #ifndef TSDF_INTEGRATE_NT
 #define TSDF_INTEGRATE_NT 1          // non-temporal colour loads/stores (colour is streamed once and never re-read by the tracker)
 #endif
+#ifndef TSDF_INTEGRATE_NT_DW
+#define TSDF_INTEGRATE_NT_DW 0       // experiment: {D,W} streamed non-temporally too (keeps the pixel records in L2?)
+#endif
 #ifndef TSDF_INTEGRATE_DEBUG
 #define TSDF_INTEGRATE_DEBUG 0      // 1 compiles the p.debug timing experiments in (uniform branches split the step)
 #endif
@@ -306,15 +354,19 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     const double cd = (double)p.g.cell_d;
     const float delta = p.g.delta, eps = p.g.epsilon;
     const unsigned n_items = *count;
-    const unsigned n_waves = gridDim.x * (kIntegrateBlock / 64);
+    constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
     // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
     // list = one x-range of the slab = one band of the image, so the pixel records it gathers stay in
     // its own L2 instead of every XCD streaming the whole 10 MB image through.
     const unsigned vblock = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const unsigned gwave = vblock * (kIntegrateBlock / 64) + wv;
-    // this wavefront's contiguous share of the work list (items of one row stay together)
-    const unsigned first = (unsigned)(((unsigned long long)n_items * gwave) / n_waves);
-    const unsigned last = (unsigned)(((unsigned long long)n_items * (gwave + 1)) / n_waves);
+    // The workgroup's contiguous share of the work list (items of one row stay together), dealt to its wavefronts
+    // ITEM BY ITEM: at any moment the NW wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring
+    // voxel rows, which project to the same few image columns -- the pixel-record lines one wavefront pulls into the
+    // CU's L1 serve the others.  (Measured with one contiguous range per wavefront: 63 % of the launch's fabric reads,
+    // 296 MB for a 9.8 MB image, were pixel records fetched again and again -- every wavefront of the CU was gathering
+    // from another part of the image and the L1 turned over several times per step.)
+    const unsigned wg_first = (unsigned)(((unsigned long long)n_items * vblock) / gridDim.x);
+    const unsigned wg_last = (unsigned)(((unsigned long long)n_items * (vblock + 1)) / gridDim.x);
     unsigned n_own = 0, n_halo = 0;
     unsigned code_v = 0;
     double s0_v = 0.0, s1_v = 0.0, s2_v = 0.0;
@@ -326,6 +378,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     // streams and the scheduler can interleave them (f64 chains are latency-bound on their own; at 4 waves
     // per SIMD the VALU otherwise idles half the time).  Loads are issued on every path (dead lanes read a
     // cache-resident line) so hipcc emits counted s_waitcnt vmcnt(N), never vmcnt(0), inside the loop.
+    const long long own_row0 = (long long)(p.g.own_x0 - p.g.xs) * m, own_row1 = (long long)(p.g.own_x1 - p.g.xs) * m;
     auto step = [&](int j, GatherState& g /*out: item j*/, const GatherState& gin /*item j-1, record arrived*/,
                     UpdateState& u /*out: item j-1*/, const UpdateState& uin /*item j-2, volume data arrived*/) {
         // ---------------- S1(j): geometry, request the pixel record
@@ -334,11 +387,8 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             const unsigned code = __builtin_amdgcn_readlane(code_v, jj);
             const long long row = (long long)(code >> 6);
             const int k = (int)(code & 63u) * 64 + lane;
-            const int il = (tl.log2m >= 0) ? (int)(row >> tl.log2m) : (int)(row / m);
-            const int i = il + p.g.xs;
-            g.owned = (i >= p.g.own_x0 && i < p.g.own_x1);
+            (void)row;
             const double sx = readlane_f64(s0_v, jj), sy = readlane_f64(s1_v, jj), sz = readlane_f64(s2_v, jj);
-            g.idx = row * m + (k < m ? k : 0);
             // get_global_coordinates (sdf.h:153-157) + project_world_to_camera (camera_tracking.cpp:51-54)
             const double gz = cd * ((double)k + 0.5) + oz;
             g.pcx = (sx + p.rot_inv[2] * gz) + p.rot_inv_trans[0];
@@ -364,9 +414,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
             ok = ok && (uu > -1.0 && uu < (double)p.width && ww > -1.0 && ww < (double)p.height);
             const int iu = ok ? (int)uu : 0, iw = ok ? (int)ww : 0;
-            g.pix = (long long)iu * p.pix_su + (long long)iw * p.pix_sv;
+            int rec = iu * p.pix_su + iw * p.pix_sv;                     // record index (< width * height)
 #if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 1) g.pix = __shfl(g.pix, 0);      // timing experiment only: one record per wave
+            if (p.debug & 1) rec = __shfl(rec, 0);          // timing experiment only: one record per wave
 #endif
             // Pixel-record gather, paired: the vector L1 looks every distinct 128-byte line up once per
             // INSTRUCTION, and the two 16-byte halves of a 32-byte record are two instructions.  Instead, the first
@@ -374,7 +424,6 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             // second those of lanes 32..63: each line is looked up once per item instead of twice (the L1 was the
             // measured bottleneck: TCP busy ~90 %, 70 % of its look-ups were this gather).  S2 un-shuffles
             // the pieces through a wave-private LDS buffer.
-            const int rec = (int)g.pix;
             const int recA = __shfl(rec, lane >> 1);
             const int recB = __shfl(rec, 32 + (lane >> 1));
             g.P = pn[2 * (long long)recA + (lane & 1)];      // piece for LDS slot lane
@@ -394,8 +443,14 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             c_out = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
                                 (c.x * c.w + wc * pb) / cw_sum);
         }
-        n_own += (uin.live && uin.owned) ? 1u : 0u;
-        n_halo += (uin.live && !uin.owned) ? 1u : 0u;
+        // the item of S3 (j - 1 - DEPTH): its row decides owned / halo, its code gives the address of its segment
+        const int j3 = j - 1 - TSDF_INTEGRATE_DEPTH;
+        const unsigned code3 = __builtin_amdgcn_readlane(code_v, (j3 >= 0 && j3 < cnt) ? j3 : 0);
+        const long long row3 = (long long)(code3 >> 6);
+        const bool owned3 = row3 >= own_row0 && row3 < own_row1;                 // wave-uniform; rows of the owned x layers
+        const long long base3 = row3 * m + (long long)(code3 & 63u) * 64;
+        n_own += (uin.live && owned3) ? 1u : 0u;
+        n_halo += (uin.live && !owned3) ? 1u : 0u;
         // ---------------- S2(j-1): distance + weight from the pixel record; request {D,W} (+ colour)
         bool need_cos;
         float4 Nrec;
@@ -434,8 +489,6 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             if (p.debug & 2) ok = false;                                        // timing experiment only: no volume RMW
 #endif
             u.d_new = d; u.w_new = wn; u.rgb = __float_as_uint(P.w);
-            u.owned = gin.owned;
-            u.idx = gin.idx;
             u.live = ok;
             // sdf.cpp:294-299: wc = (float)(w_new * cosine).  w_new == 1 (every voxel in front of the surface)
             // makes it the pre-rounded cosine of the record; the exp() band recomputes the f64 product (rare path).
@@ -443,41 +496,69 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             need_cos = COLOR && ok && wn != 1.0f;
         }
         if (need_cos) u.wc = (float)((double)u.w_new * pixel_cosine(Nrec.x, Nrec.y, Nrec.z));
-        // ---------------- memory: volume reads of item j-1, stores of item j-2
+        // ---------------- memory: volume reads of item j-1, stores of item j-1-DEPTH
         {
-            const long long ld = u.live ? u.idx : 0ll;          // dead lanes share voxel 0's (cache-resident) line
-            u.old = dw[ld];                                     // {D,W}: the tracker re-reads these lines -> keep them cached
+            // Dead lanes re-read the voxel of the item's first live lane (a line that is being fetched anyway); an
+            // item without a live lane reads the first voxel of the slab (cache-resident): no traffic is added and the
+            // loads stay unconditional, so hipcc keeps the counted s_waitcnt of the pipelined loop.
+            const int j2 = j - 1;
+            const unsigned code2 = __builtin_amdgcn_readlane(code_v, (j2 >= 0 && j2 < cnt) ? j2 : 0);
+            const unsigned long long live2 = __ballot(u.live);
+            const long long base2 = live2 ? (long long)(code2 >> 6) * m + (long long)(code2 & 63u) * 64 : 0ll;
+            const int first2 = live2 ? (int)__ffsll((long long)live2) - 1 : 0;
+            const int sel = u.live ? lane : first2;
+            const float2* __restrict__ dwb = dw + base2;
+#if TSDF_INTEGRATE_NT_DW
+            {
+                typedef float nt_f2 __attribute__((ext_vector_type(2)));
+                const nt_f2 o2 = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(dwb) + sel);
+                u.old = make_float2(o2.x, o2.y);
+            }
+#else
+            u.old = dwb[sel];                                    // {D,W}: the tracker re-reads these lines -> keep them cached
+#endif
 #if TSDF_INTEGRATE_NT
             if (COLOR) {   // colour is streamed once per frame and never read by the tracker: non-temporal
                 typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                const nt_f4 c4 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(&crgb[ld]));
+                const nt_f4 c4 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(crgb + base2) + sel);
                 u.col = make_float4(c4.x, c4.y, c4.z, c4.w);
             }
 #else
-            if (COLOR) u.col = crgb[ld];
+            if (COLOR) u.col = (crgb + base2)[sel];
 #endif
         }
         if (uin.live) {
-            dw[uin.idx] = make_float2(d_out, w_sum);
+#if TSDF_INTEGRATE_NT_DW
+            {
+                typedef float nt_f2 __attribute__((ext_vector_type(2)));
+                nt_f2 o2; o2.x = d_out; o2.y = w_sum;
+                __builtin_nontemporal_store(o2, reinterpret_cast<nt_f2*>(dw + base3) + lane);
+            }
+#else
+            (dw + base3)[lane] = make_float2(d_out, w_sum);
+#endif
 #if TSDF_INTEGRATE_NT
             if (COLOR) {
                 typedef float nt_f4 __attribute__((ext_vector_type(4)));
                 nt_f4 c4; c4.x = c_out.x; c4.y = c_out.y; c4.z = c_out.z; c4.w = c_out.w;
-                __builtin_nontemporal_store(c4, reinterpret_cast<nt_f4*>(&crgb[uin.idx]));
+                __builtin_nontemporal_store(c4, reinterpret_cast<nt_f4*>(crgb + base3) + lane);
             }
 #else
-            if (COLOR) crgb[uin.idx] = c_out;
+            if (COLOR) (crgb + base3)[lane] = c_out;
 #endif
         }
     };
 
-    for (unsigned blk = first; blk < last; blk += 64) {
-        cnt = (int)((last - blk) < 64u ? (last - blk) : 64u);
-        // lane l fetches item blk+l and its row constants: one round of memory latency per 64 items;
+    for (unsigned blk = wg_first; blk < wg_last; blk += 64u * NW) {
+        // this wavefront's items of the round: blk + wv, blk + wv + NW, ... (at most 64)
+        const unsigned left = wg_last - blk;
+        cnt = left > (unsigned)wv ? (int)((left - (unsigned)wv + NW - 1u) / NW) : 0;
+        cnt = cnt > 64 ? 64 : cnt;
+        // lane l fetches the wavefront's l-th item and its row constants: one round of memory latency per 64 items;
         // the stages broadcast them with v_readlane (no further scalar/vector loads per item)
         code_v = 0; s0_v = s1_v = s2_v = 0.0;
         if (lane < cnt) {
-            code_v = list[blk + lane];
+            code_v = list[blk + (unsigned)wv + NW * (unsigned)lane];
             const long long r = (long long)(code_v >> 6);
             s0_v = rowbase[3 * r + 0]; s1_v = rowbase[3 * r + 1]; s2_v = rowbase[3 * r + 2];
         }
@@ -497,13 +578,13 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         UpdateState U[NU];
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            G[q].live = false; G[q].owned = false; G[q].idx = 0; G[q].pix = 0;
+            G[q].live = false;
             G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
             G[q].P = make_float4(0.f, 0.f, 0.f, 0.f); G[q].N = G[q].P;
         }
 #pragma unroll
         for (int q = 0; q < NU; ++q) {
-            U[q].live = false; U[q].owned = false; U[q].idx = 0;
+            U[q].live = false;
             U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].wc = 0.f; U[q].rgb = 0u;
             U[q].old = make_float2(0.f, 1.f); U[q].col = make_float4(1.f, 0.f, 0.f, 0.f);
         }
@@ -544,9 +625,11 @@ int integrate_blocks_per_cu() {
     return n;
 }
 
+size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords; }
+
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            unsigned* worklist, unsigned* work_count, double* rowbase, int n_blocks,
+                            unsigned* worklist, unsigned* work_count, unsigned* rowinfo, double* rowbase, int n_blocks,
                             unsigned launch_parity) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
@@ -559,13 +642,15 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     tl.k_std = (p.K[1] == 0.0 && p.K[3] == 0.0 && p.K[6] == 0.0 && p.K[7] == 0.0 && p.K[8] == 1.0) ? 1 : 0;
     if (p.debug & 4) tl.k_std = 0;
     if (tl.n_rows >= (1ll << 26)) return hipErrorInvalidValue;       // row index must fit the 26-bit item code
-    // two work counters used alternately: this launch's clip kernel re-zeroes the one the NEXT launch will use
-    // (nobody touches it during this launch), which saves a memset node per frame
-    unsigned* const cur = work_count + (launch_parity & 1);
-    unsigned* const nxt = work_count + ((launch_parity + 1) & 1);
+    // two bookkeeping sets used alternately (see kBinSetWords)
+    unsigned* const cur = work_count + (launch_parity & 1) * kBinSetWords;
+    unsigned* const nxt = work_count + ((launch_parity + 1) & 1) * kBinSetWords;
     hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
-    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, worklist, cur, nxt, rowbase, counters);
+    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt, rowbase, counters);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(tl.n_rows, rowinfo, cur, worklist);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 1/16
@@ -780,7 +865,7 @@ __device__ __forceinline__ void voxel_of(const TrackParams& p, const double* R, 
     vz = (wz - p.g.origin[2]) * (double)p.g.m_div_d - 0.5;
 }
 
-struct TrackFold {               // in-launch fan-in of the per-workgroup rows (null ctr = rows only, folded by later launches)
+struct TrackFold {               // in-launch fan-in of the per-workgroup rows
     unsigned* ctr;               // kTrackShards shard counters + 1 top counter, one 128-byte line each, zero between passes
     double* shard_rows;          // kTrackShards x kPartWidth
     double* red_dev;             // kRedWidth: result row for an in-stream all-reduce (may be null)
@@ -993,14 +1078,9 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         else if (qq == 2 && e == 5) slot = kPartOog;
         else if (qq == 3 && e == 5) slot = kPartNan;
         else if (qq == 4 && e == 5) slot = kPartSamples;
-        if (fold.ctr == nullptr) {
-            if (slot >= 0) partials[(long long)blockIdx.x * kPartWidth + slot] = v;
-        } else {
-            if (qq == 7 && e == 7) { slot = kPartWidth - 1; v = fold.tag; }
-            if (slot >= 0) store_sc1(&partials[(long long)blockIdx.x * kPartWidth + slot], v);
-        }
+        if (qq == 7 && e == 7) { slot = kPartWidth - 1; v = fold.tag; }
+        if (slot >= 0) store_sc1(&partials[(long long)blockIdx.x * kPartWidth + slot], v);
     }
-    if (fold.ctr == nullptr) return;
 
     // ---- in-launch fan-in (no second launch, no host-side fold): every workgroup has written its row write-through;
     // one lane arrives on the counter of its shard (blockIdx % 8: workgroups b and b + 8 share an XCD, so a shard's
@@ -1139,95 +1219,9 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     }
 }
 
-// Fixed-order final sum in two levels (kernel boundaries = visibility; no atomics, no spin):
-// track_fold_kernel folds the per-workgroup rows into <= kFoldBlocks rows, track_final_kernel adds those
-// and converts to the result row of tsdf_device.h.  Every sum has a fixed order: bitwise reproducible.
-
-__device__ __forceinline__ void fold_rows(const double* __restrict__ rows, int first, int last, double* out /*LDS[kPartWidth]*/) {
-    constexpr int RG = 256 / kPartWidth;             // 6 row groups of 40 columns
-    __shared__ double s[RG][kPartWidth];
-    const int tid = threadIdx.x;
-    const int col = tid % kPartWidth, rg = tid / kPartWidth;
-    if (rg < RG) {
-        double v = 0.0;
-        for (int r = first + rg; r < last; r += RG) v += rows[(long long)r * kPartWidth + col];
-        s[rg][col] = v;
-    }
-    __syncthreads();
-    if (tid < kPartWidth) {
-        double v = s[0][tid];
-        for (int r = 1; r < RG; ++r) v += s[r][tid];
-        out[tid] = v;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void track_fold_kernel(const double* __restrict__ partials, int nrows,
-                                                          double* __restrict__ folded,
-                                                          double* __restrict__ host_rows, unsigned long long seq) {
-    __shared__ double tot[kPartWidth];
-    const int per = (nrows + gridDim.x - 1) / gridDim.x;
-    const int first = blockIdx.x * per;
-    const int last = first + per < nrows ? first + per : nrows;
-    fold_rows(partials, first, last, tot);
-    if (threadIdx.x < 64) {                                   // one wave
-        if (host_rows) {
-            // single-rank hand-off: the <= kFoldBlocks folded rows go straight to pinned host memory (one coalesced
-            // 320-byte store), a system-scope fence, then the pass number; the host adds the rows in block
-            // order -- the device-side final kernel (one more dependent launch, ~5 us) is not needed.
-            double* slot = host_rows + (size_t)blockIdx.x * kFoldSlotDoubles;
-            if (threadIdx.x < kPartWidth) slot[threadIdx.x] = tot[threadIdx.x];
-            __threadfence_system();
-            if (threadIdx.x == 0)
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + kPartWidth), seq, __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if (threadIdx.x < kPartWidth) {
-            folded[(long long)blockIdx.x * kPartWidth + threadIdx.x] = tot[threadIdx.x];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void track_final_kernel(const double* __restrict__ folded, int nrows,
-                                                           double* __restrict__ red_dev,
-                                                           double* __restrict__ red_host,
-                                                           unsigned long long seq) {
-    __shared__ double tot[kPartWidth];
-    __shared__ double res[kRedWidth];
-    fold_rows(folded, 0, nrows, tot);
-    const int tid = threadIdx.x;
-    if (tid < kRedWidth) {
-        double v = 0.0;
-        if (tid < 21) {
-            // upper triangle, row-major: (a,b) with a <= b  ->  product slot of q = a or q = b
-            int a = 0, e = tid;
-            while (e >= 6 - a) { e -= 6 - a; ++a; }
-            const int b = a + e, d = b - a;
-            v = (d <= 3) ? tot[5 * a + d] : tot[5 * b + (6 - d)];     // (a,b) = (q,(q+d')%6) with q = b, d' = 6-d
-        } else if (tid < 27) v = tot[5 * (tid - 21) + 4];
-        else if (tid == 27) v = tot[kPartTerms];
-        else if (tid == 28) v = tot[kPartViol];
-        else if (tid == 29) v = tot[kPartOk];
-        else if (tid == 30) v = tot[kPartInOwned];
-        else if (tid == 31) v = tot[kPartOog];
-        else if (tid == 32) v = tot[kPartNan];
-        else if (tid == 33) v = tot[kPartSamples];
-        red_dev[tid] = v;
-        res[tid] = v;
-    }
-    __syncthreads();
-    // Host hand-off without a stream synchronisation: ONE lane writes the row to pinned host memory,
-    // fences at system scope, then publishes the pass number; the host spins on that word.
-    if (red_host && tid == 0) {
-        for (int e = 0; e < kRedWidth; ++e) red_host[e] = res[e];
-        __threadfence_system();
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(red_host + kRedWidth), seq, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// After an in-stream all-reduce (RCCL) of red_dev: hand the reduced row to the host the same way
-// track_final_kernel does (pinned memory + system-scope release of the pass number), so the host can
-// poll instead of waiting for a stream synchronisation.
+// After an in-stream all-reduce (RCCL) of red_dev: hand the reduced row to the host the way track_kernel's last
+// workgroup does (pinned memory + system-scope release of the pass number), so the host can poll instead of
+// waiting for a stream synchronisation.
 __global__ __launch_bounds__(64) void track_publish_kernel(const double* __restrict__ red_dev,
                                                             double* __restrict__ red_host, unsigned long long seq) {
     if (threadIdx.x == 0) {
@@ -1244,31 +1238,7 @@ hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* re
 }
 
 int track_num_blocks(int32_t n_samples) { return (n_samples + kSamplesPerBlock - 1) / kSamplesPerBlock; }
-size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blocks(n_samples) + kFoldBlocks) * kPartWidth; }
-
-int track_fold_blocks(int32_t n_samples) {
-    const int nb = track_num_blocks(n_samples);
-    return nb < kFoldBlocks ? nb : kFoldBlocks;
-}
-
-hipError_t launch_track(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                        double* partials, double* red_dev, double* red_host, double* fold_host,
-                        unsigned long long seq) {
-    const int nb = track_num_blocks(p.n_samples);
-    if (nb <= 0) return hipErrorInvalidValue;
-    TrackFold none{};
-    track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, none);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // unwritten counter slots of the rows (37..39) are never read into a result; terms/counters are all written
-    double* folded = partials + (size_t)nb * kPartWidth;
-    const int fb = track_fold_blocks(p.n_samples);
-    track_fold_kernel<<<dim3(fb), dim3(256), 0, s>>>(partials, nb, folded, fold_host, seq);
-    e = hipGetLastError();
-    if (e != hipSuccess || fold_host) return e;
-    track_final_kernel<<<dim3(1), dim3(256), 0, s>>>(folded, fb, red_dev, red_host, seq);
-    return hipGetLastError();
-}
+size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blocks(n_samples) + kTrackShards) * kPartWidth; }
 
 // One launch per pass: rows, fan-in and result row inside track_kernel.  ctr: track_fold_counter_words() unsigned, zero
 // before the first pass (the kernel re-zeroes them); shard rows live behind the per-workgroup rows in `partials`.
