@@ -417,6 +417,14 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             int rec = iu * p.pix_su + iw * p.pix_sv;                     // record index (< width * height)
 #if TSDF_INTEGRATE_DEBUG
             if (p.debug & 1) rec = __shfl(rec, 0);          // timing experiment only: one record per wave
+            if (p.debug & 8) {                              // timing experiment only: 64 consecutive records (coalesced)
+                const int r0 = __shfl(rec, 0);
+                rec = r0 + lane < p.width * p.height ? r0 + lane : r0;
+            }
+            if (p.debug & 16) {                             // timing experiment only: consecutive records, 2 lanes each
+                const int r0 = __shfl(rec, 0);
+                rec = r0 + lane * 3 / 2 < p.width * p.height ? r0 + lane * 3 / 2 : r0;
+            }
 #endif
             // Pixel-record gather, paired: the vector L1 looks every distinct 128-byte line up once per
             // INSTRUCTION, and the two 16-byte halves of a 32-byte record are two instructions.  Instead, the first
