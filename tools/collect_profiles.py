@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Collect the rocprofv3 evidence bench.py's roofline object refers to (run on the GPU box).
 
-  python3 tools/collect_profiles.py <out_dir> [tag]
+  python3 tools/collect_profiles.py <out_dir> [tag]          (then copy <out_dir>/<tag>_* into profiles/)
 
-Three separate rocprofv3 runs of the same bench.py command (never --pmc together with a trace domain):
-  1. --kernel-trace --stats      -> <tag>_bench_kernel_stats.csv, <tag>_bench.json (the bench line of that run)
-  2. --pmc FETCH_SIZE            } -> <tag>_pmc_traffic.json: mean bytes per launch and kernel, and the HBM
-  3. --pmc WRITE_SIZE            }    traffic of one integrate launch (clip_rows_kernel + integrate_kernel)
-rocprofv3 is started with the program itself after `--` (python3 bench.py ...), as the pool requires.
-Copy the three files into profiles/ to have them judged.
+  1. rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras ...   -> <tag>_bench_kernel_stats.csv (our kernels
+     only) and <tag>_bench_under_rocprofv3.json (the bench line of that run)
+  2. python3 bench.py (the default command; it measures roofline.traffic itself with two --pmc child passes)
+                                                                            -> <tag>_bench.json
+  3. tools/pmc_memside.py (separate --pmc passes: SQ, TCP, TCC request sizes) -> <tag>_pmc_memside.json
+  4. tools/pmc_calibrate.py (known-byte kernels; needs `make pmc_calibrate`)  -> <tag>_fetch_calibration.json
+rocprofv3 always gets the program itself after `--`; --pmc is never combined with a trace domain.
 """
 import csv
 import glob
@@ -19,79 +20,53 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = ["python3", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"]
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py")]
 
 
-def run(cmd, log):
-    env = dict(os.environ, TMPDIR="/tmp")
-    with open(log, "w") as f:
-        return subprocess.run(cmd, cwd="/tmp", env=env, stdout=f, stderr=subprocess.STDOUT).returncode
-
-
-def short(name):
-    name = name.replace("void ", "")
-    return name.split("(")[0]
+def last_json_line(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith('{"metric"')]
+    return json.loads(lines[-1]) if lines else None
 
 
 def main():
     out = os.path.abspath(sys.argv[1])
-    tag = sys.argv[2] if len(sys.argv) > 2 else "r01_final"
+    tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
     os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
     # 1. kernel trace
     d = os.path.join(out, "kt")
     shutil.rmtree(d, ignore_errors=True)
-    log = os.path.join(out, "kt.log")
-    rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + BENCH +
-             ["--steps", "60", "--warmup", "5"], log)
-    stats = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))
-    if rc or not stats:
-        sys.exit("kernel-trace run failed, see " + log)
-    shutil.copy(stats[0], os.path.join(out, tag + "_bench_kernel_stats.csv"))
-    line = [ln for ln in open(log) if ln.startswith('{"metric"')]
+    p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + BENCH +
+                       ["--steps", "60", "--warmup", "5", "--no-extras", "--no-cpu-baseline"], cwd="/tmp", env=env,
+                       capture_output=True, text=True)
+    stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    if p.returncode or not stats:
+        sys.exit("kernel-trace run failed: " + p.stderr[-2000:])
+    with open(stats[0]) as f, open(os.path.join(out, tag + "_bench_kernel_stats.csv"), "w", newline="") as g:
+        rd = csv.reader(f)
+        wr = csv.writer(g)
+        wr.writerow(next(rd))
+        for row in rd:
+            if "tsdf::" in row[0]:          # the renderer's torch kernels are input generation, not the hot path
+                wr.writerow(row)
+    line = last_json_line(p.stdout)
     if line:
-        with open(os.path.join(out, tag + "_bench.json"), "w") as f:
-            json.dump(json.loads(line[-1]), f, indent=1)
-    # 2./3. PMC passes
-    kernels = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = os.path.join(out, "pmc_" + counter)
-        shutil.rmtree(d, ignore_errors=True)
-        log = os.path.join(out, "pmc_%s.log" % counter)
-        rc = run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + BENCH +
-                 ["--steps", "20", "--warmup", "2"], log)
-        files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
-        if rc or not files:
-            sys.exit("pmc %s run failed, see %s" % (counter, log))
-        acc = {}
-        for r in csv.DictReader(open(files[0])):
-            if r["Counter_Name"] != counter:
-                continue
-            k = short(r["Kernel_Name"])
-            a = acc.setdefault(k, [0, 0.0])
-            a[0] += 1
-            a[1] += float(r["Counter_Value"]) * 1024.0          # rocprofv3 reports KB
-        for k, (n, tot) in acc.items():
-            kernels.setdefault(k, {})[counter] = {"launches": n, "mean_bytes": tot / n}
-
-    def tot(kname):
-        e = kernels.get(kname, {})
-        return sum(e.get(c, {}).get("mean_bytes", 0.0) for c in ("FETCH_SIZE", "WRITE_SIZE"))
-    integ = [k for k in kernels if k.startswith("tsdf::integrate_kernel")]
-    traffic = tot("tsdf::clip_rows_kernel") + sum(tot(k) for k in integ)
-    doc = {
-        "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline "
-                   "(one counter per pass; tools/collect_profiles.py)",
-        "unit": "bytes per launch (rocprofv3 reports KB)",
-        "kernels": kernels,
-        "integrate_launch_traffic_bytes": traffic,
-        "correction": "none applied: the gfx950 1/2-count of FETCH_SIZE holds for wide (16 B/lane) coalesced streaming "
-                      "reads; here WRITE_SIZE equals the known write volume (updated voxels x 24 B) and FETCH_SIZE "
-                      "exceeds the known read volume (updated voxels x 24 B + 9.8 MB of pixel records), so no halving "
-                      "is present for this 8/16-byte RMW + gather pattern",
-    }
-    with open(os.path.join(out, tag + "_pmc_traffic.json"), "w") as f:
-        json.dump(doc, f, indent=1)
-    print(json.dumps({"traffic": traffic, "kernel_stats": os.path.basename(stats[0])}))
+        with open(os.path.join(out, tag + "_bench_under_rocprofv3.json"), "w") as f:
+            json.dump(line, f, indent=1)
+    shutil.rmtree(d, ignore_errors=True)
+    # 2. the default bench command
+    p = subprocess.run(BENCH, cwd=ROOT, env=env, capture_output=True, text=True)
+    line = last_json_line(p.stdout)
+    if p.returncode or not line:
+        sys.exit("bench.py failed: " + p.stderr[-2000:])
+    with open(os.path.join(out, tag + "_bench.json"), "w") as f:
+        json.dump(line, f, indent=1)
+    # 3. / 4.
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_memside.py"), out, tag, "--passes=9,10,0,1,2,4,5,6,7"],
+                   cwd=ROOT, env=env)
+    if os.path.exists(os.path.join(ROOT, "build", "pmc_calibrate")):
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_calibrate.py"), out], cwd=ROOT, env=env)
+    print(json.dumps({"value": line["value"], "traffic": line["roofline"]["traffic"], "frac": line["roofline"]["frac"]}))
 
 
 if __name__ == "__main__":
