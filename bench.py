@@ -43,9 +43,11 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MI
 WORKLOADS = {     # config -> (m at the reference GPU count, reference GPU count, width, height, label)
     2: (256, 1, 640, 480, "config 2: fr1/plant path, 256^3, 640x480"),
     3: (512, 1, 640, 480, "config 3 / metric: fr1/plant path, 512^3, 640x480"),
-    4: (1024, 8, 640, 480, "config 4 shape: 1024^3 on 8 GPUs, 640x480 (weak: m = 1024 (N/8)^(1/3))"),
+    4: (1024, 8, 640, 480, "config 4 shape: 1024^3 on 8 GPUs, 640x480, fr3 intrinsics (weak: m = 1024 (N/8)^(1/3))"),
     5: (2048, 8, 1280, 960, "config 5 shape: 2048^3 on 8 GPUs, 1280x960 (weak: m = 2048 (N/8)^(1/3))"),
 }
+# config 4 is a freiburg3 sequence -- its calibrated intrinsics (fx, fy, cx, cy) instead of the ROS default
+FR3_K = ((535.4, 0.0, 320.1), (0.0, 539.2, 247.6), (0.0, 0.0, 1.0))
 
 
 def parse(argv=None):
@@ -322,9 +324,9 @@ def run(args):
     m, width, height, wl_label, scaling = resolve(args.config, args.m, args.width, args.height)
     noise = not args.no_noise
 
-    def render_frames(w, h, n_frames, step=1):
+    def render_frames(w, h, n_frames, step=1, K=None):
         """Synthetic input, identical on every rank, rendered on this rank's GPU and left there."""
-        seq = synth.Sequence(n_frames=n_frames, width=w, height=h, noise=noise, holes=0.02 if noise else 0.0, step=step)
+        seq = synth.Sequence(n_frames=n_frames, width=w, height=h, noise=noise, holes=0.02 if noise else 0.0, step=step, K=K)
         if len(seq) < n_frames:
             raise SystemExit(f"trajectory has only {len(seq)} poses, need {n_frames}")
         fr = [seq.frame_torch(k, dev) for k in range(n_frames)]
@@ -411,7 +413,8 @@ def run(args):
             self.sdf.close()
 
     n_frames = 1 + args.warmup + args.steps
-    seq, d_frames = render_frames(width, height, n_frames, args.frame_step)
+    seq, d_frames = render_frames(width, height, n_frames, args.frame_step,
+                                  np.array(FR3_K) if args.config == 4 and (width, height) == (640, 480) else None)
     leg = Leg(m, width, height, seq.K)
     sdf = leg.sdf
     halo_main = leg.halo

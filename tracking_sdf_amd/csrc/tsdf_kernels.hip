@@ -150,10 +150,17 @@ struct IntegrateTiling {
     int k_std;           // 1 = K = [[fx,0,cx],[0,fy,cy],[0,0,1]] exactly: zero terms can be dropped
 };
 
-// interval of k (real-valued) on which a + k*b > 0, intersected into [lo, hi]
+// interval of k (real-valued) on which a + k*b > 0, intersected into [lo, hi].  The crossing -a/b only has to be
+// good to a fraction of a voxel (the interval gets a whole voxel of slack per side and every voxel inside still
+// runs the reference's exact test), so it is a refined reciprocal times -a, not an IEEE division.
+__device__ __forceinline__ double clip_crossing(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return -a * r;
+}
 __device__ __forceinline__ void clip_affine(double a, double b, double& lo, double& hi) {
-    if (b > 0.0) { const double t = -a / b; if (t > lo) lo = t; }
-    else if (b < 0.0) { const double t = -a / b; if (t < hi) hi = t; }
+    if (b > 0.0) { const double t = clip_crossing(a, b); if (t > lo) lo = t; }
+    else if (b < 0.0) { const double t = clip_crossing(a, b); if (t < hi) hi = t; }
     else if (a < -1.0e-9) { lo = 1.0; hi = 0.0; }   // row parallel to this plane and clearly outside it
     // (b == 0 and a within rounding of 0: leave it to the exact per-voxel test)
 }
@@ -1122,24 +1129,25 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         bool bad = false;
         if (rg < RG) {
             // rows shard, shard + 8, ...: this thread adds every RG-th of them, in order
-            double part[8];
+            constexpr int NF = 12;                                    // loads in flight per thread (714 workgroups: 10 rows per thread)
+            double part[NF];
             unsigned r = shard + (unsigned)kTrackShards * (unsigned)rg;
             while (r < n_wg) {
                 int nld = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {                         // 8 loads in flight, summed in row order
+                for (int u = 0; u < NF; ++u) {                        // NF loads in flight, summed in row order
                     const unsigned ru = r + (unsigned)(kTrackShards * RG) * (unsigned)u;
                     part[u] = ru < n_wg ? load_sc1(&partials[(long long)ru * kPartWidth + col]) : 0.0;
                     nld += ru < n_wg ? 1 : 0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < NF; ++u) {
                     if (u < nld) {
                         if (col == kPartWidth - 1) bad |= part[u] != fold.tag;
                         v += part[u];
                     }
                 }
-                r += (unsigned)(kTrackShards * RG) * 8u;
+                r += (unsigned)(kTrackShards * RG) * (unsigned)NF;
             }
             s_fold[rg][col] = v;
         }
