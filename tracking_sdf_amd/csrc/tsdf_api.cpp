@@ -55,6 +55,8 @@ struct tsdf_handle {
     int64_t n_stored = 0;          // voxels in [xs, xe)
     unsigned long long* counters = nullptr;     // device, kNumCounters
     unsigned long long* counters_host = nullptr;  // pinned
+    unsigned long long* wg_counts = nullptr;      // device: {owned, halo} voxels updated, cumulative, per integrate workgroup
+    unsigned long long* wg_counts_host = nullptr; // pinned mirror
     unsigned* worklist = nullptr;  // integrate work items (row << 6 | chunk)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
     unsigned* rowinfo = nullptr;      // per voxel row: first chunk, chunk count, image band
@@ -479,6 +481,20 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     return TSDF_OK;
 }
 
+// Cumulative device counters into h->counters_host (synchronises the main stream): the item count comes from the
+// counter block, the updated-voxel counts are the sums of the integrate workgroups' own words.
+int fetch_counters(tsdf_handle* h) {
+    const size_t nw = 2 * (size_t)h->integrate_blocks;
+    HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->wg_counts_host, h->wg_counts, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    unsigned long long own = 0, halo = 0;
+    for (size_t b = 0; b < nw; b += 2) { own += h->wg_counts_host[b]; halo += h->wg_counts_host[b + 1]; }
+    h->counters_host[kCntUpdatedOwned] = own;
+    h->counters_host[kCntUpdatedHalo] = halo;
+    return TSDF_OK;
+}
+
 void unpack_normal_equations(const double* row, double A[36], double b[6]) {
     int e = 0;
     for (int a = 0; a < 6; ++a)
@@ -639,6 +655,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
         const int per_cu = env ? std::atoi(env) : integrate_blocks_per_cu();
         h->integrate_blocks = (prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4) + 7) / 8 * 8;   // whole XCD groups
     }
+    CREATE_TRY(hipMalloc((void**)&h->wg_counts, 2 * (size_t)h->integrate_blocks * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(h->wg_counts, 0, 2 * (size_t)h->integrate_blocks * sizeof(unsigned long long), h->stream));
+    CREATE_TRY(hipHostMalloc((void**)&h->wg_counts_host, 2 * (size_t)h->integrate_blocks * sizeof(unsigned long long), hipHostMallocDefault));
     CREATE_TRY(hipMalloc((void**)&h->red_dev, kRedWidth * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->red_host, (kRedWidth + 2) * sizeof(double), hipHostMallocDefault));
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
@@ -680,6 +699,8 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->rowinfo) (void)hipFree(h->rowinfo);
     if (h->rowbase) (void)hipFree(h->rowbase);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
+    if (h->wg_counts) (void)hipFree(h->wg_counts);
+    if (h->wg_counts_host) (void)hipHostFree(h->wg_counts_host);
     if (h->sample_vox) (void)hipFree(h->sample_vox);
     if (h->sample_val) (void)hipFree(h->sample_val);
     if (h->sample_ok) (void)hipFree(h->sample_ok);
@@ -857,15 +878,15 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     p.debug = h->integrate_debug;
     unsigned long long before[kNumCounters];
     if (stats) {
-        HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof before, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        rc = fetch_counters(h);
+        if (rc) return rc;
         std::memcpy(before, h->counters_host, sizeof before);
     }
     EventPair* ep;
     rc = timed_begin(h, 0, &ep, h->stream);
     if (rc) return rc;
     HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count, h->rowinfo,
-                                h->rowbase, h->integrate_blocks, h->integrate_launches++));
+                                h->rowbase, h->integrate_blocks, h->integrate_launches++, h->wg_counts));
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
     if (h->frame_side) {     // the next-but-one pack (on the frame stream) may overwrite this buffer after this launch
@@ -878,8 +899,8 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     h->cnt.integrate_calls++;
     h->cnt.n_voxels_swept += h->n_stored;
     if (stats) {
-        HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof before, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        rc = fetch_counters(h);
+        if (rc) return rc;
         stats->n_updated = (int64_t)(h->counters_host[kCntUpdatedOwned] - before[kCntUpdatedOwned]);
         stats->n_updated_halo = (int64_t)(h->counters_host[kCntUpdatedHalo] - before[kCntUpdatedHalo]);
         stats->n_voxels = h->n_stored;
@@ -1528,8 +1549,8 @@ int tsdf_read_timing(tsdf_handle* h, tsdf_timing* out, int32_t reset) {
 int tsdf_read_counters(tsdf_handle* h, tsdf_counters* out, int32_t reset) {
     int rc = check_ready(h, false);
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    rc = fetch_counters(h);
+    if (rc) return rc;
     h->cnt.n_updated = (int64_t)(h->counters_host[kCntUpdatedOwned] - h->cnt_base[kCntUpdatedOwned]);
     h->cnt.n_updated_halo = (int64_t)(h->counters_host[kCntUpdatedHalo] - h->cnt_base[kCntUpdatedHalo]);
     h->cnt.integrate_items = (int64_t)(h->counters_host[kCntItems] - h->cnt_base[kCntItems]);

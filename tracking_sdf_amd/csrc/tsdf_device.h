@@ -92,7 +92,7 @@ int integrate_blocks_per_cu();
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             unsigned* worklist, unsigned* work_count, unsigned* rowinfo, double* rowbase, int n_blocks,
-                            unsigned launch_parity);
+                            unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */);
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit

@@ -241,15 +241,12 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
     }
     if (n) atomicAdd(&s_hist[bin], (unsigned)n);
     __syncthreads();
+    // only the band counters are touched here (no-return adds on up to 64 different words): a total that every
+    // workgroup adds to is one hot word, and a thousand returning atomics on one word cost ~12 us by themselves;
+    // the scatter pass gets the total out of its scan of the bands
     if (tid < kBins) {
-        unsigned hcnt = s_hist[tid];
+        const unsigned hcnt = s_hist[tid];
         if (hcnt) atomicAdd(&set[1 + tid], hcnt);
-        // workgroup total by a wave reduction over the 64 bands
-        for (int off = 32; off > 0; off >>= 1) hcnt += __shfl_xor(hcnt, off);
-        if (tid == 0 && hcnt) {
-            atomicAdd(&set[0], hcnt);
-            atomicAdd(&counters[kCntItems], (unsigned long long)hcnt);
-        }
     }
 }
 
@@ -260,7 +257,8 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
 // gathered from the whole image, and 63 % of the launch's fabric reads were pixel records fetched again and again
 // (296 MB for a 9.8 MB image).
 __global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(long long n_rows, const unsigned* __restrict__ rowinfo,
-                                                                   unsigned* __restrict__ set, unsigned* __restrict__ list) {
+                                                                   unsigned* __restrict__ set, unsigned* __restrict__ list,
+                                                                   unsigned long long* __restrict__ counters) {
     static_assert(kBins == 64, "one wavefront scans the bands");
     __shared__ unsigned s_start[kBins], s_wg[kBins], s_base[kBins];
     const int tid = threadIdx.x;
@@ -275,6 +273,10 @@ __global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(long long n_ro
         }
         s_start[tid] = incl - hcnt;
         s_wg[tid] = 0u;
+        if (blockIdx.x == 0 && tid == kBins - 1) {          // the launch's item count, for integrate_kernel and the statistics
+            set[0] = incl;
+            if (incl) atomicAdd(&counters[kCntItems], (unsigned long long)incl);
+        }
     }
     __syncthreads();
     const unsigned info = row < n_rows ? rowinfo[row] : 0u;
@@ -353,7 +355,7 @@ template <bool COLOR, bool KSTD, bool EXPPOLY>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, const unsigned* __restrict__ list, const unsigned* __restrict__ count,
     const double* __restrict__ rowbase, float2* __restrict__ dw, float4* __restrict__ crgb,
-    const float4* __restrict__ pn, unsigned long long* __restrict__ counters) {
+    const float4* __restrict__ pn, unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */) {
     const int m = p.g.m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -612,7 +614,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         // (steps run up to j >= cnt + DEPTH, so S3 has retired item cnt-1 inside the loop: nothing to drain)
     }
 
-    // one atomic per counter per workgroup that updated anything: wave shuffle, then LDS across the 4 waves
+    // Update counts: wave shuffle, LDS across the waves, then the workgroup adds to ITS OWN pair of cumulative words
+    // (plain read-modify-write, nobody else touches them; the host adds the pairs up when somebody asks).  A thousand
+    // workgroups finishing together with an atomic on one shared word each were a serial tail of the launch.
     __shared__ unsigned s_cnt[2][kIntegrateBlock / 64];
     for (int off = 32; off > 0; off >>= 1) {
         n_own += __shfl_xor(n_own, off);
@@ -623,8 +627,8 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     if (tid == 0) {
         unsigned a = 0, b = 0;
         for (int q = 0; q < kIntegrateBlock / 64; ++q) { a += s_cnt[0][q]; b += s_cnt[1][q]; }
-        if (a) atomicAdd(&counters[kCntUpdatedOwned], (unsigned long long)a);
-        if (b) atomicAdd(&counters[kCntUpdatedHalo], (unsigned long long)b);
+        if (a) counters[2 * blockIdx.x + 0] += (unsigned long long)a;
+        if (b) counters[2 * blockIdx.x + 1] += (unsigned long long)b;
     }
 }
 
@@ -645,7 +649,7 @@ size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords; }
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             unsigned* worklist, unsigned* work_count, unsigned* rowinfo, double* rowbase, int n_blocks,
-                            unsigned launch_parity) {
+                            unsigned launch_parity, unsigned long long* wg_counts) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
@@ -665,14 +669,14 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt, rowbase, counters);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(tl.n_rows, rowinfo, cur, worklist);
+    scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(tl.n_rows, rowinfo, cur, worklist, counters);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 1/16
     const double span = (double)p.g.delta - (double)p.g.epsilon;
     const bool exp_poly = span >= 0.0 && 0.5 * span * span <= 0.0625;
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP) \
-    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, cur, rowbase, dw, crgb, pn, counters)
+    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, cur, rowbase, dw, crgb, pn, wg_counts)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE(C, KS, true); else TSDF_LAUNCH_INTEGRATE(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
     else { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(false, true); else TSDF_LAUNCH_INTEGRATE2(false, false); }
