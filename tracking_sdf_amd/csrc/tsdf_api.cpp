@@ -97,6 +97,8 @@ struct tsdf_handle {
     unsigned long long pass_seq = 0;
     bool host_fold = true;         // shared-memory fan-in: the host publishes this rank's row (TSDF_HOST_FOLD=0: the device writes the slot itself)
     unsigned* fold_ctr = nullptr;  // arrival counters of the in-launch fan-in of track_kernel
+    double* shard_host = nullptr;  // pinned: kTrackShards slots of kShardSlotDoubles (host side of the fan-in)
+    bool host_fanin = true;        // the second level of the tracker fan-in runs on the host (TSDF_HOST_FANIN=0: on the device)
     unsigned integrate_launches = 0;
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
 
@@ -418,8 +420,11 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         ? reinterpret_cast<double*>(h->shm.dev_base + shm_slot_offset(h, h->shm.rank, seq)) : h->red_host;
     const unsigned long long dev_word = dev_publish_shm ? shm_word(h, seq) : seq;
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
+    // the row ends up on this host anyway (no in-stream all-reduce, no device-published slot): let the device stop
+    // after the shard level and add the <= 8 shard rows here
+    const bool host_fanin = h->host_fanin && h->poll && !use_rccl && !dev_publish_shm && !h->timing_track;
     HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
-                                   use_rccl ? nullptr : host_row, dev_word, seq));
+                                   use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq));
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
     if (use_rccl) {
         std::string cerr;
@@ -430,7 +435,32 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
                                        h->stream));
     }
     bool arrived = false;
-    if (dev_publish_shm) {
+    if (host_fanin) {
+        const int ns = track_num_shards(h->n_samples);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool all = true;
+        for (int sh = 0; sh < ns && all; ++sh) {
+            const volatile unsigned long long* word =
+                reinterpret_cast<const volatile unsigned long long*>(h->shard_host + (size_t)sh * kShardSlotDoubles + kPartWidth);
+            for (unsigned spins = 0;; ++spins) {
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { all = false; break; }
+            }
+        }
+        if (!all) HIP_TRY(h, hipStreamSynchronize(h->stream));      // a shard row did not show up in time: synchronise for real
+        // shard order, as the device's last workgroup adds them: the same bits in every exchange mode
+        double tot[kPartWidth];
+        bool stale = false;
+        for (int e = 0; e < kPartWidth; ++e) {
+            double v = h->shard_host[e];
+            for (int sh = 1; sh < ns; ++sh) v += h->shard_host[(size_t)sh * kShardSlotDoubles + e];
+            tot[e] = v;
+        }
+        for (int sh = 0; sh < ns; ++sh) stale |= h->shard_host[(size_t)sh * kShardSlotDoubles + kPartWidth - 1] != (double)(seq & 0xFFFFFFFFFFFFull);
+        track_unpack_row(tot, h->red_host);
+        if (stale) h->red_host[27] = std::nan("");
+        arrived = true;
+    } else if (dev_publish_shm) {
         int rc2 = shm_fan_in(h, seq, kRedAllreduce);
         if (rc2) return rc2;
         arrived = true;
@@ -663,6 +693,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
     { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
     { const char* ev = std::getenv("TSDF_HOST_FOLD"); h->host_fold = !(ev && std::atoi(ev) == 0); }
+    CREATE_TRY(hipHostMalloc((void**)&h->shard_host, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double), hipHostMallocDefault));
+    std::memset(h->shard_host, 0, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double));
+    { const char* ev = std::getenv("TSDF_HOST_FANIN"); h->host_fanin = !(ev && std::atoi(ev) == 0); }
     CREATE_TRY(hipMalloc((void**)&h->fold_ctr, track_fold_counter_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, track_fold_counter_words() * sizeof(unsigned), h->stream));
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
@@ -693,6 +726,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
     if (h->fold_ctr) (void)hipFree(h->fold_ctr);
+    if (h->shard_host) (void)hipHostFree(h->shard_host);
     if (h->counters) (void)hipFree(h->counters);
     if (h->worklist) (void)hipFree(h->worklist);
     if (h->work_count) (void)hipFree(h->work_count);

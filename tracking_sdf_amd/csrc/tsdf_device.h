@@ -30,6 +30,21 @@ constexpr int kTrackBlock = TSDF_TRACK_BLOCK;    // threads per tracker workgrou
 #endif
 constexpr int kIntegrateBlock = TSDF_INTEGRATE_BLOCK;   // threads per integrate workgroup
 constexpr int kTrackShards = 8;                  // fan-in shards of the in-launch fold (blockIdx % 8: one per XCD)
+constexpr int kShardSlotDoubles = 48;            // pinned host slot of a shard row: 40 values + the pass word + pad
+
+// partial row (kPartWidth) -> result row (kRedWidth): the mapping track_kernel's last workgroup applies, for the host
+// side of the fan-in
+inline void track_unpack_row(const double* tot, double* red) {
+    int e = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            const int d = b - a;
+            red[e++] = (d <= 3) ? tot[5 * a + d] : tot[5 * b + (6 - d)];
+        }
+    for (int a = 0; a < 6; ++a) red[21 + a] = tot[5 * a + 4];
+    red[27] = tot[kPartTerms]; red[28] = tot[kPartViol]; red[29] = tot[kPartOk]; red[30] = tot[kPartInOwned];
+    red[31] = tot[kPartOog]; red[32] = tot[kPartNan]; red[33] = tot[kPartSamples];
+}
 
 // Geometry of the stored part of the volume.  Device layout: one float2 {D,W} per voxel
 // (and one float4 {Color_W,R,G,B} when colour is kept), reference index order
@@ -96,10 +111,12 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit
-// word that receives `word` after the row is complete; `pass` tags the rows of this pass.
+// word that receives `word` after the row is complete; host_shards (pinned, may be null): when given, the shard rows go
+// to the host instead (kShardSlotDoubles per shard, word at [kPartWidth]) and the host adds them; `pass` tags the rows.
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                               double* partials, unsigned* ctr, double* red_dev, double* host_row,
+                               double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
                                unsigned long long word, unsigned long long pass);
+int track_num_shards(int32_t n_samples);
 size_t track_fold_counter_words();
 hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);

@@ -889,6 +889,8 @@ struct TrackFold {               // in-launch fan-in of the per-workgroup rows
     double* shard_rows;          // kTrackShards x kPartWidth
     double* red_dev;             // kRedWidth: result row for an in-stream all-reduce (may be null)
     double* host_row;            // pinned host (or shared-segment alias): kRedWidth doubles + the word (may be null)
+    double* host_shards;         // pinned host, kTrackShards x kShardSlotDoubles: when given, the shard rows go to the host
+                                 // (each behind its own word) and the second fan-in level runs there
     unsigned long long word;     // what is released behind host_row once it is complete
     double tag;                  // pass number carried by every row (last column): a stale row cannot pass for a fresh one
 };
@@ -1162,12 +1164,28 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    double shard_v = 0.0;
     if (tid < kPartWidth) {
-        double v = s_fold[0][tid];
-        for (int g2 = 1; g2 < RG; ++g2) v += s_fold[g2][tid];
-        if (tid == kPartWidth - 1) v = stale ? -1.0 : fold.tag;       // the shard row's own tag
-        store_sc1(&fold.shard_rows[shard * kPartWidth + tid], v);
+        shard_v = s_fold[0][tid];
+        for (int g2 = 1; g2 < RG; ++g2) shard_v += s_fold[g2][tid];
+        if (tid == kPartWidth - 1) shard_v = stale ? -1.0 : fold.tag;  // the shard row's own tag
     }
+    if (fold.host_shards) {
+        // Single-rank hand-off: the (at most 8) shard rows go straight to pinned host memory, each behind its own
+        // pass word, and the host adds them in shard order -- the second level of the fan-in (another device-scope
+        // hand-off: store, drain, atomic, load) is a few hundred host cycles instead of ~2 us on the device.
+        if (tid < 64) {
+            double* slot = fold.host_shards + (size_t)shard * kShardSlotDoubles;
+            if (tid < kPartWidth) slot[tid] = shard_v;
+            if (tid == 0) __hip_atomic_store(&fold.ctr[32 * shard], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next pass
+            __threadfence_system();
+            if (tid == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + kPartWidth), fold.word, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (tid < kPartWidth) store_sc1(&fold.shard_rows[shard * kPartWidth + tid], shard_v);
     __syncthreads();
     if (tid < 64) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1263,7 +1281,7 @@ size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blo
 // One launch per pass: rows, fan-in and result row inside track_kernel.  ctr: track_fold_counter_words() unsigned, zero
 // before the first pass (the kernel re-zeroes them); shard rows live behind the per-workgroup rows in `partials`.
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
-                               double* partials, unsigned* ctr, double* red_dev, double* host_row,
+                               double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
                                unsigned long long word, unsigned long long pass) {
     const int nb = track_num_blocks(p.n_samples);
     if (nb <= 0) return hipErrorInvalidValue;
@@ -1272,6 +1290,7 @@ hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2
     f.shard_rows = partials + (size_t)nb * kPartWidth;
     f.red_dev = red_dev;
     f.host_row = host_row;
+    f.host_shards = host_shards;
     f.word = word;
     f.tag = (double)(pass & 0xFFFFFFFFFFFFull);
     track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, f);
@@ -1279,6 +1298,10 @@ hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2
 }
 
 size_t track_fold_counter_words() { return 32 * (size_t)(kTrackShards + 1); }
+int track_num_shards(int32_t n_samples) {
+    const int nb = track_num_blocks(n_samples);
+    return nb < kTrackShards ? nb : kTrackShards;
+}
 
 // ------------------------------------------------------------------------------------------------
 // (de)interleave helpers for tsdf_download / tsdf_upload (reference-order host mirrors)
