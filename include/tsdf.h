@@ -123,7 +123,8 @@ int tsdf_get_pose(const tsdf_handle *h, double rot[9], double trans[3],
                   double rot_inv[9], double rot_inv_trans[3]);    /* any pointer may be NULL */
 
 /* ---- per-frame input ------------------------------------------------------------------------
- * tsdf_set_frame copies host images to the device (pinned staging, async).  nrm / rgb may be NULL
+ * tsdf_set_frame copies host images to the device (through pinned staging; page-locked caller buffers -- hipHostMalloc /
+ * hipHostRegister -- are copied from directly; either way the buffers are only borrowed for the call).  nrm / rgb may be NULL
  * (tracking needs xyz only; integration needs nrm; rgb is needed only when with_color = 1).
  * tsdf_set_frame_device borrows DEVICE pointers (same layouts) that must stay valid until the next
  * set_frame* call or destroy, and whose contents must be complete when the call is made.

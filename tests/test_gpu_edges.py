@@ -148,3 +148,20 @@ def test_many_handles_are_created_and_released_cleanly():
             free0 = free
         if it > 2:
             assert free >= free0 - (64 << 20), (it, free0, free)      # allocator granularity, not growth
+
+
+def test_page_locked_caller_buffers_are_copied_from_directly_with_the_same_result():
+    """tsdf_set_frame takes page-locked host buffers without the staging memcpy; the buffers are still only borrowed
+    for the call (overwriting them right after it must not change the frame)."""
+    import torch
+    seq, (xyz, nrm, rgb) = render(160, 120)
+    a, ta = make_gpu(48, seq.K)
+    b, tb = make_gpu(48, seq.K)
+    a.update(ta, xyz, nrm, rgb)
+    pin = [torch.from_numpy(v).pin_memory() for v in (xyz, nrm, rgb)]
+    px, pn_, pc = (t.numpy() for t in pin)
+    b.set_frame(px, pn_, pc)
+    px[:] = np.nan; pn_[:] = 0; pc[:] = 0                      # the call has returned: the library must not read them any more
+    b.update(tb)
+    assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(a.download(), b.download()))
+    assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(a.download_color(), b.download_color()))

@@ -72,6 +72,25 @@ def test_a_failing_rank_fails_the_launcher(tmp_path):
     assert "GPU(s) visible" in p.stderr and "stopping the other ranks" in p.stderr
 
 
+@pytest.mark.parametrize("config,image", [(4, [640, 480]), (5, [1280, 960])])
+def test_config4_and_5_workloads_run_sharded(tmp_path, config, image):
+    """The weak-scaling workloads of BASELINE configs 4 and 5 (fr3 intrinsics / 1280x960 images, m = m8 (N/8)^(1/3)) through
+    the self-launching bench with two ranks; a small --voxels override keeps the test short, the unsharded run of the
+    same command must give the same trajectory."""
+    args = ["--config", str(config), "--voxels", "160", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = []
+    for n in (1, 2):
+        traj = str(tmp_path / f"c{config}_n{n}.txt")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--trajectory-out", traj] + args
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert j["n_gpus"] == n and j["scaling"] == "weak" and j["config"]["config"] == config and j["config"]["image"] == image
+        out.append(np.loadtxt(traj))
+    assert np.array_equal(out[0], out[1])
+
+
 def test_device_published_rows_give_the_same_trajectory(tmp_path):
     """TSDF_HOST_FOLD=0: every rank's final kernel writes its row into the shared segment through the
     hipHostRegister alias (the path used when the host fold is off); same bits as the host-folded default."""

@@ -82,6 +82,7 @@ struct tsdf_handle {
     // read buffer b (the tracker passes are host-synchronous and need no event).
     hipStream_t fstream = nullptr;
     hipEvent_t ev_frame = nullptr;
+    hipEvent_t ev_copied = nullptr;            // the H2D copies of a frame handed over in page-locked caller buffers
     hipEvent_t ev_buf_used[2] = {nullptr, nullptr};
     bool used_valid[2] = {false, false};
     bool used_untracked[2] = {false, false};   // read by an integration that recorded no event
@@ -657,6 +658,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
@@ -722,6 +724,7 @@ void tsdf_destroy(tsdf_handle* h) {
         if (h->ev_buf_used[b]) (void)hipEventDestroy(h->ev_buf_used[b]);
     }
     if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
+    if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
@@ -799,6 +802,15 @@ int tsdf_get_pose(const tsdf_handle* h, double rot[9], double trans[3], double r
 
 // ---- frames ------------------------------------------------------------------------------------------
 
+namespace {
+// Is this host pointer page-locked memory HIP can copy from directly (hipHostMalloc / hipHostRegister)?
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
 int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
     if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame: bad argument") : TSDF_E_BADARG;
     int rc = bind_device(h);
@@ -806,18 +818,27 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     rc = ensure_frame_buffers(h, width, height, true);
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
+    // Page-locked caller buffers are copied from directly (no staging pass through the library's own pinned buffers:
+    // at 640x480 that memcpy is 8.3 MB per frame, longer than the frame's GPU work); the copies are complete when the
+    // call returns, so the buffers are borrowed for the call only, as for pageable ones.
+    const bool direct = is_pinned_host(xyz) && (!nrm || is_pinned_host(nrm)) && (!rgb || is_pinned_host(rgb));
     // the pinned staging buffers may still feed the previous frame's async copies (frame stream only: the
     // integration of the previous frame keeps running on the main stream meanwhile)
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
-    std::memcpy(h->pin_xyz, xyz, npix * 3 * sizeof(float));
-    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, h->pin_xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
-    if (nrm) {
-        std::memcpy(h->pin_nrm, nrm, npix * 3 * sizeof(float));
-        HIP_TRY(h, hipMemcpyAsync(h->in_nrm, h->pin_nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (!direct) {
+        std::memcpy(h->pin_xyz, xyz, npix * 3 * sizeof(float));
+        if (nrm) std::memcpy(h->pin_nrm, nrm, npix * 3 * sizeof(float));
+        if (rgb) std::memcpy(h->pin_rgb, rgb, npix * 3);
     }
-    if (rgb) {
-        std::memcpy(h->pin_rgb, rgb, npix * 3);
-        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, direct ? xyz : h->pin_xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, direct ? nrm : h->pin_nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, direct ? rgb : h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+    if (direct) {
+        HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
+        rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventSynchronize(h->ev_copied));      // the caller's buffers have been read
+        return TSDF_OK;
     }
     return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
 }

@@ -382,11 +382,10 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     int cnt = 0;
     __shared__ float4 s_pieces[kIntegrateBlock / 64][128];   // wave-private un-shuffle buffer of the paired gather
 
-    // One pipeline step = S1(j) | S3(j-2) | S2(j-1), written so that everything except the rare f64 cosine
-    // and the two predicated stores is straight-line code: the three stages are independent instruction
-    // streams and the scheduler can interleave them (f64 chains are latency-bound on their own; at 4 waves
-    // per SIMD the VALU otherwise idles half the time).  Loads are issued on every path (dead lanes read a
-    // cache-resident line) so hipcc emits counted s_waitcnt vmcnt(N), never vmcnt(0), inside the loop.
+    // One pipeline step = S1(j) | S3(j-1-DEPTH) | S2(j-1): three independent instruction streams the scheduler can
+    // interleave (f64 chains are latency-bound on their own).  Loads are issued on every path (dead lanes re-read a
+    // line that is fetched anyway) so hipcc emits counted s_waitcnt vmcnt(N), never vmcnt(0), inside the loop; the
+    // stores and the rare f64 cosine are the only predicated parts.
     const long long own_row0 = (long long)(p.g.own_x0 - p.g.xs) * m, own_row1 = (long long)(p.g.own_x1 - p.g.xs) * m;
     auto step = [&](int j, GatherState& g /*out: item j*/, const GatherState& gin /*item j-1, record arrived*/,
                     UpdateState& u /*out: item j-1*/, const UpdateState& uin /*item j-2, volume data arrived*/) {
@@ -586,9 +585,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         // that in-flight registers never have to be copied (a copy would force the wait):
         //   step j:  S1(j) request pixel record | S2(j-1) request {D,W}/colour | S3(j-1-DEPTH) average + store
         // DEPTH = steps between the volume request of an item and its use: DEPTH + 1 update states rotate, i.e.
-        // DEPTH items' worth of HBM reads (1.5 KB each) stay in flight per wavefront.  The launch is bound by
-        // bytes in flight (Little's law: ~2 us loaded HBM latency x 5 TB/s = 10 MB chip-wide = 2.4 KB per wavefront at
-        // 4 waves per SIMD), which one item per wavefront does not supply.
+        // DEPTH items' worth of HBM reads (1.5 KB each) stay in flight per wavefront.  Measured at 512^3: DEPTH 1 / 2 /
+        // 3 = 138.5 / 138.1 / 140.4 us per launch (119 / 127 VGPRs for 2 / 3, still 4 waves per SIMD) -- the launch is
+        // not bound by bytes in flight but by L1 transactions and f64 issue per item; 1 it stays.
         constexpr int NU = TSDF_INTEGRATE_DEPTH + 1, NG = 2;
         constexpr int PERIOD = (NU % 2 == 0) ? NU : 2 * NU;
         GatherState G[NG];
