@@ -72,6 +72,17 @@ CYLINDERS = (
     (-2.0, -2.8, 0.3, -0.3, 2.8, 5),
     (-1.9, -0.4, 0.18, -0.3, 1.1, 4), (1.1, 1.0, 0.22, -0.3, 0.9, 4),      # free-standing posts
 )
+# The round-1 benchmark scene (an almost empty room: one ball, a table, a cabinet), kept as a fixed yardstick: kernel
+# timings of different rounds are only comparable on the same workload (Sequence(scene="room"), bench.py's
+# `round1_scene` leg).  The tracker loses the camera on it at 256^3 -- it is not a tracking benchmark.
+ROOM_SCENE = {
+    "spheres": (((-1.3, -1.9, 0.9), 0.45, 1),),
+    "boxes": (((0.9, -2.7, -0.3), (2.1, -1.6, 0.45), 2), ((-0.35, -2.75, -0.3), (0.35, -2.35, 1.3), 3)),
+    "cylinders": (),
+}
+PLANT_SCENE = {"spheres": SPHERES, "boxes": BOXES, "cylinders": CYLINDERS}
+SCENES = {"plant": PLANT_SCENE, "room": ROOM_SCENE}
+
 BASE_COLOURS = np.array([[200, 200, 190], [60, 160, 70], [170, 110, 60], [90, 90, 170], [180, 70, 70],
                          [150, 150, 165]], dtype=np.float64)
 
@@ -197,7 +208,7 @@ def _ray_cylinder(o, d, cx, cy, r, z0, z1):
 
 
 def render_frame(R, t, K, width=640, height=480, noise=False, holes=0.0, max_depth=5.0, min_depth=0.4,
-                 rng=None):
+                 rng=None, scene="plant"):
     """Render one organised cloud from camera-to-world pose (R, t).
 
     noise: Kinect-like axial noise sigma(z) = 0.0012 + 0.0019 (z - 0.4)^2 metres; holes: fraction of
@@ -214,11 +225,12 @@ def render_frame(R, t, K, width=640, height=480, noise=False, holes=0.0, max_dep
         nonlocal best, nrm, prim
         m = s < best
         best = np.where(m, s, best); nrm = np.where(m[..., None], n, nrm); prim = np.where(m, colour, prim)
-    for c, r, colour in SPHERES:
+    sc = SCENES[scene]
+    for c, r, colour in sc["spheres"]:
         take(*_ray_sphere(o, dw, np.asarray(c), r), colour)
-    for lo, hi, colour in BOXES:
+    for lo, hi, colour in sc["boxes"]:
         take(*_ray_box_outside(o, dw, np.asarray(lo), np.asarray(hi)), colour)
-    for cx, cy, r, z0, z1, colour in CYLINDERS:
+    for cx, cy, r, z0, z1, colour in sc["cylinders"]:
         take(*_ray_cylinder(o, dw, cx, cy, r, z0, z1), colour)
     z = best.copy()
     pw = o + z[..., None] * dw                       # exact world hit point (for the texture)
@@ -251,8 +263,11 @@ def render_frame(R, t, K, width=640, height=480, noise=False, holes=0.0, max_dep
 class TorchRenderer:
     """render(R, t) -> (xyz, nrm, rgb) torch tensors on `device`, shaped like render_frame's arrays."""
 
-    def __init__(self, K, width=640, height=480, device="cpu", max_depth=5.0, min_depth=0.4):
+    def __init__(self, K, width=640, height=480, device="cpu", max_depth=5.0, min_depth=0.4, scene="plant"):
         import torch
+        sc = SCENES[scene]
+        SPHERES, BOXES = sc["spheres"], sc["boxes"]
+        CYLINDERS = sc["cylinders"] or ((0.0, 0.0, 0.01, -9.0, -8.9, 0),)      # a degenerate one far below the room keeps the tensor shapes
         self.torch = torch
         self.dev = torch.device(device)
         f64 = dict(dtype=torch.float64, device=self.dev)
@@ -379,7 +394,8 @@ class TorchRenderer:
 class Sequence:
     """The synthetic stand-in for a TUM sequence: frames rendered on demand along fr1/plant."""
 
-    def __init__(self, n_frames=100, width=640, height=480, noise=False, holes=0.0, seed=0, step=1, K=None):
+    def __init__(self, n_frames=100, width=640, height=480, noise=False, holes=0.0, seed=0, step=1, K=None, scene="plant"):
+        self.scene = scene
         self.width, self.height = int(width), int(height)
         self.K = default_intrinsics(width, height) if K is None else np.asarray(K, dtype=np.float64)
         self.stamps, self.R, self.t = load_trajectory(n_frames, step)
@@ -391,13 +407,14 @@ class Sequence:
 
     def frame(self, k):
         rng = np.random.default_rng([self.seed, k])
-        return render_frame(self.R[k], self.t[k], self.K, self.width, self.height, self.noise, self.holes, rng=rng)
+        return render_frame(self.R[k], self.t[k], self.K, self.width, self.height, self.noise, self.holes, rng=rng,
+                            scene=self.scene)
 
     def frame_torch(self, k, device="cuda"):
         """Frame k rendered with torch on `device` (device tensors; the noise differs from frame(k)'s)."""
         import torch
         if self._tr is None or str(self._tr.dev) != str(torch.device(device)):
-            self._tr = TorchRenderer(self.K, self.width, self.height, device)
+            self._tr = TorchRenderer(self.K, self.width, self.height, device, scene=self.scene)
             self._gen = torch.Generator(device=self._tr.dev)
         self._gen.manual_seed(self.seed * 1000003 + k)
         return self._tr.render(self.R[k], self.t[k], self.noise, self.holes, self._gen)
