@@ -66,3 +66,11 @@ refcall_demo: $(LIB)
 	g++ -std=c++11 -O2 -Wall -Wextra -DTSDF_WITH_EIGEN_PCL -DTSDF_WITH_ROS -I$(ROOT)tests/mock -I$(ROOT)include \
 	    -o $(ROOT)build/refcall_demo $(ROOT)tests/mock/refcall_demo.cpp -L$(LIBDIR) -ltsdf_hip -Wl,-rpath,$(LIBDIR)
 .PHONY: refcall_demo
+
+# stand-in for librccl over POSIX shared memory (tests/mock_rccl): lets TWO ranks on the one GPU of the test box drive the
+# in-library RCCL code path (select it with TSDF_RCCL_LIBRARY=build/libmock_rccl.so); test infrastructure only
+mock_rccl:
+	@mkdir -p $(ROOT)build
+	gcc -O2 -Wall -Wextra -shared -fPIC -I/opt/rocm/include -o $(ROOT)build/libmock_rccl.so $(ROOT)tests/mock_rccl/mock_rccl.c \
+	    -L/opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib
+.PHONY: mock_rccl

@@ -78,6 +78,9 @@ def parse(argv=None):
     ap.add_argument("--timing-period", type=int, default=4, help="HIP events around every n-th integrate/pack launch")
     ap.add_argument("--trajectory-out", default=None, help="write the estimated trajectory (TUM format)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rccl-under-gloo", action="store_true",
+                    help="keep the in-library RCCL exchange step as a candidate under --dist-backend gloo (ranks sharing one GPU: "
+                         "only with TSDF_RCCL_LIBRARY pointing at a library that accepts that, e.g. the tests' shared-memory mock)")
     return ap.parse_args(argv)
 
 
@@ -483,7 +486,7 @@ def run(args):
         s.comm_finalize()
         s.set_allreduce_hook(None)
         order = {"rccl": ["rccl", "shm"], "shm": ["shm"], "torch": []}[want]
-        if args.dist_backend != "nccl" and "rccl" in order:
+        if args.dist_backend != "nccl" and "rccl" in order and not args.rccl_under_gloo:
             order.remove("rccl")               # ranks may share a GPU under gloo: RCCL refuses that
         for mode in order:
             ok = init_rccl(s) if mode == "rccl" else init_shm(s)
@@ -499,7 +502,7 @@ def run(args):
     if world > 1:
         # time both in-library exchange steps on this machine (reported either way)
         for mode in ("rccl", "shm"):
-            if mode == "rccl" and args.dist_backend != "nccl":
+            if mode == "rccl" and args.dist_backend != "nccl" and not args.rccl_under_gloo:
                 continue
             if (init_rccl(sdf) if mode == "rccl" else init_shm(sdf)):
                 good, us = probe(sdf)

@@ -91,6 +91,21 @@ def test_config4_and_5_workloads_run_sharded(tmp_path, config, image):
     assert np.array_equal(out[0], out[1])
 
 
+def test_in_library_rccl_code_path_with_two_ranks_over_a_mock_collective(tmp_path):
+    """RCCL refuses two ranks on one device and this box has one, so the N > 1 run of the in-library RCCL path
+    (communicator from a broadcast id, tracker result row -> collective on the library's stream -> publish kernel ->
+    host polling) is driven through tests/mock_rccl: the same five entry points with rccl.h's ABI, implemented over
+    shared memory (TSDF_RCCL_LIBRARY selects it).  It proves the product's code around the collective, not RCCL."""
+    subprocess.check_call(["make", "-C", ROOT, "-s", "mock_rccl"])
+    mock = os.path.join(ROOT, "build", "libmock_rccl.so")
+    j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
+    jn, tn = run_bench(["--allreduce", "rccl", "--rccl-under-gloo"], 2, str(tmp_path / "t2.txt"), 29671, env={"TSDF_RCCL_LIBRARY": mock})
+    assert jn["n_gpus"] == 2 and jn["config"]["allreduce"] == "rccl-in-library"
+    assert "rccl" in jn["config"]["exchange_step_us_measured"] and "shm" in jn["config"]["exchange_step_us_measured"]
+    assert np.array_equal(t1, tn) and abs(jn["ate_rmse_m"] - j1["ate_rmse_m"]) < 1e-9
+    assert jn["gn_iterations_per_frame"] == j1["gn_iterations_per_frame"]
+
+
 def test_device_published_rows_give_the_same_trajectory(tmp_path):
     """TSDF_HOST_FOLD=0: every rank's final kernel writes its row into the shared segment through the
     hipHostRegister alias (the path used when the host fold is off); same bits as the host-folded default."""
