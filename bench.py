@@ -585,8 +585,11 @@ def run(args):
         depth16 = [np.where(np.isnan(x[..., 2]), 0, np.round(x[..., 2] * 5000.0)).astype(np.uint16) for x, _, _ in host_frames]
         e3 = best_of_two("depth", host_frames, depth16)
         extras["value_depth_input_inclusive"] = args.steps / e3
-        extras["depth_input_note"] = ("raw uint16 depth + rgb (5 B/pixel) as host buffers; back-projection, bilateral filter "
+        extras["depth_input_note"] = ("raw uint16 depth + rgb (5 B/pixel) as host buffers; back-projection, bilateral-grid filter "
                                       "and normals on the GPU (tsdf_set_depth_frame; PCL parity of that stage is unpinned)")
+        pin16 = [torch.from_numpy(d.view(np.int16)).pin_memory() for d in depth16]
+        e3p = best_of_two("depth", pinned_frames, [t.numpy().view(np.uint16) for t in pin16])
+        extras["value_depth_input_inclusive_pinned_buffers"] = args.steps / e3p
     if n1_extras:
         guarded("h2d_inclusive", leg_h2d)
 

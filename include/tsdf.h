@@ -149,6 +149,8 @@ typedef struct tsdf_preproc_params {
     int32_t radius;             /* bilateral window radius, pixels; 0 = no filtering; <= 32 (default 2*sigma_s capped) */
     int32_t normal_radius;      /* gradient averaging radius, pixels (reference smoothing size 10 -> 5); 1..8      */
     float   max_depth_change;   /* depth-discontinuity factor (reference 0.02)                                    */
+    int32_t grid_filter;        /* 1 (default): bilateral GRID (Paris & Durand; the algorithm family of pcl::FastBilateralFilter),
+                                   sigma_s in [1, 30], `radius` only switches it off (0); 0: exact windowed filter of `radius` */
 } tsdf_preproc_params;
 void tsdf_default_preproc(tsdf_preproc_params *p);
 /* depth16 (uint16) or depthf (float metres, <= 0 / NaN invalid): exactly one non-null; host pointers; rgb may be null */

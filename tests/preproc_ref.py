@@ -3,7 +3,8 @@ tracking_sdf_amd/csrc/preproc_kernels.hip).  TEST INFRASTRUCTURE ONLY.
 
 The reference pre-processes with PCL (sdf_reconstruction.cpp:29-49), which is neither in the reference tree
 nor in this image: PARITY WITH PCL IS UNPINNED.  Every float operation below is done in float32, in the same
-order as the kernels (taps row by row), so the two agree to the last bits except for expf.
+order as the kernels, so the two agree to the last bits except for expf; the bilateral-grid
+filter (grid_filter=1, the default) has no transcendental in it and agrees bit for bit.
 """
 import numpy as np
 
@@ -45,6 +46,71 @@ def bilateral(z, R, sigma_s, sigma_r):
     return out
 
 
+GRID_PAD = 2
+
+
+def _blur_axis(G, axis):
+    """Two passes of [1 2 1]/4 along `axis` over the cells interior in all three axes; face cells stay."""
+    for _ in range(2):
+        N = G.copy()
+        inner = G[1:-1, 1:-1, 1:-1]
+        lo = [slice(1, -1)] * 3; hi = [slice(1, -1)] * 3
+        lo[axis] = slice(0, -2); hi[axis] = slice(2, None)
+        N[1:-1, 1:-1, 1:-1] = (((G[tuple(lo)] + G[tuple(hi)]).astype(F) + (F(2.0) * inner).astype(F)).astype(F) * F(0.25)).astype(F)
+        G = N
+    return G
+
+
+def bilateral_grid(z, sigma_s, sigma_r):
+    """Bilateral grid (Paris & Durand 2006; the algorithm family of pcl::FastBilateralFilter): nearest-cell splat of
+    (z, 1) with exact depth sums, [1 2 1]/4 twice per axis, trilinear slice, z' = S / W."""
+    h, w = z.shape
+    P = GRID_PAD
+    ss, sr = F(sigma_s), F(sigma_r)
+    valid = ~np.isnan(z)
+    if not valid.any():
+        return z.copy()
+    zv = z[valid]
+    zmin, zmax = zv.min(), zv.max()
+    gx = int(F(w - 1) / ss) + 1 + 2 * P
+    gy = int(F(h - 1) / ss) + 1 + 2 * P
+    gz = int(F(zmax - zmin) / sr) + 1 + 2 * P
+    ys, xs = np.nonzero(valid)
+    cx = (xs.astype(F) / ss + F(0.5)).astype(np.int64) + P
+    cy = (ys.astype(F) / ss + F(0.5)).astype(np.int64) + P
+    cz = ((zv - zmin).astype(F) / sr + F(0.5)).astype(np.int64) + P
+    Si = np.zeros((gx, gy, gz), dtype=np.int64)                 # exact sums of trunc(z * 2^32), rounded to f32 once
+    Wi = np.zeros((gx, gy, gz), dtype=np.int64)
+    np.add.at(Si, (cx, cy, cz), (zv.astype(np.float64) * 4294967296.0).astype(np.int64))
+    np.add.at(Wi, (cx, cy, cz), 1)
+    S = (Si.astype(np.float64) * (1.0 / 4294967296.0)).astype(F)
+    W = Wi.astype(F)
+    for axis in range(3):
+        S = _blur_axis(S, axis)
+        W = _blur_axis(W, axis)
+    px = (xs.astype(F) / ss + F(P)).astype(F)
+    py = (ys.astype(F) / ss + F(P)).astype(F)
+    pz = ((zv - zmin).astype(F) / sr + F(P)).astype(F)
+    xi, yi, zi = px.astype(np.int64), py.astype(np.int64), pz.astype(np.int64)
+    xa, ya, za = (px - xi.astype(F)).astype(F), (py - yi.astype(F)).astype(F), (pz - zi.astype(F)).astype(F)
+    xi, yi, zi = np.clip(xi, 0, gx - 1), np.clip(yi, 0, gy - 1), np.clip(zi, 0, gz - 1)
+    xx, yy, zz = np.minimum(xi + 1, gx - 1), np.minimum(yi + 1, gy - 1), np.minimum(zi + 1, gz - 1)
+    xb, yb, zb = (F(1.0) - xa).astype(F), (F(1.0) - ya).astype(F), (F(1.0) - za).astype(F)
+    accS = accW = None
+    for (wx, ix), (wy, iy), (wz, iz) in [((xb, xi), (yb, yi), (zb, zi)), ((xa, xx), (yb, yi), (zb, zi)),
+                                          ((xb, xi), (ya, yy), (zb, zi)), ((xa, xx), (ya, yy), (zb, zi)),
+                                          ((xb, xi), (yb, yi), (za, zz)), ((xa, xx), (yb, yi), (za, zz)),
+                                          ((xb, xi), (ya, yy), (za, zz)), ((xa, xx), (ya, yy), (za, zz))]:
+        wgt = ((wx * wy).astype(F) * wz).astype(F)
+        tS, tW = (wgt * S[ix, iy, iz]).astype(F), (wgt * W[ix, iy, iz]).astype(F)
+        accS = tS if accS is None else (accS + tS).astype(F)
+        accW = tW if accW is None else (accW + tW).astype(F)
+    out = np.full((h, w), np.nan, dtype=F)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out[valid] = (accS / accW).astype(F)
+    return out
+
+
 def backproject(z, zf, K):
     h, w = z.shape
     fx, fy, cx, cy = F(K[0, 0]), F(K[1, 1]), F(K[0, 2]), F(K[1, 2])
@@ -73,17 +139,19 @@ def normals(xyz, r, max_change):
     dh[1:-1, 1:-1] = np.where(valid[..., None], rr - l, 0).astype(F)
     dv[1:-1, 1:-1] = np.where(valid[..., None], dn - up, 0).astype(F)
     ok[1:-1, 1:-1] = valid
-    # windowed sums, taps row by row (same order as the kernel)
-    pdh = np.zeros((h + 2 * r, w + 2 * r, 3), dtype=F); pdh[r:r + h, r:r + w] = dh
-    pdv = np.zeros((h + 2 * r, w + 2 * r, 3), dtype=F); pdv[r:r + h, r:r + w] = dv
-    pok = np.zeros((h + 2 * r, w + 2 * r), dtype=bool); pok[r:r + h, r:r + w] = ok
-    sh = np.zeros((h, w, 3), dtype=F); sv = np.zeros((h, w, 3), dtype=F); cnt = np.zeros((h, w), dtype=F)
-    for dy in range(-r, r + 1):
-        for dx in range(-r, r + 1):
-            m = pok[r + dy:r + dy + h, r + dx:r + dx + w]
-            sh = np.where(m[..., None], (sh + pdh[r + dy:r + dy + h, r + dx:r + dx + w]).astype(F), sh)
-            sv = np.where(m[..., None], (sv + pdv[r + dy:r + dy + h, r + dx:r + dx + w]).astype(F), sv)
-            cnt = cnt + m.astype(F)
+    # windowed sums, separably like the kernel: each row left to right, then the row sums top to bottom
+    # (an invalid gradient is stored as zeros, so adding it is the same as skipping it)
+    def box(a):
+        pad = np.zeros((h + 2 * r, w + 2 * r) + a.shape[2:], dtype=F)
+        pad[r:r + h, r:r + w] = a
+        rows = np.zeros((h + 2 * r, w) + a.shape[2:], dtype=F)
+        for dx in range(2 * r + 1):
+            rows = (rows + pad[:, dx:dx + w]).astype(F)
+        out = np.zeros((h, w) + a.shape[2:], dtype=F)
+        for dy in range(2 * r + 1):
+            out = (out + rows[dy:dy + h]).astype(F)
+        return out
+    sh, sv, cnt = box(dh), box(dv), box(ok.astype(F))
     c0 = (sv[..., 1] * sh[..., 2]).astype(F) - (sv[..., 2] * sh[..., 1]).astype(F)
     c1 = (sv[..., 2] * sh[..., 0]).astype(F) - (sv[..., 0] * sh[..., 2]).astype(F)
     c2 = (sv[..., 0] * sh[..., 1]).astype(F) - (sv[..., 1] * sh[..., 0]).astype(F)
@@ -99,8 +167,11 @@ def normals(xyz, r, max_change):
 
 
 def preprocess(depth, K, depth_scale=1.0 / 5000.0, sigma_s=15.0, sigma_r=0.05, radius=30, normal_radius=5,
-               max_depth_change=0.02):
+               max_depth_change=0.02, grid_filter=1):
     z = depth_to_z(depth, depth_scale)
-    zf = bilateral(z, radius, sigma_s, sigma_r)
+    if grid_filter and radius > 0:
+        zf = bilateral_grid(z, sigma_s, sigma_r)
+    else:
+        zf = bilateral(z, radius, sigma_s, sigma_r)
     xyz = backproject(z, zf, K)
     return xyz, normals(xyz, normal_radius, max_depth_change)

@@ -1,6 +1,7 @@
 """GPU depth pre-processing (tsdf_set_depth_frame) against its NumPy statement (tests/preproc_ref.py).
-Tolerances: z within 2e-6 relative (expf differs in the last bits between ocml and NumPy), x,y bit-exact,
-normals within 2e-4 (angle) where both are defined, identical NaN masks away from ties."""
+Tolerances: x,y bit-exact; z bit-exact with the bilateral grid (grid_filter=1, the default), within 2e-6 relative
+with the windowed filter (expf differs in the last bits between the GPU and NumPy); normals within 2e-4 (angle)
+where both are defined, identical NaN masks away from ties."""
 import numpy as np
 import pytest
 
@@ -22,10 +23,15 @@ def depth_image(w, h, k=0, to_u16=True):
 
 
 @pytest.mark.parametrize("w,h,params", [
-    (96, 72, dict(radius=4, sigma_s=2.0, sigma_r=0.03, normal_radius=2)),
-    (160, 120, dict(radius=9, sigma_s=4.5, sigma_r=0.05, normal_radius=5)),
-    (64, 48, dict()),                                   # PCL-like defaults: sigma_s 15, radius 30
+    (96, 72, dict(radius=4, sigma_s=2.0, sigma_r=0.03, normal_radius=2, grid_filter=0)),
+    (160, 120, dict(radius=9, sigma_s=4.5, sigma_r=0.05, normal_radius=5, grid_filter=0)),
+    (64, 48, dict(grid_filter=0)),                      # windowed, PCL-like sigmas: sigma_s 15, radius 30
     (80, 60, dict(radius=0, normal_radius=1)),          # no filtering
+    (64, 48, dict()),                                   # the defaults: bilateral grid, sigma_s 15, sigma_r 0.05
+    (160, 120, dict(sigma_s=4.5, sigma_r=0.05)),
+    (203, 117, dict(sigma_s=7.3, sigma_r=0.021, normal_radius=3)),   # ragged cells, many depth cells
+    (96, 72, dict(sigma_s=1.0, sigma_r=0.5)),           # one pixel per cell
+    (320, 240, dict(sigma_s=30.0, sigma_r=0.05)),       # the largest cell (961 pixels)
 ])
 def test_preprocessing_matches_numpy_statement(w, h, params):
     import tracking_sdf_amd as ts
@@ -39,6 +45,8 @@ def test_preprocessing_matches_numpy_statement(w, h, params):
     assert np.array_equal(np.isnan(xyz[..., 2]), np.isnan(want_xyz[..., 2]))
     ok = ~np.isnan(want_xyz[..., 2])
     assert np.array_equal(xyz[..., :2][ok], want_xyz[..., :2][ok])                 # raw back-projection: exact
+    if params.get("grid_filter", 1) and params.get("radius", 30) > 0:
+        assert np.array_equal(xyz[..., 2][ok], want_xyz[..., 2][ok])               # bilateral grid: exact
     assert np.max(np.abs(xyz[..., 2][ok] - want_xyz[..., 2][ok]) / want_xyz[..., 2][ok]) < 2e-6
     both = ~np.isnan(nrm[..., 0]) & ~np.isnan(want_n[..., 0])
     assert (np.isnan(nrm[..., 0]) != np.isnan(want_n[..., 0])).mean() < 2e-3        # discontinuity-test ties only
@@ -89,6 +97,18 @@ def test_preproc_argument_checks():
     t.set_K(synth.default_intrinsics(64, 48))
     with pytest.raises(ts.TsdfError):
         s.set_depth_frame(d, radius=40)
+    for bad in (dict(sigma_s=0.5), dict(sigma_s=31.0), dict(depth_scale=0.0)):
+        with pytest.raises(ts.TsdfError) as ei:
+            s.set_depth_frame(d, **bad)
+        assert ei.value.code == ts.E_BADARG
+    deep = np.zeros((48, 64), dtype=np.float32); deep[0, 0] = 1.0; deep[1, 1] = np.inf
+    with pytest.raises(ts.TsdfError) as ei:
+        s.set_depth_frame(deep)                            # an infinite depth range is not a grid
+    assert ei.value.code == ts.E_BADARG
+    one = np.zeros((48, 64), dtype=np.uint16); one[20, 30] = 5000
+    s.set_depth_frame(one)                                 # a single valid pixel filters to itself
+    xyz1, _ = s.get_preprocessed()
+    assert xyz1[20, 30, 2] == np.float32(5000) * np.float32(1.0 / 5000.0) and np.isnan(xyz1[..., 2]).sum() == 48 * 64 - 1
     s.set_depth_frame(d, radius=2)                         # all-invalid depth: fine, everything NaN
     xyz, nrm = s.get_preprocessed()
     assert np.isnan(xyz).all() and np.isnan(nrm).all()

@@ -5,6 +5,7 @@
 //
 //   sdf_offline <tum_dir> <voxels> <trajectory.txt> [max_frames] [fx fy cx cy] [bilateral_radius] [mesh.ply] [groundtruth.txt]
 //
+// bilateral_radius: 0 = no depth filter, > 0 = bilateral grid (the default), < 0 = exact windowed filter of radius |r|.
 // mesh.ply ("-" = none): the visualiser's mesh of the final volume.  groundtruth.txt (TUM format: stamp tx ty tz qx qy qz
 // qw, camera -> world): the reference's _useGroundTruth mode (sdf_reconstruction.cpp:51-66) -- no tracking, every depth
 // frame is fused at the ground-truth pose nearest in time (frames without a pose within 20 ms are skipped).
@@ -174,7 +175,11 @@ int main(int argc, char** argv) {
     if (argc > 8) { K[0] = std::atof(argv[5]); K[4] = std::atof(argv[6]); K[2] = std::atof(argv[7]); K[5] = std::atof(argv[8]); }
     tsdf_preproc_params pp;
     tsdf_default_preproc(&pp);
-    if (argc > 9) pp.radius = std::atoi(argv[9]);
+    if (argc > 9) {                                            // 0: no filter; > 0: bilateral grid; < 0: windowed filter of that radius
+        const int r = std::atoi(argv[9]);
+        pp.radius = r < 0 ? -r : r;
+        pp.grid_filter = r < 0 ? 0 : 1;
+    }
 
     std::ifstream list(dir + "/depth.txt");
     if (!list) { std::fprintf(stderr, "cannot open %s/depth.txt\n", dir.c_str()); return 2; }

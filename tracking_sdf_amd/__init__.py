@@ -45,7 +45,7 @@ class Config(C.Structure):
 class PreprocParams(C.Structure):
     """struct tsdf_preproc_params"""
     _fields_ = [("depth_scale", C.c_float), ("sigma_s", C.c_float), ("sigma_r", C.c_float), ("radius", C.c_int32),
-                ("normal_radius", C.c_int32), ("max_depth_change", C.c_float)]
+                ("normal_radius", C.c_int32), ("max_depth_change", C.c_float), ("grid_filter", C.c_int32)]
 
 
 class IntegrateStats(C.Structure):

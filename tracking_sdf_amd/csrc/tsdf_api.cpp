@@ -73,6 +73,8 @@ struct tsdf_handle {
     size_t in_cap = 0;             // pixels the staging buffers hold
     float* pre_z = nullptr; float* pre_zf = nullptr; void* pre_depth = nullptr; void* pin_depth = nullptr;   // pre-processing scratch
     size_t pre_cap = 0;
+    float2* pre_grid_a = nullptr; float2* pre_grid_b = nullptr; size_t pre_grid_cap = 0;                     // bilateral grid (cells)
+    unsigned* pre_minmax = nullptr; unsigned* pin_minmax = nullptr;                                           // depth range words
     float4* pn = nullptr;          // 2 x float4 per pixel      } the CURRENT frame's buffers: one of the two below
     float4* samples = nullptr;     //                            }
     size_t pn_cap = 0, samples_cap = 0;
@@ -177,7 +179,13 @@ void free_preproc(tsdf_handle* h) {
     if (h->pre_zf) (void)hipFree(h->pre_zf);
     if (h->pre_depth) (void)hipFree(h->pre_depth);
     if (h->pin_depth) (void)hipHostFree(h->pin_depth);
+    if (h->pre_grid_a) (void)hipFree(h->pre_grid_a);
+    if (h->pre_grid_b) (void)hipFree(h->pre_grid_b);
+    if (h->pre_minmax) (void)hipFree(h->pre_minmax);
+    if (h->pin_minmax) (void)hipHostFree(h->pin_minmax);
     h->pre_z = h->pre_zf = nullptr; h->pre_depth = h->pin_depth = nullptr; h->pre_cap = 0;
+    h->pre_grid_a = h->pre_grid_b = nullptr; h->pre_grid_cap = 0;
+    h->pre_minmax = h->pin_minmax = nullptr;
 }
 
 void free_frame(tsdf_handle* h) {
@@ -862,6 +870,7 @@ void tsdf_default_preproc(tsdf_preproc_params* p) {
     p->radius = 30;
     p->normal_radius = 5;
     p->max_depth_change = 0.02f;
+    p->grid_filter = 1;
 }
 
 int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
@@ -873,6 +882,11 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
     if (params) pp = *params; else tsdf_default_preproc(&pp);
     if (pp.radius < 0 || pp.radius > 32 || pp.normal_radius < 1 || pp.normal_radius > 8 || !(pp.sigma_s > 0) || !(pp.sigma_r > 0))
         return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: bad parameters (radius %d, normal_radius %d)", pp.radius, pp.normal_radius);
+    const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
+    if (use_grid && !(pp.sigma_s >= 1.0f && pp.sigma_s <= 30.0f))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: the bilateral grid takes sigma_s in [1, 30] pixels, not %g", (double)pp.sigma_s);
+    if (depth16 && !(pp.depth_scale > 0))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: depth_scale must be positive");
     int rc = bind_device(h);
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, true);
@@ -884,22 +898,63 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
         HIP_TRY(h, hipMalloc((void**)&h->pre_zf, npix * sizeof(float)));
         HIP_TRY(h, hipMalloc((void**)&h->pre_depth, npix * sizeof(float)));
         HIP_TRY(h, hipHostMalloc((void**)&h->pin_depth, npix * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc((void**)&h->pre_minmax, 2 * sizeof(unsigned)));
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_minmax, 2 * sizeof(unsigned), hipHostMallocDefault));
         h->pre_cap = npix;
     }
     HIP_TRY(h, hipStreamSynchronize(h->fstream));          // pinned staging may still feed the previous frame
     const size_t dbytes = npix * (depth16 ? sizeof(uint16_t) : sizeof(float));
-    std::memcpy(h->pin_depth, depth16 ? (const void*)depth16 : (const void*)depthf, dbytes);
-    HIP_TRY(h, hipMemcpyAsync(h->pre_depth, h->pin_depth, dbytes, hipMemcpyHostToDevice, h->fstream));
+    const void* dsrc = depth16 ? (const void*)depth16 : (const void*)depthf;
+    // page-locked caller buffers are copied from directly, as in tsdf_set_frame
+    const bool direct = is_pinned_host(dsrc) && (!rgb || is_pinned_host(rgb));
+    if (!direct) std::memcpy(h->pin_depth, dsrc, dbytes);
+    HIP_TRY(h, hipMemcpyAsync(h->pre_depth, direct ? dsrc : h->pin_depth, dbytes, hipMemcpyHostToDevice, h->fstream));
+    HIP_TRY(h, launch_depth_to_z(h->fstream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
+                                 depth16 ? nullptr : (const float*)h->pre_depth, pp.depth_scale, (int)npix, h->pre_z,
+                                 use_grid ? h->pre_minmax : nullptr));
+    if (use_grid)
+        HIP_TRY(h, hipMemcpyAsync(h->pin_minmax, h->pre_minmax, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->fstream));
     if (rgb) {
-        std::memcpy(h->pin_rgb, rgb, npix * 3);
-        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+        if (!direct) std::memcpy(h->pin_rgb, rgb, npix * 3);
+        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, direct ? rgb : h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+    }
+    if (direct && !use_grid) HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
+    // The grid's depth extent follows the frame's depth range: the one host round trip of this path (8 bytes).
+    BilateralGrid bg;
+    bool grid_on = false;
+    if (use_grid) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        if (h->pin_minmax[0] != 0xffffffffu) {             // else no valid pixel at all: nothing to filter
+            float zmin, zmax;
+            const unsigned lo = h->pin_minmax[0], hi = ~h->pin_minmax[1];
+            std::memcpy(&zmin, &lo, 4); std::memcpy(&zmax, &hi, 4);
+            if (!bilateral_grid_plan(width, height, pp.sigma_s, pp.sigma_r, zmin, zmax, &bg))
+                return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: depth range [%g, %g] m is not a usable bilateral grid at sigma_r %g",
+                            (double)zmin, (double)zmax, (double)pp.sigma_r);
+            const size_t cells = (size_t)bg.gx * bg.gy * bg.gz;
+            if (cells > ((size_t)1 << 26))
+                return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: bilateral grid of %d x %d x %d cells is too large (sigma_s %g, sigma_r %g)",
+                            bg.gx, bg.gy, bg.gz, (double)pp.sigma_s, (double)pp.sigma_r);
+            if (cells > h->pre_grid_cap) {
+                if (h->pre_grid_a) (void)hipFree(h->pre_grid_a);
+                if (h->pre_grid_b) (void)hipFree(h->pre_grid_b);
+                h->pre_grid_a = h->pre_grid_b = nullptr; h->pre_grid_cap = 0;
+                const size_t cap = cells + cells / 2;      // the range moves from frame to frame: head-room
+                HIP_TRY(h, hipMalloc((void**)&h->pre_grid_a, cap * sizeof(float2)));
+                HIP_TRY(h, hipMalloc((void**)&h->pre_grid_b, cap * sizeof(float2)));
+                h->pre_grid_cap = cap;
+            }
+            grid_on = true;
+        }
     }
     const float Kf[4] = {(float)h->K[0], (float)h->K[4], (float)h->K[2], (float)h->K[5]};
-    HIP_TRY(h, launch_preproc(h->fstream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
-                              depth16 ? nullptr : (const float*)h->pre_depth, pp.depth_scale, width, height, Kf,
-                              pp.radius, pp.sigma_s, pp.sigma_r, pp.normal_radius, pp.max_depth_change,
+    HIP_TRY(h, launch_preproc(h->fstream, width, height, Kf, use_grid && !grid_on ? 0 : pp.radius, pp.sigma_s, pp.sigma_r,
+                              pp.normal_radius, pp.max_depth_change, grid_on ? &bg : nullptr, h->pre_grid_a, h->pre_grid_b,
                               h->pre_z, h->pre_zf, h->in_xyz, h->in_nrm));
-    return run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
+    rc = run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
+    if (rc) return rc;
+    if (direct && !use_grid) HIP_TRY(h, hipEventSynchronize(h->ev_copied));   // (the grid path has synchronised already)
+    return TSDF_OK;
 }
 
 int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {

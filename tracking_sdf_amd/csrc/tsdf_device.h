@@ -121,9 +121,16 @@ size_t track_fold_counter_words();
 hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);
 int track_num_blocks(int32_t n_samples);
 size_t track_partials_doubles(int32_t n_samples);
-hipError_t launch_preproc(hipStream_t s, const uint16_t* d16, const float* dflt, float scale, int w, int h,
-                          const float* K /*fx fy cx cy*/, int R, float sigma_s, float sigma_r, int nr, float max_change,
-                          float* z, float* zf, float* xyz, float* nrm);
+// depth -> z plane; with `minmax` (2 words) also min bits / ~max bits of the valid depths (0xffffffff = none)
+hipError_t launch_depth_to_z(hipStream_t s, const uint16_t* d16, const float* dflt, float scale, int n, float* z,
+                             unsigned* minmax);
+struct BilateralGrid { int gx, gy, gz; float zmin; };     // cells per axis (padding included), depth of cell 2
+// false: sigma_s outside [1, 30], or a depth range / sigma_r that is not a sane cell count
+bool bilateral_grid_plan(int w, int h, float sigma_s, float sigma_r, float zmin, float zmax, BilateralGrid* g);
+// bg = nullptr: windowed bilateral of radius R; else the bilateral grid in grid_a / grid_b (gx*gy*gz cells each)
+hipError_t launch_preproc(hipStream_t s, int w, int h, const float* K /*fx fy cx cy*/, int R, float sigma_s, float sigma_r,
+                          int nr, float max_change, const BilateralGrid* bg, float2* grid_a, float2* grid_b,
+                          const float* z, float* zf, float* xyz, float* nrm);
 // row_count / row_offset: mesh_rows(p) entries; group_sum / group_base: mesh_scan_groups(rows) entries (groups of
 // 1024 rows); total: one 64-bit word (triangles).  Row r starts at triangle group_base[r >> 10] + row_offset[r].
 inline long long mesh_rows(const MeshParams& p) { return (long long)(p.ci1 > p.ci0 ? p.ci1 - p.ci0 : 0) * (p.g.m - 2); }
