@@ -19,7 +19,7 @@ all: $(LIB) oracle
 
 $(LIB): $(SRCS) $(HDRS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS) -ldl
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS) -ldl -pthread
 
 oracle:
 	$(MAKE) -C $(ROOT)oracle

@@ -372,6 +372,8 @@ def run(args):
                                       C.c_void_p(dc.data_ptr()), self.w, self.h))
             elif mode == "host":
                 self.sdf.set_frame(*host[k])
+            elif mode == "aos":
+                self.sdf.set_frame_aos(*host[k])
             else:
                 self.sdf.set_depth_frame(depth16[k], host[k][2])
 
@@ -587,6 +589,20 @@ def run(args):
         extras["value_depth_input_inclusive"] = args.steps / e3
         extras["depth_input_note"] = ("raw uint16 depth + rgb (5 B/pixel) as host buffers; back-projection, bilateral-grid filter "
                                       "and normals on the GPU (tsdf_set_depth_frame; PCL parity of that stage is unpinned)")
+        # the frame as the reference's callback holds it: pcl::PointCloud<PointXYZRGB> + pcl::PointCloud<Normal>, 32-byte
+        # structs in pageable memory (64 B/pixel read on the host by the library's staging threads)
+        aos = []
+        for x, n, c in host_frames:
+            pts = np.zeros(x.shape[:2], dtype=ts.PCL_POINT_XYZRGB)
+            pts["x"], pts["y"], pts["z"] = x[..., 0], x[..., 1], x[..., 2]
+            pts["r"], pts["g"], pts["b"] = c[..., 0], c[..., 1], c[..., 2]
+            nn = np.zeros(x.shape[:2], dtype=ts.PCL_NORMAL)
+            nn["normal_x"], nn["normal_y"], nn["normal_z"] = n[..., 0], n[..., 1], n[..., 2]
+            aos.append((pts, nn))
+        e4 = best_of_two("aos", aos)
+        extras["value_pcl_clouds_inclusive"] = args.steps / e4
+        extras["pcl_clouds_note"] = ("frames handed over as arrays of PCL's 32-byte point / normal structs in pageable memory "
+                                     "(tsdf_set_frame_aos): what the reference's callback holds, sdf_reconstruction.cpp:33-49")
         pin16 = [torch.from_numpy(d.view(np.int16)).pin_memory() for d in depth16]
         e3p = best_of_two("depth", pinned_frames, [t.numpy().view(np.uint16) for t in pin16])
         extras["value_depth_input_inclusive_pinned_buffers"] = args.steps / e3p

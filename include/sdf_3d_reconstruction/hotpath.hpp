@@ -211,8 +211,8 @@ inline void SDF::update(CameraTracking* camera_tracking) {
 // `SDF` and `CameraTracking` below have the reference's constructor / method signatures and Eigen-typed public
 // fields, so that the hot-path call sites of sdf_reconstruction.cpp (:70 estimate_new_position, :71 writePoseToFile
 // reading trans / rot, :65 set_camera_transformation, :74 update, :83-88 the two constructors) compile unchanged
-// once sdf_reconstruction.h includes this header instead of sdf.h / camera_tracking.h.  PCL's 32-byte AoS points are
-// repacked into the planes the C ABI takes.  With TSDF_WITH_ROS also camera_info_cb and the cam_info subscriber
+// once sdf_reconstruction.h includes this header instead of sdf.h / camera_tracking.h.  PCL's 32-byte AoS points go
+// to the library as they are (tsdf_set_frame_aos repacks them into its pinned staging planes with a few threads).  With TSDF_WITH_ROS also camera_info_cb and the cam_info subscriber
 // (camera_tracking.cpp:22-36, sdf_reconstruction.cpp:90-91).
 #include <Eigen/Core>
 #include <pcl/point_cloud.h>
@@ -245,6 +245,27 @@ struct PclFrame {
         }
     }
 };
+
+// Byte layout of the two PCL point types as this build sees them (PCL pads both to 32 bytes; measured on an instance,
+// offsetof is not defined for them), for tsdf_set_frame_aos: the clouds go to the library as they are.
+inline const tsdf_aos_layout& pcl_layout() {
+    static const tsdf_aos_layout lay = [] {
+        const pcl::PointXYZRGB p = pcl::PointXYZRGB();
+        const pcl::Normal n = pcl::Normal();
+        const char* pb = reinterpret_cast<const char*>(&p);
+        const char* nb = reinterpret_cast<const char*>(&n);
+        tsdf_aos_layout l;
+        l.point_stride = (int32_t)sizeof(pcl::PointXYZRGB);
+        l.xyz_offset = (int32_t)(reinterpret_cast<const char*>(&p.x) - pb);
+        l.r_offset = (int32_t)(reinterpret_cast<const char*>(&p.r) - pb);
+        l.g_offset = (int32_t)(reinterpret_cast<const char*>(&p.g) - pb);
+        l.b_offset = (int32_t)(reinterpret_cast<const char*>(&p.b) - pb);
+        l.normal_stride = (int32_t)sizeof(pcl::Normal);
+        l.normal_offset = (int32_t)(reinterpret_cast<const char*>(&n.normal_x) - nb);
+        return l;
+    }();
+    return lay;
+}
 
 namespace ref_types {
 
@@ -309,9 +330,25 @@ public:
     }
     // camera_tracking.h:101
     void estimate_new_position(const SDF* sdf, const pcl::PointCloud<pcl::PointXYZRGB>::Ptr& point_cloud) {
-        const PclFrame f(*point_cloud, nullptr);
-        try { impl_.estimate_new_position(sdf, f.cloud); } catch (...) { pull(); throw; }
+        tracked_points_ = nullptr;
+        sdf->check(tsdf_set_frame_aos(sdf->handle(), point_cloud->points.data(), nullptr, &pcl_layout(),
+                                      (int32_t)point_cloud->width, (int32_t)point_cloud->height), "tsdf_set_frame_aos");
+        tracked_points_ = point_cloud->points.data(); tracked_w_ = point_cloud->width; tracked_h_ = point_cloud->height;
+        try { impl_.estimate_new_position(sdf); } catch (...) { pull(); throw; }
         pull();
+    }
+    // The reference hands the cloud it has just tracked to SDF::update (sdf_reconstruction.cpp:70,74): its points are
+    // in HBM already, update() then uploads the normals only.  One-shot: true once per tracked cloud.  Define
+    // TSDF_SHIM_NO_CLOUD_REUSE if the caller changes the points between the two calls.
+    bool take_tracked(const pcl::PointCloud<pcl::PointXYZRGB>& c) {
+#ifdef TSDF_SHIM_NO_CLOUD_REUSE
+        (void)c;
+        return false;
+#else
+        const bool same = tracked_points_ && tracked_points_ == c.points.data() && tracked_w_ == c.width && tracked_h_ == c.height;
+        tracked_points_ = nullptr;
+        return same;
+#endif
     }
     tsdf_shim::CameraTracking* impl() { return &impl_; }
     void pull() {                          // native handle -> the public Eigen fields
@@ -323,12 +360,16 @@ public:
 
 private:
     tsdf_shim::CameraTracking impl_;
+    const void* tracked_points_ = nullptr;
+    uint32_t tracked_w_ = 0, tracked_h_ = 0;
 };
 
 inline void SDF::update(CameraTracking* camera_tracking, pcl::PointCloud<pcl::PointXYZRGB>::Ptr cloud_filtered,
                         pcl::PointCloud<pcl::Normal>::Ptr normals) {
-    const PclFrame f(*cloud_filtered, normals.get());
-    tsdf_shim::SDF::update(camera_tracking ? camera_tracking->impl() : nullptr, f.cloud, f.normals);
+    const bool reuse = camera_tracking && camera_tracking->take_tracked(*cloud_filtered);
+    check(tsdf_set_frame_aos(handle(), reuse ? nullptr : cloud_filtered->points.data(), normals->points.data(), &pcl_layout(),
+                             (int32_t)cloud_filtered->width, (int32_t)cloud_filtered->height), "tsdf_set_frame_aos");
+    tsdf_shim::SDF::update(camera_tracking ? camera_tracking->impl() : nullptr);
 }
 
 }  // namespace ref_types

@@ -136,6 +136,22 @@ int tsdf_set_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uin
 int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb,
                           int32_t width, int32_t height);
 
+/* The frame in the reference's OWN format: arrays of point structs, as pcl::PointCloud<pcl::PointXYZRGB>::points and
+ * pcl::PointCloud<pcl::Normal>::points hold them (sdf_reconstruction.cpp:33-49; PCL pads both to 32 bytes) -- any
+ * array-of-structs layout is described by strides and byte offsets.  A few library threads repack it straight into
+ * the pinned staging planes (one pass over the caller's memory, no intermediate copy).  The reference hands the same
+ * cloud to estimate_new_position (points only) and then to update (points + normals): pass points = NULL in the
+ * second call to keep the xyz / rgb uploaded by the first and add only the normals (TSDF_E_NO_FRAME unless the current
+ * frame came from a host buffer of the same size).  Host buffers are borrowed for the call only. */
+typedef struct tsdf_aos_layout {
+    int32_t point_stride;                   /* bytes from one point to the next                         */
+    int32_t xyz_offset;                     /* x, y, z: three consecutive floats at this byte offset    */
+    int32_t r_offset, g_offset, b_offset;   /* one byte each; any of them < 0 = the points have no colour */
+    int32_t normal_stride, normal_offset;   /* same for the normals: three consecutive floats           */
+} tsdf_aos_layout;
+int tsdf_set_frame_aos(tsdf_handle *h, const void *points, const void *normals, const tsdf_aos_layout *layout,
+                       int32_t width, int32_t height);
+
 /* ---- optional: depth pre-processing on the GPU.  Replaces, for callers that have a raw
  * depth image instead of PCL clouds, the host-side steps of sdf_reconstruction.cpp:29-49 (cloud conversion,
  * pcl::FastBilateralFilter, pcl::IntegralImageNormalEstimation).  PCL is not available here, so this is the

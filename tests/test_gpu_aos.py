@@ -1,0 +1,133 @@
+"""tsdf_set_frame_aos: the frame in the reference's own format (arrays of PCL point structs) against the planar entry
+point -- bit-identical volumes and poses, including the two-call sequence of the reference (points for the tracker,
+then the normals of the same cloud for the integration)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tracking_sdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, M = 160, 120, 48
+
+
+def clouds(xyz, nrm, rgb, point_dtype=None, normal_dtype=None):
+    import tracking_sdf_amd as ts
+    pts = np.zeros(xyz.shape[:2], dtype=point_dtype or ts.PCL_POINT_XYZRGB)
+    pts["x"], pts["y"], pts["z"] = xyz[..., 0], xyz[..., 1], xyz[..., 2]
+    if "r" in pts.dtype.fields:
+        pts["r"], pts["g"], pts["b"] = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    nn = np.zeros(xyz.shape[:2], dtype=normal_dtype or ts.PCL_NORMAL)
+    nn["normal_x"], nn["normal_y"], nn["normal_z"] = nrm[..., 0], nrm[..., 1], nrm[..., 2]
+    return pts, nn
+
+
+def run_sequence(feed, n=4, color=True):
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=n, width=W, height=H, noise=True, holes=0.02, step=4)
+    s = ts.SDF(M, with_color=color)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    poses = []
+    for k in range(n):
+        feed(s, t, k, *seq.frame(k))
+        poses.append((t.rot.copy(), t.trans.copy()))
+    D, Wt = s.download()
+    col = s.download_color() if color else None
+    s.close()
+    return poses, D, Wt, col
+
+
+def planar(s, t, k, xyz, nrm, rgb):
+    if k > 0:
+        s.set_frame(xyz, None, rgb)
+        t.estimate_new_position()
+    s.set_frame(xyz, nrm, rgb)
+    s.update()
+
+
+def aos_reference_order(s, t, k, xyz, nrm, rgb):
+    pts, nn = clouds(xyz, nrm, rgb)
+    if k > 0:
+        s.set_frame_aos(pts)                  # estimate_new_position(sdf, cloud_filtered)
+        t.estimate_new_position()
+        s.set_frame_aos(None, nn)             # update(tracker, cloud_filtered, normals): the points are in HBM already
+    else:
+        s.set_frame_aos(pts, nn)
+    s.update()
+
+
+def aos_tight(s, t, k, xyz, nrm, rgb):
+    """another layout: 16-byte points with the colour bytes in r, g, b order, 12-byte normals"""
+    pd = np.dtype({"names": ["r", "g", "b", "x", "y", "z"], "formats": ["u1", "u1", "u1", "<f4", "<f4", "<f4"],
+                   "offsets": [0, 1, 2, 4, 8, 12], "itemsize": 16})
+    nd = np.dtype([("normal_x", "<f4"), ("normal_y", "<f4"), ("normal_z", "<f4")])
+    pts, nn = clouds(xyz, nrm, rgb, pd, nd)
+    if k > 0:
+        s.set_frame_aos(pts)
+        t.estimate_new_position()
+    s.set_frame_aos(pts, nn)
+    s.update()
+
+
+@pytest.mark.parametrize("feed", [aos_reference_order, aos_tight])
+def test_aos_frames_give_the_planar_result(feed):
+    want = run_sequence(planar)
+    got = run_sequence(feed)
+    for (r0, t0), (r1, t1) in zip(want[0], got[0]):
+        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+    assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2])
+    for a, b in zip(want[3], got[3]):
+        assert np.array_equal(a, b)
+
+
+def test_points_without_colour_and_argument_checks():
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=1, width=W, height=H, step=4)
+    xyz, nrm, rgb = seq.frame(0)
+    pd = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4")])
+    pts, nn = clouds(xyz, nrm, rgb, pd)
+    a = ts.SDF(M, with_color=False); ta = ts.CameraTracking(sdf=a); ta.set_K(seq.K)
+    b = ts.SDF(M, with_color=False); tb = ts.CameraTracking(sdf=b); tb.set_K(seq.K)
+    a.set_frame_aos(pts, nn); a.update()
+    b.set_frame(xyz, nrm); b.update()
+    assert all(np.array_equal(x, y) for x, y in zip(a.download(), b.download()))
+    c = ts.SDF(M)                                   # with colour: a colourless cloud cannot be integrated
+    tc = ts.CameraTracking(sdf=c); tc.set_K(seq.K)
+    with pytest.raises(ts.TsdfError) as ei:
+        c.set_frame_aos(None, nn)                   # no current host frame to complete
+    assert ei.value.code == ts.E_NO_FRAME
+    c.set_frame_aos(pts, nn)
+    with pytest.raises(ts.TsdfError) as ei:
+        c.update()
+    assert ei.value.code == ts.E_NO_FRAME
+    lay = ts.AosLayout(8, 0, -1, -1, -1, 12, 0)     # 8-byte stride cannot hold three floats
+    import ctypes as C
+    rc = ts.lib().tsdf_set_frame_aos(c._h, C.c_void_p(pts.ctypes.data), None, C.byref(lay), W, H)
+    assert rc == ts.E_BADARG
+    small = np.zeros((H // 2, W // 2), dtype=ts.PCL_NORMAL)
+    with pytest.raises(ts.TsdfError) as ei:
+        c.set_frame_aos(None, small)                # size differs from the current frame
+    assert ei.value.code == ts.E_NO_FRAME
+    for s in (a, b, c):
+        s.close()
+
+
+def test_staging_thread_count_does_not_change_the_result():
+    code = ("import numpy as np, tracking_sdf_amd as ts\n"
+            "from tracking_sdf_amd import synth\n"
+            "seq = synth.Sequence(n_frames=2, width=203, height=117, noise=True, holes=0.02, step=4)\n"
+            "s = ts.SDF(32); t = ts.CameraTracking(sdf=s); t.set_K(seq.K)\n"
+            "for k in range(2):\n"
+            "    s.set_frame(*seq.frame(k)); s.update()\n"
+            "D, W = s.download(); print(float(D.sum()), float(W.sum()), int((W > 0).sum()))\n")
+    outs = []
+    for n in ("1", "3", "7"):
+        env = dict(os.environ, TSDF_HOST_THREADS=n)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip())
+    assert outs[0] and outs[0] == outs[1] == outs[2], outs

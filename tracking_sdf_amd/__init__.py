@@ -48,6 +48,20 @@ class PreprocParams(C.Structure):
                 ("normal_radius", C.c_int32), ("max_depth_change", C.c_float), ("grid_filter", C.c_int32)]
 
 
+class AosLayout(C.Structure):
+    """struct tsdf_aos_layout"""
+    _fields_ = [("point_stride", C.c_int32), ("xyz_offset", C.c_int32), ("r_offset", C.c_int32), ("g_offset", C.c_int32),
+                ("b_offset", C.c_int32), ("normal_stride", C.c_int32), ("normal_offset", C.c_int32)]
+
+
+# numpy views of PCL's two point types as the reference holds them (32 bytes each, EIGEN_ALIGN16 unions):
+# PointXYZRGB = {x, y, z, pad, b, g, r, a, pad[12]}, Normal = {normal_x, normal_y, normal_z, pad, curvature, pad[12]}
+PCL_POINT_XYZRGB = np.dtype({"names": ["x", "y", "z", "b", "g", "r", "a"], "formats": ["<f4", "<f4", "<f4", "u1", "u1", "u1", "u1"],
+                             "offsets": [0, 4, 8, 16, 17, 18, 19], "itemsize": 32})
+PCL_NORMAL = np.dtype({"names": ["normal_x", "normal_y", "normal_z", "curvature"], "formats": ["<f4"] * 4,
+                       "offsets": [0, 4, 8, 16], "itemsize": 32})
+
+
 class IntegrateStats(C.Structure):
     _fields_ = [("n_updated", C.c_int64), ("n_updated_halo", C.c_int64), ("n_voxels", C.c_int64)]
 
@@ -88,7 +102,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p
 ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
-    "tsdf_set_frame_device", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
+    "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
@@ -135,6 +149,7 @@ def lib():
         "tsdf_get_pose": (C.c_int, [H, dp, dp, dp, dp]),
         "tsdf_set_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
         "tsdf_set_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+        "tsdf_set_frame_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32]),
         "tsdf_default_preproc": (None, [C.POINTER(PreprocParams)]),
         "tsdf_set_depth_frame": (C.c_int, [H, C.POINTER(C.c_uint16), fp, u8p, C.c_int32, C.c_int32, C.POINTER(PreprocParams)]),
         "tsdf_get_preprocessed": (C.c_int, [H, fp, fp]),
@@ -354,6 +369,38 @@ class SDF:
         nrm = np.empty((h, w, 3), dtype=np.float32)
         self._check(lib().tsdf_get_preprocessed(self._h, _fptr(xyz), _fptr(nrm)))
         return xyz, nrm
+
+    def set_frame_aos(self, points=None, normals=None):
+        """The frame as arrays of point structs (numpy structured arrays of shape (height, width), e.g. of dtype
+        PCL_POINT_XYZRGB / PCL_NORMAL): fields x, y, z (consecutive floats) and optionally r, g, b (bytes); normals with
+        normal_x, normal_y, normal_z.  points=None keeps the xyz / rgb of the current host frame and adds the normals."""
+        lay = AosLayout(0, 0, -1, -1, -1, 0, 0)
+        shape = None
+        pp = nn = None
+        if points is not None:
+            points = np.ascontiguousarray(points)
+            f = points.dtype.fields
+            if not (f["y"][1] == f["x"][1] + 4 and f["z"][1] == f["x"][1] + 8):
+                raise ValueError("x, y, z must be consecutive floats")
+            lay.point_stride, lay.xyz_offset = points.dtype.itemsize, f["x"][1]
+            if all(k in f for k in "rgb"):
+                lay.r_offset, lay.g_offset, lay.b_offset = f["r"][1], f["g"][1], f["b"][1]
+            shape = points.shape
+            pp = C.c_void_p(points.ctypes.data)
+        if normals is not None:
+            normals = np.ascontiguousarray(normals)
+            f = normals.dtype.fields
+            if not (f["normal_y"][1] == f["normal_x"][1] + 4 and f["normal_z"][1] == f["normal_x"][1] + 8):
+                raise ValueError("normal_x, normal_y, normal_z must be consecutive floats")
+            lay.normal_stride, lay.normal_offset = normals.dtype.itemsize, f["normal_x"][1]
+            if shape is not None and normals.shape != shape:
+                raise ValueError("points and normals differ in shape")
+            shape = normals.shape
+            nn = C.c_void_p(normals.ctypes.data)
+        if shape is None or len(shape) != 2:
+            raise ValueError("organized clouds of shape (height, width) are needed")
+        self._check(lib().tsdf_set_frame_aos(self._h, pp, nn, C.byref(lay), shape[1], shape[0]))
+        self._frame_shape = tuple(shape)
 
     def set_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
         """Borrow device pointers (ints, e.g. torch.Tensor.data_ptr()) of images already in HBM."""

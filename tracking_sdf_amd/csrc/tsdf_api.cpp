@@ -16,12 +16,17 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <ctime>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_math.hpp"
@@ -36,6 +41,55 @@ std::mutex g_err_mu;
 std::string g_create_error;
 
 struct EventPair { hipEvent_t a = nullptr, b = nullptr; };
+
+// A few host threads for the one host-side job that is longer than the frame's GPU work: moving a frame handed over
+// in PAGEABLE memory into the pinned staging buffers (8.3 MB of planes at 640x480, or the 19.7 MB of PCL's 32-byte
+// array-of-structs points + normals they are repacked from).  run(fn) calls fn(part, parts) once per part -- part 0
+// on the caller, the others on the workers -- and returns when all are done.
+class HostPool {
+public:
+    explicit HostPool(int workers) {
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this, i] { loop(i + 1); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    int parts() const { return (int)threads_.size() + 1; }
+    void run(const std::function<void(int, int)>& fn) {
+        if (threads_.empty()) { fn(0, 1); return; }
+        { std::lock_guard<std::mutex> g(mu_); fn_ = &fn; pending_ = (int)threads_.size(); ++gen_; }
+        cv_.notify_all();
+        fn(0, parts());
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop(int part) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int, int)>* fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_; fn = fn_;
+            }
+            (*fn)(part, parts());
+            { std::lock_guard<std::mutex> g(mu_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)>* fn_ = nullptr;
+    unsigned long long gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+};
 
 }  // namespace
 
@@ -71,6 +125,8 @@ struct tsdf_handle {
     float* in_xyz = nullptr; float* in_nrm = nullptr; uint8_t* in_rgb = nullptr;   // device staging (owned)
     float* pin_xyz = nullptr; float* pin_nrm = nullptr; uint8_t* pin_rgb = nullptr;  // pinned host staging
     size_t in_cap = 0;             // pixels the staging buffers hold
+    bool staged_xyz = false;       // in_xyz (and in_rgb, if frame_has_rgb) hold the CURRENT frame (host / AoS / depth frames)
+    std::unique_ptr<HostPool> pool;   // staging threads, started by the first pageable frame (TSDF_HOST_THREADS, default 4)
     float* pre_z = nullptr; float* pre_zf = nullptr; void* pre_depth = nullptr; void* pin_depth = nullptr;   // pre-processing scratch
     size_t pre_cap = 0;
     float2* pre_grid_a = nullptr; float2* pre_grid_b = nullptr; size_t pre_grid_cap = 0;                     // bilateral grid (cells)
@@ -817,6 +873,56 @@ bool is_pinned_host(const void* p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
+
+HostPool* host_pool(tsdf_handle* h) {
+    if (!h->pool) {
+        int n = 4;
+        if (const char* e = std::getenv("TSDF_HOST_THREADS")) n = std::atoi(e);
+        const unsigned hc = std::thread::hardware_concurrency();
+        if (hc && (unsigned)n > hc) n = (int)hc;
+        n = n < 1 ? 1 : n > 16 ? 16 : n;
+        h->pool.reset(new HostPool(n - 1));
+    }
+    return h->pool.get();
+}
+
+// Pageable frame -> pinned staging -> HBM, pipelined: the pixels are cut into chunks; the pool's workers fill chunk
+// after chunk of the pinned planes (fill(i0, i1) writes pixels [i0, i1)), the calling thread issues the H2D copies of a
+// chunk the moment its last worker is done, so the DMA of chunk c runs while chunk c+1 is being filled (filling and
+// copying one after the other put both on the critical path of the frame: the tracker waits for the upload).
+hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
+                            const std::function<void(size_t, size_t)>& fill) {
+    constexpr int kChunks = 4;
+    std::atomic<int> done[kChunks];
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    hipError_t err = hipSuccess;
+    auto chunk_lo = [npix](int c) { return npix * (size_t)c / kChunks; };
+    auto upload = [&](int c) {
+        const size_t i0 = chunk_lo(c), n = chunk_lo(c + 1) - i0;
+        if (!n || err != hipSuccess) return;
+        if (has_xyz) err = hipMemcpyAsync(h->in_xyz + 3 * i0, h->pin_xyz + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
+        if (has_nrm && err == hipSuccess) err = hipMemcpyAsync(h->in_nrm + 3 * i0, h->pin_nrm + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
+        if (has_rgb && err == hipSuccess) err = hipMemcpyAsync(h->in_rgb + 3 * i0, h->pin_rgb + 3 * i0, n * 3, hipMemcpyHostToDevice, h->fstream);
+    };
+    host_pool(h)->run([&](int part, int parts) {
+        if (parts == 1) {                                   // no workers: fill and issue in turn (the DMA still overlaps)
+            for (int c = 0; c < kChunks; ++c) { fill(chunk_lo(c), chunk_lo(c + 1)); upload(c); }
+        } else if (part == 0) {                             // the caller: HIP calls only
+            for (int c = 0; c < kChunks; ++c) {
+                while (done[c].load(std::memory_order_acquire) < parts - 1) std::this_thread::yield();
+                upload(c);
+            }
+        } else {
+            const size_t wk = (size_t)(part - 1), nw = (size_t)(parts - 1);
+            for (int c = 0; c < kChunks; ++c) {
+                const size_t c0 = chunk_lo(c), n = chunk_lo(c + 1) - c0;
+                fill(c0 + n * wk / nw, c0 + n * (wk + 1) / nw);
+                done[c].fetch_add(1, std::memory_order_release);
+            }
+        }
+    });
+    return err;
+}
 }  // namespace
 
 int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
@@ -833,22 +939,23 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     // the pinned staging buffers may still feed the previous frame's async copies (frame stream only: the
     // integration of the previous frame keeps running on the main stream meanwhile)
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    h->staged_xyz = true;
     if (!direct) {
-        std::memcpy(h->pin_xyz, xyz, npix * 3 * sizeof(float));
-        if (nrm) std::memcpy(h->pin_nrm, nrm, npix * 3 * sizeof(float));
-        if (rgb) std::memcpy(h->pin_rgb, rgb, npix * 3);
+        HIP_TRY(h, stage_and_upload(h, npix, true, nrm != nullptr, rgb != nullptr, [&](size_t i0, size_t i1) {
+            std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+            if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+            if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
+        }));
+        return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
     }
-    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, direct ? xyz : h->pin_xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
-    if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, direct ? nrm : h->pin_nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
-    if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, direct ? rgb : h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
-    if (direct) {
-        HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
-        rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
-        if (rc) return rc;
-        HIP_TRY(h, hipEventSynchronize(h->ev_copied));      // the caller's buffers have been read
-        return TSDF_OK;
-    }
-    return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
+    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+    HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
+    rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventSynchronize(h->ev_copied));      // the caller's buffers have been read
+    return TSDF_OK;
 }
 
 int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
@@ -857,7 +964,48 @@ int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, false);
     if (rc) return rc;
+    h->staged_xyz = false;
     return run_pack(h, d_xyz, d_nrm, d_rgb, h->stream);
+}
+
+int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L,
+                       int32_t width, int32_t height) {
+    if (!h || !L || (!points && !normals) || width <= 0 || height <= 0)
+        return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: bad argument") : TSDF_E_BADARG;
+    const bool color = points && L->r_offset >= 0 && L->g_offset >= 0 && L->b_offset >= 0;
+    if (points && (L->point_stride < 12 || L->xyz_offset < 0 || L->xyz_offset + 12 > L->point_stride ||
+                   (color && (L->r_offset >= L->point_stride || L->g_offset >= L->point_stride || L->b_offset >= L->point_stride))))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: point layout (stride %d, xyz at %d) does not hold three floats and the colour bytes",
+                    L->point_stride, L->xyz_offset);
+    if (normals && (L->normal_stride < 12 || L->normal_offset < 0 || L->normal_offset + 12 > L->normal_stride))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: normal layout (stride %d, normal at %d) does not hold three floats",
+                    L->normal_stride, L->normal_offset);
+    if (!points && !(h->have_frame && h->staged_xyz && h->fw == width && h->fh == height))
+        return fail(h, TSDF_E_NO_FRAME, "tsdf_set_frame_aos: normals alone complete the CURRENT host frame of the same size; there is none");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));          // the pinned staging buffers may still feed the previous frame
+    float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
+    const tsdf_aos_layout lay = *L;
+    HIP_TRY(h, stage_and_upload(h, npix, points != nullptr, normals != nullptr, color, [&](size_t i0, size_t i1) {
+        if (points) {
+            const char* p = (const char*)points + i0 * (size_t)lay.point_stride;
+            for (size_t i = i0; i < i1; ++i, p += lay.point_stride) {
+                std::memcpy(px + 3 * i, p + lay.xyz_offset, 12);
+                if (color) { pc[3 * i] = (uint8_t)p[lay.r_offset]; pc[3 * i + 1] = (uint8_t)p[lay.g_offset]; pc[3 * i + 2] = (uint8_t)p[lay.b_offset]; }
+            }
+        }
+        if (normals) {
+            const char* q = (const char*)normals + i0 * (size_t)lay.normal_stride + lay.normal_offset;
+            for (size_t i = i0; i < i1; ++i, q += lay.normal_stride) std::memcpy(pnm + 3 * i, q, 12);
+        }
+    }));
+    const bool has_rgb = points ? color : h->frame_has_rgb;
+    h->staged_xyz = true;
+    return run_pack(h, h->in_xyz, normals ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, h->fstream);
 }
 
 // ---- depth pre-processing (optional stage in front of the hot path) -------------------------------------------
@@ -951,6 +1099,7 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
     HIP_TRY(h, launch_preproc(h->fstream, width, height, Kf, use_grid && !grid_on ? 0 : pp.radius, pp.sigma_s, pp.sigma_r,
                               pp.normal_radius, pp.max_depth_change, grid_on ? &bg : nullptr, h->pre_grid_a, h->pre_grid_b,
                               h->pre_z, h->pre_zf, h->in_xyz, h->in_nrm));
+    h->staged_xyz = true;
     rc = run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
     if (rc) return rc;
     if (direct && !use_grid) HIP_TRY(h, hipEventSynchronize(h->ev_copied));   // (the grid path has synchronised already)
