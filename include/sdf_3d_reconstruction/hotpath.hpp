@@ -222,6 +222,8 @@ inline void SDF::update(CameraTracking* camera_tracking) {
 #include <sensor_msgs/CameraInfo.h>
 #endif
 namespace tsdf_shim {
+// PCL clouds -> the planes of the plain-type classes above (a host-side repack; the exact-type classes below hand the
+// clouds to tsdf_set_frame_aos instead and do not use it)
 struct PclFrame {
     std::vector<float> xyz, nrm;
     std::vector<uint8_t> rgb;

@@ -280,7 +280,7 @@ int tsdf_host_gn_step(double rot[9], double trans[3], const double A[36], const 
 typedef struct tsdf_timing {
     double  integrate_ms;       /* integrate_kernel only                                              */
     int64_t integrate_launches;
-    double  track_ms;           /* track_kernel + track_final_kernel, one launch pair per GN iteration */
+    double  track_ms;           /* track_kernel (rows + in-launch fan-in), one launch per GN iteration    */
     int64_t track_launches;
     double  pack_ms;            /* per-frame image packing kernel                                      */
     int64_t pack_launches;

@@ -49,7 +49,12 @@ struct EventPair { hipEvent_t a = nullptr, b = nullptr; };
 class HostPool {
 public:
     explicit HostPool(int workers) {
-        for (int i = 0; i < workers; ++i) threads_.emplace_back([this, i] { loop(i + 1); });
+        // a thread that cannot be started (resource limits) only means fewer parts: nothing may throw across the C ABI
+        try {
+            threads_.reserve((size_t)workers);
+            for (int i = 0; i < workers; ++i) threads_.emplace_back([this, i] { loop(i + 1); });
+        } catch (...) {
+        }
     }
     ~HostPool() {
         { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
@@ -881,7 +886,7 @@ HostPool* host_pool(tsdf_handle* h) {
         const unsigned hc = std::thread::hardware_concurrency();
         if (hc && (unsigned)n > hc) n = (int)hc;
         n = n < 1 ? 1 : n > 16 ? 16 : n;
-        h->pool.reset(new HostPool(n - 1));
+        h->pool.reset(new (std::nothrow) HostPool(n - 1));
     }
     return h->pool.get();
 }
@@ -904,7 +909,8 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
         if (has_nrm && err == hipSuccess) err = hipMemcpyAsync(h->in_nrm + 3 * i0, h->pin_nrm + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
         if (has_rgb && err == hipSuccess) err = hipMemcpyAsync(h->in_rgb + 3 * i0, h->pin_rgb + 3 * i0, n * 3, hipMemcpyHostToDevice, h->fstream);
     };
-    host_pool(h)->run([&](int part, int parts) {
+    HostPool* const pool = host_pool(h);
+    const std::function<void(int, int)> job = [&](int part, int parts) {
         if (parts == 1) {                                   // no workers: fill and issue in turn (the DMA still overlaps)
             for (int c = 0; c < kChunks; ++c) { fill(chunk_lo(c), chunk_lo(c + 1)); upload(c); }
         } else if (part == 0) {                             // the caller: HIP calls only
@@ -920,7 +926,8 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
                 done[c].fetch_add(1, std::memory_order_release);
             }
         }
-    });
+    };
+    if (pool) pool->run(job); else job(0, 1);
     return err;
 }
 }  // namespace

@@ -17,7 +17,7 @@ namespace tsdf {
 //   [31]     out-of-grid samples   [32] NaN samples   [33] sampled pixels
 constexpr int kRedWidth = 34;
 constexpr int kRedAllreduce = 30;   // the leading part that is summed over ranks
-// partial-row layout of track_kernel / track_fold_kernel: [5*q + d] (q = 0..5, d = 0..4) = J[q]*J[(q+d)%6] for
+// partial-row layout of track_kernel (workgroup rows and shard rows): [5*q + d] (q = 0..5, d = 0..4) = J[q]*J[(q+d)%6] for
 // d <= 3 and r*J[q] for d = 4, then counters
 constexpr int kPartTerms = 30, kPartViol = 31, kPartOk = 32, kPartInOwned = 33, kPartOog = 34, kPartNan = 35,
               kPartSamples = 36, kPartWidth = 40;

@@ -838,7 +838,8 @@ hipError_t launch_sample(hipStream_t s, const Grid& g, const float2* dw, const d
 // look-up each needed 8560 wavefronts: a second, nearly empty round on 256 CUs x 32 waves).
 // Reduction: lane q < 6 of a group forms J[q] J[(q+d)%6] (d = 0..3: all 21 unique products) and
 // r J[q]; the 8 groups of a wavefront are added by shuffles, the 4 wavefronts through LDS, one row of
-// `partials` per workgroup; track_final_kernel adds the rows in a fixed order (bitwise reproducible).
+// `partials` per workgroup; the in-launch fan-in (TrackFold, below) adds the rows in a fixed order (bitwise
+// reproducible).
 
 enum { kClsSkip = 0, kClsOog = 1, kClsIn = 2 };
 constexpr int kLanesPerSample = 8;
