@@ -9,6 +9,7 @@
                                                                             -> <tag>_bench.json
   3. tools/pmc_memside.py (separate --pmc passes: SQ, TCP, TCC request sizes) -> <tag>_pmc_memside.json
   4. tools/pmc_calibrate.py (known-byte kernels; needs `make pmc_calibrate`)  -> <tag>_fetch_calibration.json
+  5. rocprofv3 --kernel-trace --stats -- python3 tools/preproc_workload.py  -> <tag>_preproc_kernel_stats.csv
 rocprofv3 always gets the program itself after `--`; --pmc is never combined with a trace domain.
 """
 import csv
@@ -53,6 +54,25 @@ def main():
     if line:
         with open(os.path.join(out, tag + "_bench_under_rocprofv3.json"), "w") as f:
             json.dump(line, f, indent=1)
+    shutil.rmtree(d, ignore_errors=True)
+    # 5. the pre-processing stage alone (bilateral grid, then the windowed filter), kernel trace
+    with open(os.path.join(out, tag + "_preproc_kernel_stats.csv"), "w", newline="") as g:
+        wr = csv.writer(g)
+        for mode in ("1", "0"):
+            shutil.rmtree(d, ignore_errors=True)
+            p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "preproc_workload.py"), mode], cwd="/tmp", env=env, capture_output=True, text=True)
+            stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+            if p.returncode or not stats:
+                print("preproc kernel trace failed: " + p.stderr[-500:], file=sys.stderr)
+                continue
+            with open(stats[0]) as f:
+                rd = csv.reader(f)
+                hdr = next(rd)
+                wr.writerow(["grid_filter=" + mode] + hdr)
+                for row in rd:
+                    if "tsdf::" in row[0] and "fill_kernel" not in row[0]:
+                        wr.writerow([""] + row)
     shutil.rmtree(d, ignore_errors=True)
     # 2. the default bench command
     p = subprocess.run(BENCH, cwd=ROOT, env=env, capture_output=True, text=True)
