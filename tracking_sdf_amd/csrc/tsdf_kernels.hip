@@ -464,7 +464,10 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         const unsigned code3 = __builtin_amdgcn_readlane(code_v, (j3 >= 0 && j3 < cnt) ? j3 : 0);
         const long long row3 = (long long)(code3 >> 6);
         const bool owned3 = row3 >= own_row0 && row3 < own_row1;                 // wave-uniform; rows of the owned x layers
-        const long long base3 = row3 * m + (long long)(code3 & 63u) * 64;
+        long long base3 = row3 * m + (long long)(code3 & 63u) * 64;
+#if TSDF_INTEGRATE_DEBUG
+        if (p.debug & 1024) base3 = (long long)(blockIdx.x & 255) * 4096 + wv * 64;   // timing experiment only: stores to a cache-resident region
+#endif
         n_own += (uin.live && owned3) ? 1u : 0u;
         n_halo += (uin.live && !owned3) ? 1u : 0u;
         // ---------------- S2(j-1): distance + weight from the pixel record; request {D,W} (+ colour)
@@ -522,8 +525,11 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             const unsigned long long live2 = __ballot(u.live);
             const long long base2 = live2 ? (long long)(code2 >> 6) * m + (long long)(code2 & 63u) * 64 : 0ll;
             const int first2 = live2 ? (int)__ffsll((long long)live2) - 1 : 0;
-            const int sel = u.live ? lane : first2;
-            const float2* __restrict__ dwb = dw + base2;
+            int sel = u.live ? lane : first2;
+#if TSDF_INTEGRATE_DEBUG
+            if (p.debug & 64) sel = lane;                   // timing experiment only (with base 0 below): cache-resident volume reads
+#endif
+            const float2* __restrict__ dwb = dw + ((TSDF_INTEGRATE_DEBUG && (p.debug & 64)) ? 0ll : base2);
 #if TSDF_INTEGRATE_NT_DW
             {
                 typedef float nt_f2 __attribute__((ext_vector_type(2)));
@@ -536,14 +542,22 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 #if TSDF_INTEGRATE_NT
             if (COLOR) {   // colour is streamed once per frame and never read by the tracker: non-temporal
                 typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                const nt_f4 c4 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(crgb + base2) + sel);
+                const nt_f4 c4 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(crgb + ((TSDF_INTEGRATE_DEBUG && (p.debug & 64)) ? 0ll : base2)) + sel);
                 u.col = make_float4(c4.x, c4.y, c4.z, c4.w);
             }
 #else
             if (COLOR) u.col = (crgb + base2)[sel];
 #endif
         }
-        if (uin.live) {
+        bool do_store = uin.live;
+        bool st_dw = true, st_col = true;
+#if TSDF_INTEGRATE_DEBUG
+        // timing experiments only: 32 no stores, 128 no {D,W} store, 256 no colour store, 512 every lane of a listed item stores
+        if (p.debug & 32) do_store = false;
+        if (p.debug & 512) do_store = j3 >= 0 && j3 < cnt;
+        st_dw = !(p.debug & 128); st_col = !(p.debug & 256);
+#endif
+        if (do_store) {
 #if TSDF_INTEGRATE_NT_DW
             {
                 typedef float nt_f2 __attribute__((ext_vector_type(2)));
@@ -551,16 +565,16 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
                 __builtin_nontemporal_store(o2, reinterpret_cast<nt_f2*>(dw + base3) + lane);
             }
 #else
-            (dw + base3)[lane] = make_float2(d_out, w_sum);
+            if (st_dw) (dw + base3)[lane] = make_float2(d_out, w_sum);
 #endif
 #if TSDF_INTEGRATE_NT
-            if (COLOR) {
+            if (COLOR && st_col) {
                 typedef float nt_f4 __attribute__((ext_vector_type(4)));
                 nt_f4 c4; c4.x = c_out.x; c4.y = c_out.y; c4.z = c_out.z; c4.w = c_out.w;
                 __builtin_nontemporal_store(c4, reinterpret_cast<nt_f4*>(crgb + base3) + lane);
             }
 #else
-            if (COLOR) (crgb + base3)[lane] = c_out;
+            if (COLOR && st_col) (crgb + base3)[lane] = c_out;
 #endif
         }
     };
