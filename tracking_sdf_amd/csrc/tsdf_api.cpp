@@ -120,7 +120,6 @@ struct tsdf_handle {
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
     unsigned* rowinfo = nullptr;      // per voxel row: first chunk, chunk count, image band
     int integrate_blocks = 0;      // persistent grid of integrate_kernel
-    double* rowbase = nullptr;     // per-row share of rot_inv * g (3 doubles per row)
     int integrate_debug = 0;       // timing experiments; only honoured by builds with -DTSDF_INTEGRATE_DEBUG=1
 
     // frame
@@ -746,8 +745,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMalloc((void**)&h->worklist, integrate_worklist_entries(g) * sizeof(unsigned)));
     CREATE_TRY(hipMalloc((void**)&h->work_count, integrate_bookkeeping_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->work_count, 0, integrate_bookkeeping_words() * sizeof(unsigned), h->stream));
-    CREATE_TRY(hipMalloc((void**)&h->rowinfo, (integrate_rowbase_entries(g) / 3) * sizeof(unsigned)));
-    CREATE_TRY(hipMalloc((void**)&h->rowbase, integrate_rowbase_entries(g) * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->rowinfo, integrate_row_entries(g) * sizeof(unsigned)));
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
@@ -803,7 +801,6 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->worklist) (void)hipFree(h->worklist);
     if (h->work_count) (void)hipFree(h->work_count);
     if (h->rowinfo) (void)hipFree(h->rowinfo);
-    if (h->rowbase) (void)hipFree(h->rowbase);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->wg_counts) (void)hipFree(h->wg_counts);
     if (h->wg_counts_host) (void)hipHostFree(h->wg_counts_host);
@@ -1152,7 +1149,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     rc = timed_begin(h, 0, &ep, h->stream);
     if (rc) return rc;
     HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count, h->rowinfo,
-                                h->rowbase, h->integrate_blocks, h->integrate_launches++, h->wg_counts));
+                                h->integrate_blocks, h->integrate_launches++, h->wg_counts));
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
     if (h->frame_side) {     // the next-but-one pack (on the frame stream) may overwrite this buffer after this launch

@@ -129,12 +129,12 @@ hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const 
 //                      with five divisions per row.  The interval is widened by a voxel per side and
 //                      its 64-voxel chunks are appended to a work list (block scan + one atomic per
 //                      workgroup).  Every listed voxel still runs the reference's exact tests, so the
-//                      cull never changes a result.  The row's share of rot_inv * g (its first two
-//                      terms, identical for all k) is stored once per row.
+//                      cull never changes a result.
 //   integrate_kernel   persistent workgroups stride over the list; one item = 64 consecutive k of one
 //                      row = one 512-byte {D,W} segment (+1 KiB colour): perfectly coalesced RMW.
-//                      Row constants arrive through scalar loads (wave-uniform), so the per-voxel f64
-//                      work is 1 multiply + 2 adds per camera coordinate.
+//                      The row's share of rot_inv * g (its first two terms, identical for all k) is computed
+//                      by the lane that fetches the item code, once per item, and broadcast with v_readlane, so
+//                      the per-voxel f64 work is 1 multiply + 2 adds per camera coordinate.
 //
 // Algorithmic traffic: 16 B (48 B with colour) per *updated* voxel + the 32-byte pixel records.
 
@@ -175,9 +175,7 @@ constexpr int kBinSetWords = 2 * kBins + 2;
 __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
                                                                 unsigned* __restrict__ rowinfo,
                                                                 unsigned* __restrict__ set,
-                                                                unsigned* __restrict__ next_set,
-                                                                double* __restrict__ rowbase,
-                                                                unsigned long long* __restrict__ counters) {
+                                                                unsigned* __restrict__ next_set) {
     const int m = p.g.m;
     const int tid = threadIdx.x;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
@@ -233,10 +231,7 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
                 bin = fb >= 0.0 ? (fb < (double)(kBins - 1) ? (int)fb : kBins - 1) : 0;       // NaN -> 0
             }
         }
-        if (klo <= khi) {
-            c0 = klo >> 6; n = (khi >> 6) - c0 + 1;
-            rowbase[3 * row + 0] = S[0]; rowbase[3 * row + 1] = S[1]; rowbase[3 * row + 2] = S[2];
-        }
+        if (klo <= khi) { c0 = klo >> 6; n = (khi >> 6) - c0 + 1; }
         rowinfo[row] = n ? (0x80000000u | ((unsigned)bin << 16) | ((unsigned)n << 8) | (unsigned)c0) : 0u;
     }
     if (n) atomicAdd(&s_hist[bin], (unsigned)n);
@@ -354,7 +349,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 template <bool COLOR, bool KSTD, bool EXPPOLY>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, const unsigned* __restrict__ list, const unsigned* __restrict__ count,
-    const double* __restrict__ rowbase, float2* __restrict__ dw, float4* __restrict__ crgb,
+    float2* __restrict__ dw, float4* __restrict__ crgb,
     const float4* __restrict__ pn, unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */) {
     const int m = p.g.m;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -589,8 +584,17 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         code_v = 0; s0_v = s1_v = s2_v = 0.0;
         if (lane < cnt) {
             code_v = list[blk + (unsigned)wv + NW * (unsigned)lane];
-            const long long r = (long long)(code_v >> 6);
-            s0_v = rowbase[3 * r + 0]; s1_v = rowbase[3 * r + 1]; s2_v = rowbase[3 * r + 2];
+            // the row's share of rot_inv * g: its first two terms in Eigen's order ((r0*gx + r1*gy) + r2*gz), the same
+            // for every k of the row (get_global_coordinates, sdf.h:153-157: (extent/(float)m) * (i + 0.5) + origin)
+            const int r = (int)(code_v >> 6);
+            int il, jr;
+            if (tl.log2m >= 0) { il = r >> tl.log2m; jr = r & (m - 1); }
+            else { il = r / m; jr = r - il * m; }
+            const double gx = (double)p.g.cell_w * ((double)(il + p.g.xs) + 0.5) + p.g.origin[0];
+            const double gy = (double)p.g.cell_h * ((double)jr + 0.5) + p.g.origin[1];
+            s0_v = p.rot_inv[0] * gx + p.rot_inv[1] * gy;
+            s1_v = p.rot_inv[3] * gx + p.rot_inv[4] * gy;
+            s2_v = p.rot_inv[6] * gx + p.rot_inv[7] * gy;
         }
         // Wait for them HERE (vmcnt(0) only): otherwise hipcc puts a vmcnt(0) at their first use inside the
         // pipelined loop, where it would drain the pipeline on every step.
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 size_t integrate_worklist_entries(const Grid& g) {
     return (size_t)(g.xe - g.xs) * g.m * ((g.m + 63) / 64);
 }
-size_t integrate_rowbase_entries(const Grid& g) { return (size_t)(g.xe - g.xs) * g.m * 3; }
+size_t integrate_row_entries(const Grid& g) { return (size_t)(g.xe - g.xs) * g.m; }
 
 int integrate_blocks_per_cu() {
     int n = 0;
@@ -661,7 +665,7 @@ size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords; }
 
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            unsigned* worklist, unsigned* work_count, unsigned* rowinfo, double* rowbase, int n_blocks,
+                            unsigned* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
                             unsigned launch_parity, unsigned long long* wg_counts) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
@@ -679,7 +683,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     unsigned* const nxt = work_count + ((launch_parity + 1) & 1) * kBinSetWords;
     hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
-    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt, rowbase, counters);
+    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(tl.n_rows, rowinfo, cur, worklist, counters);
@@ -689,7 +693,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     const double span = (double)p.g.delta - (double)p.g.epsilon;
     const bool exp_poly = span >= 0.0 && 0.5 * span * span <= 0.0625;
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP) \
-    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, cur, rowbase, dw, crgb, pn, wg_counts)
+    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, cur, dw, crgb, pn, wg_counts)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE(C, KS, true); else TSDF_LAUNCH_INTEGRATE(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
     else { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(false, true); else TSDF_LAUNCH_INTEGRATE2(false, false); }
