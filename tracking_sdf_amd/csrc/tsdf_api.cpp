@@ -943,18 +943,20 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     // the pinned staging buffers may still feed the previous frame's async copies (frame stream only: the
     // integration of the previous frame keeps running on the main stream meanwhile)
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
-    h->staged_xyz = true;
+    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     if (!direct) {
         HIP_TRY(h, stage_and_upload(h, npix, true, nrm != nullptr, rgb != nullptr, [&](size_t i0, size_t i1) {
             std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
         }));
+        h->staged_xyz = true;
         return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
     }
     HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+    h->staged_xyz = true;
     HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
     rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
     if (rc) return rc;
@@ -992,6 +994,8 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
     HIP_TRY(h, hipStreamSynchronize(h->fstream));          // the pinned staging buffers may still feed the previous frame
+    const bool had_rgb = h->frame_has_rgb;
+    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
     const tsdf_aos_layout lay = *L;
     HIP_TRY(h, stage_and_upload(h, npix, points != nullptr, normals != nullptr, color, [&](size_t i0, size_t i1) {
@@ -1007,7 +1011,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
             for (size_t i = i0; i < i1; ++i, q += lay.normal_stride) std::memcpy(pnm + 3 * i, q, 12);
         }
     }));
-    const bool has_rgb = points ? color : h->frame_has_rgb;
+    const bool has_rgb = points ? color : had_rgb;
     h->staged_xyz = true;
     return run_pack(h, h->in_xyz, normals ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, h->fstream);
 }
@@ -1055,6 +1059,7 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
         h->pre_cap = npix;
     }
     HIP_TRY(h, hipStreamSynchronize(h->fstream));          // pinned staging may still feed the previous frame
+    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     const size_t dbytes = npix * (depth16 ? sizeof(uint16_t) : sizeof(float));
     const void* dsrc = depth16 ? (const void*)depth16 : (const void*)depthf;
     // page-locked caller buffers are copied from directly, as in tsdf_set_frame
