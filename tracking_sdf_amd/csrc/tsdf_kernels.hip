@@ -342,6 +342,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 #ifndef TSDF_INTEGRATE_NT_DW
 #define TSDF_INTEGRATE_NT_DW 0       // experiment: {D,W} streamed non-temporally too (keeps the pixel records in L2?)
 #endif
+#ifndef TSDF_INTEGRATE_BUFFER_STORES
+#define TSDF_INTEGRATE_BUFFER_STORES 0   // experiment (see the store section of the pipeline step): 1 = unconditional buffer stores
+#endif
 #ifndef TSDF_INTEGRATE_DEBUG
 #define TSDF_INTEGRATE_DEBUG 0      // 1 compiles the p.debug timing experiments in (uniform branches split the step)
 #endif
@@ -544,6 +547,16 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             if (COLOR) u.col = (crgb + base2)[sel];
 #endif
         }
+        // Stores of item j-1-DEPTH.  `if (live) store`: hipcc wraps the stores and the arithmetic feeding them in a branch
+        // over EXEC == 0, so the number of memory operations in flight depends on the path and every counted
+        // s_waitcnt vmcnt(N) behind the join is computed for the path WITHOUT the two stores -- two too small whenever
+        // they were issued: the wait for the pixel record of the next item then also waits for the two volume reads
+        // issued at the end of the previous step.  TSDF_INTEGRATE_BUFFER_STORES=1 issues the stores unconditionally
+        // instead (buffer stores whose dead lanes carry an out-of-range offset that the bounds check of the item's
+        // 512-byte / 1 KiB segment descriptor drops): the counted waits become exact (vmcnt(7) / (6) for the record,
+        // vmcnt(4) for the volume data) -- and the launch got 2.4 us SLOWER (134.6 against 132.3 us, same box, three
+        // runs each; bit-identical results), also with two or three items of volume reads in flight.  The exposed
+        // latency was not what the kernel waits for; the branch at least skips the divisions of items without a live lane.
         bool do_store = uin.live;
         bool st_dw = true, st_col = true;
 #if TSDF_INTEGRATE_DEBUG
@@ -552,26 +565,33 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         if (p.debug & 512) do_store = j3 >= 0 && j3 < cnt;
         st_dw = !(p.debug & 128); st_col = !(p.debug & 256);
 #endif
+#if !TSDF_INTEGRATE_BUFFER_STORES
         if (do_store) {
-#if TSDF_INTEGRATE_NT_DW
-            {
-                typedef float nt_f2 __attribute__((ext_vector_type(2)));
-                nt_f2 o2; o2.x = d_out; o2.y = w_sum;
-                __builtin_nontemporal_store(o2, reinterpret_cast<nt_f2*>(dw + base3) + lane);
-            }
-#else
             if (st_dw) (dw + base3)[lane] = make_float2(d_out, w_sum);
-#endif
-#if TSDF_INTEGRATE_NT
             if (COLOR && st_col) {
                 typedef float nt_f4 __attribute__((ext_vector_type(4)));
                 nt_f4 c4; c4.x = c_out.x; c4.y = c_out.y; c4.z = c_out.z; c4.w = c_out.w;
                 __builtin_nontemporal_store(c4, reinterpret_cast<nt_f4*>(crgb + base3) + lane);
             }
-#else
-            if (COLOR && st_col) (crgb + base3)[lane] = c_out;
-#endif
         }
+#else
+        {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int kDropped = 0x7fffffff;                       // beyond every segment: the lane stores nothing
+            constexpr int kRsrcWord3 = 0x00020000;                     // raw buffer, 32-bit data format (gfx9 family)
+            const __amdgpu_buffer_rsrc_t seg_dw = __builtin_amdgcn_make_buffer_rsrc(dw + base3, 0, 64 * (int)sizeof(float2), kRsrcWord3);
+            u32x2 o2; o2.x = __float_as_uint(d_out); o2.y = __float_as_uint(w_sum);
+            __builtin_amdgcn_raw_buffer_store_b64(o2, seg_dw, (do_store && st_dw) ? lane * (int)sizeof(float2) : kDropped, 0,
+                                                  TSDF_INTEGRATE_NT_DW ? 2 : 0);
+            if (COLOR) {
+                const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base3, 0, 64 * (int)sizeof(float4), kRsrcWord3);
+                u32x4 c4; c4.x = __float_as_uint(c_out.x); c4.y = __float_as_uint(c_out.y); c4.z = __float_as_uint(c_out.z); c4.w = __float_as_uint(c_out.w);
+                __builtin_amdgcn_raw_buffer_store_b128(c4, seg_c, (do_store && st_col) ? lane * (int)sizeof(float4) : kDropped, 0,
+                                                       TSDF_INTEGRATE_NT ? 2 : 0);   // aux 2 = nt: colour is streamed
+            }
+        }
+#endif
     };
 
     for (unsigned blk = wg_first; blk < wg_last; blk += 64u * NW) {
