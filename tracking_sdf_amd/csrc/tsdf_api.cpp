@@ -589,6 +589,10 @@ int fetch_counters(tsdf_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     unsigned long long own = 0, halo = 0;
     for (size_t b = 0; b < nw; b += 2) { own += h->wg_counts_host[b]; halo += h->wg_counts_host[b + 1]; }
+    if (h->integrate_debug & 4096) {      // load-balance experiment of debug builds: per workgroup {updated voxels, 10 ns ticks}, cumulative
+        for (size_t b = 0; b < nw; b += 2)
+            std::fprintf(stderr, "WGT %zu %llu %llu\n", b / 2, h->wg_counts_host[b + 1], h->wg_counts_host[b]);
+    }
     h->counters_host[kCntUpdatedOwned] = own;
     h->counters_host[kCntUpdatedHalo] = halo;
     return TSDF_OK;

@@ -361,6 +361,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     const double cd = (double)p.g.cell_d;
     const float delta = p.g.delta, eps = p.g.epsilon;
     const unsigned n_items = *count;
+#if TSDF_INTEGRATE_DEBUG
+    const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
     // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
     // list = one x-range of the slab = one band of the image, so the pixel records it gathers stay in
@@ -654,6 +657,12 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     // Update counts: wave shuffle, LDS across the waves, then the workgroup adds to ITS OWN pair of cumulative words
     // (plain read-modify-write, nobody else touches them; the host adds the pairs up when somebody asks).  A thousand
     // workgroups finishing together with an atomic on one shared word each were a serial tail of the launch.
+#if TSDF_INTEGRATE_DEBUG
+    if ((p.debug & 2048) && (blockIdx.x % 251) == 0 && tid == 0) {   // shader clock during the launch: cycles per 100 MHz tick
+        const unsigned long long dc = __builtin_readcyclecounter() - dbg_c0, dr = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+        printf("integrate wg %u: %llu cycles in %llu ticks of 10 ns = %.0f MHz\n", blockIdx.x, dc, dr, dr ? 100.0 * (double)dc / (double)dr : 0.0);
+    }
+#endif
     __shared__ unsigned s_cnt[2][kIntegrateBlock / 64];
     for (int off = 32; off > 0; off >>= 1) {
         n_own += __shfl_xor(n_own, off);
@@ -666,6 +675,10 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         for (int q = 0; q < kIntegrateBlock / 64; ++q) { a += s_cnt[0][q]; b += s_cnt[1][q]; }
         if (a) counters[2 * blockIdx.x + 0] += (unsigned long long)a;
         if (b) counters[2 * blockIdx.x + 1] += (unsigned long long)b;
+#if TSDF_INTEGRATE_DEBUG
+        // load-balance experiment: the halo word accumulates the workgroup's running time (10 ns ticks) instead
+        if (p.debug & 4096) counters[2 * blockIdx.x + 1] += (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+#endif
     }
 }
 
