@@ -11,7 +11,7 @@ LIB     := $(LIBDIR)/libtsdf_hip.so
 # two roundings (its g++ build sets no -O/-march flags, src/CMakeLists.txt:97-98).
 HIPEXTRA ?=
 HIPFLAGS := $(HIPEXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
-            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wextra -Wno-unused-parameter
+            -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter
 SRCS := $(CSRC)/tsdf_kernels.hip $(CSRC)/preproc_kernels.hip $(CSRC)/mesh_kernels.hip $(CSRC)/tsdf_api.cpp $(CSRC)/rccl_dyn.cpp
 HDRS := $(CSRC)/tsdf_device.h $(CSRC)/mc_tables.h $(CSRC)/host_math.hpp $(CSRC)/rccl_dyn.hpp $(ROOT)include/tsdf.h
 

@@ -116,7 +116,7 @@ struct tsdf_handle {
     unsigned long long* counters_host = nullptr;  // pinned
     unsigned long long* wg_counts = nullptr;      // device: {owned, halo} voxels updated, cumulative, per integrate workgroup
     unsigned long long* wg_counts_host = nullptr; // pinned mirror
-    unsigned* worklist = nullptr;  // integrate work items (row << 6 | chunk)
+    void* worklist = nullptr;      // integrate work items (32-byte descriptors: row << 6 | chunk, the row's share of rot_inv * g)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
     unsigned* rowinfo = nullptr;      // per voxel row: first chunk, chunk count, image band
     int integrate_blocks = 0;      // persistent grid of integrate_kernel
@@ -275,7 +275,7 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
     if (npix > h->pn_cap) {
         for (int b = 0; b < 2; ++b) { if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]); h->pn_buf[b] = nullptr; }
         h->pn = nullptr; h->pn_cap = 0; h->have_frame = false;
-        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->pn_buf[b], npix * 2 * sizeof(float4)));
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->pn_buf[b], npix * kPixelRecordBytes));
         h->pn_cap = npix;
     }
     if (ns > h->samples_cap) {
@@ -746,7 +746,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMalloc((void**)&h->counters, kNumCounters * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(h->counters, 0, kNumCounters * sizeof(unsigned long long), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->counters_host, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
-    CREATE_TRY(hipMalloc((void**)&h->worklist, integrate_worklist_entries(g) * sizeof(unsigned)));
+    CREATE_TRY(hipMalloc((void**)&h->worklist, integrate_worklist_bytes(g)));
     CREATE_TRY(hipMalloc((void**)&h->work_count, integrate_bookkeeping_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->work_count, 0, integrate_bookkeeping_words() * sizeof(unsigned), h->stream));
     CREATE_TRY(hipMalloc((void**)&h->rowinfo, integrate_row_entries(g) * sizeof(unsigned)));

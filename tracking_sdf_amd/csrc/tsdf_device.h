@@ -101,12 +101,14 @@ hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const 
 // first launch; rowinfo: one unsigned per row (integrate_row_entries(g)); n_blocks: persistent grid size (CUs x
 // integrate_blocks_per_cu()).
 size_t integrate_worklist_entries(const Grid& g);
+size_t integrate_worklist_bytes(const Grid& g);      // 32-byte item descriptors (+ slack)
+constexpr size_t kPixelRecordBytes = 32 + 8;         // per pixel: two float4 records + the f64 cosine plane behind them
 size_t integrate_row_entries(const Grid& g);
 size_t integrate_bookkeeping_words();
 int integrate_blocks_per_cu();
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            unsigned* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
+                            void* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
                             unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */);
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an

@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
     pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
     // sdf.cpp:294: cosine = |cam_vect . n| / |n| depends on the pixel only.  Its f32 rounding rides in the
     // record: for the common weight w_new == 1 the colour weight (float)(w_new * cosine) is exactly that.
-    pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)pixel_cosine(nx, ny, nz));
+    const double cosine = pixel_cosine(nx, ny, nz);
+    pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)cosine);
+    // ... and its f64 value in a plane behind the records, for the voxels whose weight is not 1 (the exp() band)
+    reinterpret_cast<double*>(pn + 2 * (long long)width * height)[rec] = cosine;
     if (col % stride == 0 && row % stride == 0) {
         const int ci = col / stride, rj = row / stride;
         if (ci < ncols && rj < nrows) samples[ci * nrows + rj] = make_float4(px, py, pz, 0.0f);
@@ -148,6 +151,7 @@ struct IntegrateTiling {
     int log2m;           // >= 0 when m is a power of two
     int clip;            // 1 = K has the usual last row (0,0,k22>0): row clipping is valid
     int k_std;           // 1 = K = [[fx,0,cx],[0,fy,cy],[0,0,1]] exactly: zero terms can be dropped
+    int fastq;           // 1 = pixel coordinates by fixed-point reciprocal multiplies (integrate_kernel), 0 = always divide
 };
 
 // interval of k (real-valued) on which a + k*b > 0, intersected into [lo, hi].  The crossing -a/b only has to be
@@ -245,14 +249,24 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
     }
 }
 
+// One work item as integrate_kernel reads it, with ONE scalar load: the item code and the row's share of rot_inv * g
+// (its first two terms in Eigen's order ((r0*gx + r1*gy) + r2*gz), identical for every k of the row).
+struct __attribute__((aligned(32))) ItemDesc {
+    unsigned code;          // row << 6 | chunk   (row = il * m + j, chunk = k / 64)
+    unsigned pad;
+    double s0, s1, s2;
+};
+static_assert(sizeof(ItemDesc) == 32, "one s_load_dwordx8 per item");
+
 // Second pass: the items of every row go to the part of the list that belongs to the row's image band (counting
 // sort by band; the order inside a band is whatever the atomics give -- every voxel belongs to exactly one item, so
 // no result depends on the order).  integrate_kernel hands each XCD one contiguous eighth of the list = a band of
 // the image whose pixel records (about 1.2 MB) then live in that XCD's L2: with the list in row order every XCD
 // gathered from the whole image, and 63 % of the launch's fabric reads were pixel records fetched again and again
 // (296 MB for a 9.8 MB image).
-__global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(long long n_rows, const unsigned* __restrict__ rowinfo,
-                                                                   unsigned* __restrict__ set, unsigned* __restrict__ list,
+__global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(IntegrateParams p, IntegrateTiling tl,
+                                                                   const unsigned* __restrict__ rowinfo,
+                                                                   unsigned* __restrict__ set, ItemDesc* __restrict__ list,
                                                                    unsigned long long* __restrict__ counters) {
     static_assert(kBins == 64, "one wavefront scans the bands");
     __shared__ unsigned s_start[kBins], s_wg[kBins], s_base[kBins];
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(long long n_ro
         }
     }
     __syncthreads();
-    const unsigned info = row < n_rows ? rowinfo[row] : 0u;
+    const unsigned info = row < tl.n_rows ? rowinfo[row] : 0u;
     const unsigned n = (info >> 8) & 0xFFu, c0 = info & 0xFFu, bin = (info >> 16) & 0x3Fu;
     unsigned rank = 0u;
     if (info) rank = atomicAdd(&s_wg[bin], n);
@@ -282,392 +296,490 @@ __global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(long long n_ro
     if (tid < kBins) s_base[tid] = s_wg[tid] ? atomicAdd(&set[1 + kBins + tid], s_wg[tid]) : 0u;
     __syncthreads();
     if (info) {
+        const int m = p.g.m;
+        int il, jr;
+        if (tl.log2m >= 0) { il = (int)(row >> tl.log2m); jr = (int)(row & (m - 1)); }
+        else { il = (int)(row / m); jr = (int)(row - (long long)il * m); }
+        // get_global_coordinates, sdf.h:153-157: (extent/(float)m) * (i + 0.5) + origin
+        const double gx = (double)p.g.cell_w * ((double)(il + p.g.xs) + 0.5) + p.g.origin[0];
+        const double gy = (double)p.g.cell_h * ((double)jr + 0.5) + p.g.origin[1];
+        ItemDesc d;
+        d.pad = 0u;
+        d.s0 = p.rot_inv[0] * gx + p.rot_inv[1] * gy;
+        d.s1 = p.rot_inv[3] * gx + p.rot_inv[4] * gy;
+        d.s2 = p.rot_inv[6] * gx + p.rot_inv[7] * gy;
         const unsigned at = s_start[bin] + s_base[bin] + rank;
         const unsigned code = (unsigned)row << 6;
-        for (unsigned q = 0; q < n; ++q) list[at + q] = code | (c0 + q);
+        for (unsigned q = 0; q < n; ++q) { d.code = code | (c0 + q); list[at + q] = d; }
     }
 }
 
-// exp(x) for the weight of sdf.cpp:278.  x = -(d-eps)^2/2 lies in [-(delta-eps)^2/2, 0]; for
-// |x| <= 1/16 (decided on the host from delta - epsilon: template flag EXPPOLY) a degree-10 Taylor polynomial in f64 (fused multiply-adds: this approximates the exact
-// function, it does not mimic reference roundings) has a truncation error below 2e-19, i.e. it is as
-// close to the true value as glibc's / ocml's exp (< 1 ulp of f64) and agrees with them after the
-// reference's f64 -> f32 narrowing except for values within ~1e-16 (relative) of an f32 rounding
-// boundary.  Larger |x| (non-default delta) use the library exp.  The polynomial is branch-free, which keeps
-// the pipeline step of integrate_kernel one basic block.
-__device__ __forceinline__ double exp_taylor10(double x) {
-    double r = 1.0 / 3628800.0;
-    r = __builtin_fma(r, x, 1.0 / 362880.0);
-    r = __builtin_fma(r, x, 1.0 / 40320.0);
-    r = __builtin_fma(r, x, 1.0 / 5040.0);
-    r = __builtin_fma(r, x, 1.0 / 720.0);
-    r = __builtin_fma(r, x, 1.0 / 120.0);
-    r = __builtin_fma(r, x, 1.0 / 24.0);
-    r = __builtin_fma(r, x, 1.0 / 6.0);
+// exp(x) for the weight of sdf.cpp:278.  x = -(d-eps)^2/2 lies in [-(delta-eps)^2/2, 0] = [-0.0378, 0] with the
+// reference's delta and epsilon; for |x| <= 0.04 (decided on the host: template flag EXPPOLY) the degree-8 Taylor polynomial
+// in f64 (fused multiply-adds: this approximates the exact function, it does not mimic reference roundings) has a
+// truncation error below 0.04^9/9! = 7e-19 relative, i.e. it is as close to the true value as glibc's / ocml's exp
+// (< 1 ulp of f64 = 1.1e-16) and agrees with them after the reference's f64 -> f32 narrowing except for values within
+// ~1e-16 (relative) of an f32 rounding boundary.  Larger |x| (non-default delta) use the library exp.
+// v_fma_f64 spelled out: hipcc turns a Horner step with a constant addend into v_mov_b64 + v_fmac_f64.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double exp_taylor8(double x) {
+    double r = fma3(x, 1.0 / 40320.0, 1.0 / 5040.0);
+    r = fma3(r, x, 1.0 / 720.0);
+    r = fma3(r, x, 1.0 / 120.0);
+    r = fma3(r, x, 1.0 / 24.0);
+    r = fma3(r, x, 1.0 / 6.0);
     r = __builtin_fma(r, x, 0.5);
     r = __builtin_fma(r, x, 1.0);
     r = __builtin_fma(r, x, 1.0);
     return r;
 }
 
-// Per-item state between the pipeline stages of integrate_kernel.  Only what is per LANE lives here: the item code
-// (row, chunk) is wave-uniform and every stage reads it again from the block's code register with v_readlane, so
-// voxel addresses are a scalar base + the lane number (no 64-bit per-lane index is carried through the pipeline).
+// ---- integrate_kernel ---------------------------------------------------------------------------------------------
+//
+// Round 3: the kernel is bound by VECTOR-INSTRUCTION ISSUE, not by memory (profiles/r03_integrate_ablation.json: with
+// every access redirected to cache-resident addresses the round-2 kernel lost 8 us of 122; one wave-instruction
+// costs ~0.33 us of launch time whatever its type), so this version is written for the smallest number of vector
+// instructions per 64-voxel item that still performs the reference's operations bit for bit:
+//   * everything that is the same for the 64 lanes of an item lives in SGPRs: the item descriptor arrives by one
+//     scalar load, addresses are scalar bases + a loop-invariant per-lane offset, predicates stay lane masks and
+//     are counted with s_bcnt1;
+//   * the k-dependent products rot_inv[.,2] * gz(k) come from a table in LDS built once per workgroup (they are
+//     the same for every row);
+//   * the two projective quotients u = ij0/ij2, v = ij1/ij2 are only needed through (int)u, (int)v and the range
+//     tests, so they are computed as ij * (refined f32 reciprocal) in 2^-20 pixel fixed point (error < 2^-10 of a
+//     unit, see fast_quotients) and the wavefront falls back to the reference's two f64 divisions whenever a lane
+//     lands within 2 units of an integer (about once in 10^4 wavefronts);
+//   * volume reads and stores are raw buffer operations on a 512-byte / 1-KiB descriptor of the item's segment:
+//     dead lanes carry an out-of-range offset and touch no memory -- no branch, no EXEC juggling, exact s_waitcnt counts;
+//   * the four f32 divisions of the running averages (one for D, three for the colour) run two at a time as packed
+//     f32 operations with the division's own FMA sequence (exactly the instruction sequence hipcc emits for
+//     a correctly rounded `/`, minus the range scaling, which a guard proves unnecessary or else takes the `/` path);
+//   * the f64 cosine of the colour weight rides in a per-pixel plane written by pack_kernel, so the exp() band costs
+//     three instructions instead of a square root and a division in f64.
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFixShift = 20;                        // pixel coordinates in 2^-20 units
+constexpr unsigned kFixOne = 1u << kFixShift;
+constexpr int kMaxFastDim = 2047;                    // (dim + 1) << 20 must fit 32 bits
+constexpr unsigned kDroppedOffset = 0x7fffffffu;     // beyond every buffer: the lane loads zeros / stores nothing
+constexpr int kRsrcWord3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
+
+// v_cvt_i32_f64 as the hardware does it (saturating, NaN -> 0); a C cast of an out-of-range value is undefined
+__device__ __forceinline__ int cvt_i32_f64_sat(double x) {
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// lane mask of a per-lane condition (v_cmp writes it straight into an SGPR pair)
+__device__ __forceinline__ unsigned long long lanes(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+
+// lanes whose value is subnormal (v_cmp_class_f32 with the two subnormal classes), straight into an SGPR pair:
+// through __builtin_amdgcn_classf + ballot hipcc makes a 0/1 VGPR of it first
+__device__ __forceinline__ unsigned long long lanes_subnormal(float x) {
+    unsigned long long m;
+    const unsigned cls = (1u << 4) | (1u << 7);
+    asm("v_cmp_class_f32 %0, %1, %2" : "=s"(m) : "v"(x), "v"(cls));
+    return m;
+}
+
+// per-lane select by a wave-uniform lane mask held in an SGPR pair: bit of the lane set ? a : b.  (A bool that
+// crosses a loop iteration becomes a 0/1 VGPR + v_and + v_cmp in hipcc's hands; masks carried as 64-bit scalars do not.)
+__device__ __forceinline__ unsigned select_by_mask(unsigned long long mask, unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+
 struct GatherState {        // stage 1 done: pixel record requested
-    bool live;
+    unsigned long long live;   // lane mask (wave-uniform)
+    unsigned code;          // the item (wave-uniform)
     double pcx, pcy, pcz;   // camera-frame voxel centre
-    float4 P, N;            // pixel record (in flight until stage 2 reads it)
+    unsigned roff;          // byte offset of the lane's pixel record (kDroppedOffset when dead)
+    u32x4 A, B;             // halves of the pixel records of lanes 0..31 (A) and 32..63 (B): lane l holds half l&1 of the
+                            // record of lane l>>1 (A) / 32 + (l>>1) (B)                 (in flight until stage 2)
 };
 struct UpdateState {        // stage 2 done: volume reads requested
-    bool live;
-    float d_new, w_new;
+    unsigned long long live;   // lane mask (wave-uniform)
+    unsigned long long band;   // lanes whose weight went through exp() (wave-uniform)
+    unsigned code;          // the item (wave-uniform)
+    float d_new, w_new, wc;
+    u32x2 C;                // f64 cosine of the pixel, band lanes only (in flight until stage 3)
     unsigned rgb;
-    float2 old;             // {D, W}            (in flight until stage 3)
-    float4 col;             // {Color_W, R, G, B} (in flight until stage 3)
-    float wc;               // colour weight (float)(w_new * cosine), sdf.cpp:299
+    unsigned off8;          // byte offset of the lane's {D,W} in the item's segment, kDroppedOffset when dead
+    u32x2 old;              // {D, W}            (in flight until stage 3)
+    u32x4 col;              // {Color_W, R, G, B} (in flight until stage 3)
 };
-
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
 
 #ifndef TSDF_INTEGRATE_DEPTH
 #define TSDF_INTEGRATE_DEPTH 1      // volume reads in flight per wavefront, in items (see the pipeline loop)
 #endif
-#ifndef TSDF_INTEGRATE_NT
-#define TSDF_INTEGRATE_NT 1          // non-temporal colour loads/stores (colour is streamed once and never re-read by the tracker)
-#endif
-#ifndef TSDF_INTEGRATE_NT_DW
-#define TSDF_INTEGRATE_NT_DW 0       // experiment: {D,W} streamed non-temporally too (keeps the pixel records in L2?)
-#endif
-#ifndef TSDF_INTEGRATE_BUFFER_STORES
-#define TSDF_INTEGRATE_BUFFER_STORES 0   // experiment (see the store section of the pipeline step): 1 = unconditional buffer stores
+#ifndef TSDF_INTEGRATE_ORDER
+#define TSDF_INTEGRATE_ORDER 123    // order of the three stages inside a pipeline step (timing experiments: 132, 213)
 #endif
 #ifndef TSDF_INTEGRATE_DEBUG
-#define TSDF_INTEGRATE_DEBUG 0      // 1 compiles the p.debug timing experiments in (uniform branches split the step)
+#define TSDF_INTEGRATE_DEBUG 0      // 1 compiles the p.debug timing experiments in
 #endif
 
-template <bool COLOR, bool KSTD, bool EXPPOLY>
+template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
-    IntegrateParams p, IntegrateTiling tl, const unsigned* __restrict__ list, const unsigned* __restrict__ count,
+    IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ count,
     float2* __restrict__ dw, float4* __restrict__ crgb,
     const float4* __restrict__ pn, unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */) {
+    extern __shared__ double s_tab[];                         // KTAB: {rot_inv[2], rot_inv[5], rot_inv[8]} * gz(k), k = 0..m-1
     const int m = p.g.m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double oz = p.g.origin[2];
     const double cd = (double)p.g.cell_d;
-    const float delta = p.g.delta, eps = p.g.epsilon;
+    const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
     const unsigned n_items = *count;
-#if TSDF_INTEGRATE_DEBUG
-    const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
+    if (KTAB) {
+        for (int k = tid; k < m; k += kIntegrateBlock) {
+            // get_global_coordinates (sdf.h:153-157): (extent/(float)m) * (k + 0.5) + origin; third term of rot_inv * g
+            const double gz = cd * ((double)k + 0.5) + oz;
+            s_tab[3 * k + 0] = p.rot_inv[2] * gz;
+            s_tab[3 * k + 1] = p.rot_inv[5] * gz;
+            s_tab[3 * k + 2] = p.rot_inv[8] * gz;
+        }
+        __syncthreads();
+    }
     // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
-    // list = one x-range of the slab = one band of the image, so the pixel records it gathers stay in
-    // its own L2 instead of every XCD streaming the whole 10 MB image through.
+    // list = one band of the image, so the pixel records it gathers stay in its own L2.
     const unsigned vblock = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    // The workgroup's contiguous share of the work list (items of one row stay together), dealt to its wavefronts
-    // ITEM BY ITEM: at any moment the NW wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring
-    // voxel rows, which project to the same few image columns -- the pixel-record lines one wavefront pulls into the
-    // CU's L1 serve the others.  (Measured with one contiguous range per wavefront: 63 % of the launch's fabric reads,
-    // 296 MB for a 9.8 MB image, were pixel records fetched again and again -- every wavefront of the CU was gathering
-    // from another part of the image and the L1 turned over several times per step.)
+    // The workgroup's contiguous share of the work list, dealt to its wavefronts ITEM BY ITEM: at any moment the NW
+    // wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring voxel rows, which project to the
+    // same few image columns -- the pixel-record lines one wavefront pulls into the CU's L1 serve the others.
     const unsigned wg_first = (unsigned)(((unsigned long long)n_items * vblock) / gridDim.x);
     const unsigned wg_last = (unsigned)(((unsigned long long)n_items * (vblock + 1)) / gridDim.x);
+    const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
     unsigned n_own = 0, n_halo = 0;
-    unsigned code_v = 0;
-    double s0_v = 0.0, s1_v = 0.0, s2_v = 0.0;
-    int cnt = 0;
-    __shared__ float4 s_pieces[kIntegrateBlock / 64][128];   // wave-private un-shuffle buffer of the paired gather
 
-    // One pipeline step = S1(j) | S3(j-1-DEPTH) | S2(j-1): three independent instruction streams the scheduler can
-    // interleave (f64 chains are latency-bound on their own).  Loads are issued on every path (dead lanes re-read a
-    // line that is fetched anyway) so hipcc emits counted s_waitcnt vmcnt(N), never vmcnt(0), inside the loop; the
-    // stores and the rare f64 cosine are the only predicated parts.
-    const long long own_row0 = (long long)(p.g.own_x0 - p.g.xs) * m, own_row1 = (long long)(p.g.own_x1 - p.g.xs) * m;
-    auto step = [&](int j, GatherState& g /*out: item j*/, const GatherState& gin /*item j-1, record arrived*/,
-                    UpdateState& u /*out: item j-1*/, const UpdateState& uin /*item j-2, volume data arrived*/) {
+    // scaled intrinsics: K rows 0 and 1 times 2^20 (exact), so that ij0, ij1 come out in 2^-20 pixel units
+    const double fix = (double)kFixOne, unfix = 1.0 / (double)kFixOne;
+    double Ks[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) Ks[a] = p.K[a] * fix;
+    const unsigned lim_u = ((unsigned)p.width + 1u) * kFixOne + 2u, lim_w = ((unsigned)p.height + 1u) * kFixOne + 2u;
+    const bool fastq = tl.fastq != 0;
+    // lanes of the last chunk that lie inside the grid when m is not a multiple of 64 (scalar select per item)
+    const unsigned last_chunk = (unsigned)(m - 1) >> 6;
+    const unsigned long long tail_mask = (m & 63) ? ((1ull << (m & 63)) - 1ull) : ~0ull;
+    // record offsets: the index of pixel (iu, iw) is iu*pix_su + iw*pix_sv; stage 1 works with iu+1, iw+1
+    const unsigned rs_u = (unsigned)p.pix_su * 32u, rs_w = (unsigned)p.pix_sv * 32u;
+    const long long npix = (long long)p.width * p.height;
+    const char* rec_base = reinterpret_cast<const char*>(pn) - ((long long)rs_u + rs_w);
+    const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(rec_base), 0, (int)(npix * 32 + rs_u + rs_w), kRsrcWord3);
+    const char* cos_base = reinterpret_cast<const char*>(pn) + npix * 32 - (((long long)rs_u + rs_w) >> 2);
+    const __amdgpu_buffer_rsrc_t cos_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(cos_base), 0, (int)(npix * 8 + ((rs_u + rs_w) >> 2)), kRsrcWord3);
+    const unsigned lane8 = (unsigned)lane * 8u;
+    const unsigned half16 = (unsigned)(lane & 1) * 16u;
+    __shared__ u32x4 s_pieces[kIntegrateBlock / 64][128];      // wave-private un-shuffle buffer of the paired gather
+    const unsigned tab_lane = (unsigned)lane * 24u;
+    const unsigned dropped = kDroppedOffset;
+
+    const unsigned own_row0 = (unsigned)((p.g.own_x0 - p.g.xs) * m), own_row1 = (unsigned)((p.g.own_x1 - p.g.xs) * m);   // rows < 2^26
+
+    // One pipeline step = S1(j) | S2(j-1) | S3(j-1-DEPTH): three independent instruction streams.  Order inside the step:
+    // S1 requests the pixel record of item j, S2 consumes the record requested a step earlier and requests the volume data,
+    // S3 consumes the volume data requested DEPTH steps earlier -- every request has (at least) a whole step to complete.
+    auto stage1 = [&](int j, GatherState& g /*out: item j*/) {
         // ---------------- S1(j): geometry, request the pixel record
         {
-            const int jj = j < cnt ? j : 0;
-            const unsigned code = __builtin_amdgcn_readlane(code_v, jj);
-            const long long row = (long long)(code >> 6);
-            const int k = (int)(code & 63u) * 64 + lane;
-            (void)row;
-            const double sx = readlane_f64(s0_v, jj), sy = readlane_f64(s1_v, jj), sz = readlane_f64(s2_v, jj);
+            const bool have = j < cnt;
+            const ItemDesc ds = list[wg_first + (unsigned)wv + NW * (unsigned)(have ? j : 0)];
+            const unsigned chunk = ds.code & 63u;
+            double a0, a1, a2;
+            if (KTAB) {
+                const double* t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_tab) + (tab_lane + chunk * (64u * 24u)));
+                a0 = t[0]; a1 = t[1]; a2 = t[2];
+            } else {
+                const double gz = cd * ((double)((int)(chunk * 64u) + lane) + 0.5) + oz;
+                a0 = p.rot_inv[2] * gz; a1 = p.rot_inv[5] * gz; a2 = p.rot_inv[8] * gz;
+            }
             // get_global_coordinates (sdf.h:153-157) + project_world_to_camera (camera_tracking.cpp:51-54)
-            const double gz = cd * ((double)k + 0.5) + oz;
-            g.pcx = (sx + p.rot_inv[2] * gz) + p.rot_inv_trans[0];
-            g.pcy = (sy + p.rot_inv[5] * gz) + p.rot_inv_trans[1];
-            g.pcz = (sz + p.rot_inv[8] * gz) + p.rot_inv_trans[2];
-            bool ok = (j < cnt) && (k < m) && !(g.pcz < 0);                     // sdf.cpp:247-249
-            // project_camera_to_image_plane, camera_tracking.cpp:40-47.  With K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
-            // the dropped terms are +-0 products: (fx*x + 0*y) + cx*z == fx*x + cx*z and (0*x + 0*y) + 1*z == z
-            // bit for bit (up to the sign of a zero, which no later step can observe).
+            g.pcx = (ds.s0 + a0) + p.rot_inv_trans[0];
+            g.pcy = (ds.s1 + a1) + p.rot_inv_trans[1];
+            g.pcz = (ds.s2 + a2) + p.rot_inv_trans[2];
+            unsigned long long okm = lanes(!(g.pcz < 0)) & (chunk == last_chunk ? tail_mask : ~0ull);   // sdf.cpp:247-249
+            if (!have) okm = 0ull;
+            // project_camera_to_image_plane, camera_tracking.cpp:40-47, rows 0 and 1 scaled by 2^20 (exact).  With
+            // K = [[fx,0,cx],[0,fy,cy],[0,0,1]] the dropped terms are +-0 products: (fx*x + 0*y) + cx*z == fx*x + cx*z
+            // and (0*x + 0*y) + 1*z == z bit for bit (up to the sign of a zero, which no later step can observe).
             double ij0, ij1, ij2;
             if (KSTD) {
-                ij0 = p.K[0] * g.pcx + p.K[2] * g.pcz;
-                ij1 = p.K[4] * g.pcy + p.K[5] * g.pcz;
+                ij0 = Ks[0] * g.pcx + Ks[2] * g.pcz;
+                ij1 = Ks[4] * g.pcy + Ks[5] * g.pcz;
                 ij2 = g.pcz;
             } else {
-                ij0 = row3(&p.K[0], g.pcx, g.pcy, g.pcz);
-                ij1 = row3(&p.K[3], g.pcx, g.pcy, g.pcz);
+                ij0 = row3(&Ks[0], g.pcx, g.pcy, g.pcz);
+                ij1 = row3(&Ks[3], g.pcx, g.pcy, g.pcz);
                 ij2 = row3(&p.K[6], g.pcx, g.pcy, g.pcz);
             }
-            const double uu = ij0 / ij2;
-            const double ww = ij1 / ij2;
-            // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
-            // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
-            ok = ok && (uu > -1.0 && uu < (double)p.width && ww > -1.0 && ww < (double)p.height);
-            const int iu = ok ? (int)uu : 0, iw = ok ? (int)ww : 0;
-            int rec = iu * p.pix_su + iw * p.pix_sv;                     // record index (< width * height)
-#if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 1) rec = __shfl(rec, 0);          // timing experiment only: one record per wave
-            if (p.debug & 8) {                              // timing experiment only: 64 consecutive records (coalesced)
-                const int r0 = __shfl(rec, 0);
-                rec = r0 + lane < p.width * p.height ? r0 + lane : r0;
+            // (int)(ij0/ij2), (int)(ij1/ij2) and the range tests of sdf.cpp:250-256 without dividing: ij2's reciprocal
+            // from v_rcp_f32 (1 ulp) and one Newton step in f64 is good to 2^-43, so q = ij * rd is within
+            // |q| 2^-42 <= 2^-11 units (|q| < 2^31 units) of the true quotient, and so is the reference's rounded
+            // quotient (2^-53 relative).  A lane whose q lies within 2 units of a multiple of 2^20 (an integer pixel
+            // coordinate: truncation and both range tests switch only there), or whose ij2 is not a plain positive
+            // number, sends the wavefront through the reference's divisions.
+            const float zf = (float)ij2;
+            double rd = (double)__builtin_amdgcn_rcpf(zf);
+            rd = __builtin_fma(__builtin_fma(-ij2, rd, 1.0), rd, rd);
+            const unsigned tu = (unsigned)cvt_i32_f64_sat(ij0 * rd) + (kFixOne + 2u);
+            const unsigned tw = (unsigned)cvt_i32_f64_sat(ij1 * rd) + (kFixOne + 2u);
+            unsigned long long inrm = lanes(tu < lim_u) & lanes(tw < lim_w);
+            unsigned iu1 = max(tu >> kFixShift, 1u), iw1 = max(tw >> kFixShift, 1u);      // pixel column + 1, row + 1
+            const unsigned long long doubtm =
+                okm & (lanes(!(zf > 1.0e-6f)) | lanes(min(tu & (kFixOne - 1u), tw & (kFixOne - 1u)) < 5u));
+            if (__builtin_expect(!fastq || doubtm != 0ull, 0)) {
+                // rows 0 and 1 unscaled again (exact: powers of two), then the reference's divisions
+                const double uu = (ij0 * unfix) / ij2, ww = (ij1 * unfix) / ij2;
+                // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
+                // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
+                const bool inr = uu > -1.0 && uu < (double)p.width && ww > -1.0 && ww < (double)p.height;
+                iu1 = inr ? (unsigned)((int)uu + 1) : 1u;
+                iw1 = inr ? (unsigned)((int)ww + 1) : 1u;
+                inrm = lanes(inr);
             }
-            if (p.debug & 16) {                             // timing experiment only: consecutive records, 2 lanes each
-                const int r0 = __shfl(rec, 0);
-                rec = r0 + lane * 3 / 2 < p.width * p.height ? r0 + lane * 3 / 2 : r0;
+            okm &= inrm;
+            unsigned roff = __umul24(iu1, rs_u) + __umul24(iw1, rs_w);          // byte offset of the record (+ the bias in rec_base)
+#if TSDF_INTEGRATE_DEBUG
+            if (p.debug & 1) roff = __builtin_amdgcn_readfirstlane(roff);       // timing experiment only: one record per wave
+#endif
+            roff = select_by_mask(okm, roff, dropped);
+            // Pixel-record gather, paired: the vector L1 serves a wave's gather about one lane-address at a time, and the
+            // two 16-byte halves of a 32-byte record are two instructions.  Instead the first load fetches both halves of
+            // the records of lanes 0..31 (lane l: record of lane l/2, half l%2), the second those of lanes 32..63: lane pairs
+            // share a line, so the look-ups of an item are halved (measured, round 3: 74 of 185 us of the launch were the
+            // three unpaired gather instructions).  Stage 2 un-shuffles the pieces through a wave-private LDS buffer.
+            g.roff = roff;
+            const unsigned ra = (unsigned)__shfl((int)roff, lane >> 1) + half16;
+            const unsigned rb = (unsigned)__shfl((int)roff, 32 + (lane >> 1)) + half16;
+            g.A = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (int)ra, 0, 0);      // piece for LDS slot lane
+            g.B = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (int)rb, 0, 0);      // piece for LDS slot 64 + lane
+#if TSDF_INTEGRATE_DEBUG
+            // issue-cost experiments: 32 extra scalar / vector / f64 instructions per step
+            if (p.debug & 2048) {
+                unsigned x = ds.code;
+                asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
+                             "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
+                             "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
+                             "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1" : "+s"(x) :: "scc");
+                n_halo += x & 0u;
+            }
+            if (p.debug & 4096) {
+                unsigned x = roff;
+                asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
+                             "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
+                             "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
+                             "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1" : "+v"(x));
+                g.roff += x & 0u;
+            }
+            if (p.debug & 8192) {
+                double x = g.pcx;
+                asm volatile("v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n"
+                             "v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n"
+                             "v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n"
+                             "v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0" : "+v"(x));
+                if (x == 12345.678) g.roff += 1u;
             }
 #endif
-            // Pixel-record gather, paired: the vector L1 looks every distinct 128-byte line up once per
-            // INSTRUCTION, and the two 16-byte halves of a 32-byte record are two instructions.  Instead, the first
-            // load fetches both halves of the records of lanes 0..31 (lane l: record of lane l/2, half l%2), the
-            // second those of lanes 32..63: each line is looked up once per item instead of twice (the L1 was the
-            // measured bottleneck: TCP busy ~90 %, 70 % of its look-ups were this gather).  S2 un-shuffles
-            // the pieces through a wave-private LDS buffer.
-            const int recA = __shfl(rec, lane >> 1);
-            const int recB = __shfl(rec, 32 + (lane >> 1));
-            g.P = pn[2 * (long long)recA + (lane & 1)];      // piece for LDS slot lane
-            g.N = pn[2 * (long long)recB + (lane & 1)];      // piece for LDS slot 64 + lane
-            g.live = ok;
+            g.live = okm;
+            g.code = ds.code;
         }
-        // ---------------- S3(j-2): running averages (unconditional arithmetic, predicated stores below)
-        const float w_sum = uin.old.y + uin.w_new;                              // sdf.cpp:289-292
-        const float d_out = (uin.old.y * uin.old.x + uin.w_new * uin.d_new) / w_sum;
-        float4 c_out = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (COLOR) {                                                            // sdf.cpp:294-304
-            const float wc = uin.wc;
-            const float pr = (float)(int)(uin.rgb & 255u), pg = (float)(int)((uin.rgb >> 8) & 255u),
-                        pb = (float)(int)((uin.rgb >> 16) & 255u);
-            const float4 c = uin.col;
-            const float cw_sum = c.x + wc;
-            c_out = make_float4(cw_sum, (c.x * c.y + wc * pr) / cw_sum, (c.x * c.z + wc * pg) / cw_sum,
-                                (c.x * c.w + wc * pb) / cw_sum);
-        }
-        // the item of S3 (j - 1 - DEPTH): its row decides owned / halo, its code gives the address of its segment
-        const int j3 = j - 1 - TSDF_INTEGRATE_DEPTH;
-        const unsigned code3 = __builtin_amdgcn_readlane(code_v, (j3 >= 0 && j3 < cnt) ? j3 : 0);
-        const long long row3 = (long long)(code3 >> 6);
-        const bool owned3 = row3 >= own_row0 && row3 < own_row1;                 // wave-uniform; rows of the owned x layers
-        long long base3 = row3 * m + (long long)(code3 & 63u) * 64;
-#if TSDF_INTEGRATE_DEBUG
-        if (p.debug & 1024) base3 = (long long)(blockIdx.x & 255) * 4096 + wv * 64;   // timing experiment only: stores to a cache-resident region
-#endif
-        n_own += (uin.live && owned3) ? 1u : 0u;
-        n_halo += (uin.live && !owned3) ? 1u : 0u;
+    };
+    auto stage2 = [&](const GatherState& gin /*item j-1, record arrived*/, UpdateState& u /*out: item j-1*/) {
         // ---------------- S2(j-1): distance + weight from the pixel record; request {D,W} (+ colour)
-        bool need_cos;
-        float4 Nrec;
         {
-            float4* stage = s_pieces[wv];
-            stage[lane] = gin.P;
-            stage[64 + lane] = gin.N;
+            u32x4* stage = s_pieces[wv];
+            stage[lane] = gin.A;
+            stage[64 + lane] = gin.B;
             // other LANES read what this lane wrote: the compiler's memory model is per thread, so without a
             // wavefront-scope fence it may (and did) hoist the reads above the second write.  No instruction is
             // emitted: LDS operations of one wave execute in order.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float4 P = stage[2 * lane + 0];             // own record: {Px,Py,Pz,rgb}
-            const float4 N = stage[2 * lane + 1];             //             {Nx,Ny,Nz,(float)cosine}
-            Nrec = N;
+            const u32x4 P = stage[2 * lane + 0];              // own record: {Px,Py,Pz,rgb}
+            const u32x4 N = stage[2 * lane + 1];              //             {Nx,Ny,Nz,(float)cosine}
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads above stay before the next step's writes
             __builtin_amdgcn_wave_barrier();
-            bool ok = gin.live && !(is_nan(P.x) || is_nan(P.y) || is_nan(N.x) || is_nan(N.y) || is_nan(N.z));  // sdf.cpp:260
+            const float Px = __uint_as_float(P.x), Py = __uint_as_float(P.y), Pz = __uint_as_float(P.z);
+            const float Nx = __uint_as_float(N.x), Ny = __uint_as_float(N.y), Nz = __uint_as_float(N.z);
+            // sdf.cpp:260: NaN in P.x, P.y or the normal
+            const unsigned long long nanm = lanes(__builtin_isunordered(Px, Py)) | lanes(__builtin_isunordered(Nx, Ny)) | lanes(is_nan(Nz));
             // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
-            const double dx = (double)P.x - gin.pcx, dy = (double)P.y - gin.pcy, dz = (double)P.z - gin.pcz;
-            const double p2p = dx * (double)N.x + (dy * (double)N.y + dz * (double)N.z);
+            const double dx = (double)Px - gin.pcx, dy = (double)Py - gin.pcy, dz = (double)Pz - gin.pcz;
+            const double p2p = dx * (double)Nx + (dy * (double)Ny + dz * (double)Nz);
             float d = (float)p2p;                                               // sdf.cpp:274
-            ok = ok && !(d > delta);                                            // sdf.cpp:280-283
-            const bool band = ok && d >= eps && d <= delta;                     // sdf.cpp:277-279
-            const float a = d - eps;
-            const double xarg = (-0.5 * (double)a) * (double)a;
+            unsigned long long okm = gin.live & ~nanm & ~lanes(d > delta);   // sdf.cpp:280-283
+            const unsigned long long bandm = okm & lanes(d >= eps);          // sdf.cpp:277-279 (d <= delta holds in okm)
             float wn = 1.0f;
-            if (EXPPOLY) {
-                wn = band ? (float)exp_taylor10(band ? xarg : 0.0) : 1.0f;
-            } else {
-                if (band) wn = (float)exp(xarg);
+            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  For w_new == 1 that is the pre-rounded cosine of the record;
+            // the lanes of the exp() band fetch the pixel's f64 cosine here and stage 3 forms the product.
+            if (COLOR) u.C = __builtin_amdgcn_raw_buffer_load_b64(cos_rsrc, (int)select_by_mask(bandm, gin.roff >> 2, dropped), 0, 0);
+            if (bandm != 0ull) {
+                const float a = d - eps;
+                const double xarg = (-0.5 * (double)a) * (double)a;
+                float e;
+                if (EXPPOLY) e = (float)exp_taylor8(xarg);                      // (lanes outside the band compute garbage, dropped below)
+                else e = (float)exp(xarg);
+                wn = __uint_as_float(select_by_mask(bandm, __float_as_uint(e), 0x3f800000u));
             }
-            if (d < -delta) d = -delta;                                         // sdf.cpp:285-287
+            d = d < neg_delta ? neg_delta : d;                                  // sdf.cpp:285-287
 #if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 2) ok = false;                                        // timing experiment only: no volume RMW
+            if (p.debug & 2) okm = 0ull;                                        // timing experiment only: no volume RMW
 #endif
-            u.d_new = d; u.w_new = wn; u.rgb = __float_as_uint(P.w);
-            u.live = ok;
-            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  w_new == 1 (every voxel in front of the surface)
-            // makes it the pre-rounded cosine of the record; the exp() band recomputes the f64 product (rare path).
-            u.wc = N.w;
-            need_cos = COLOR && ok && wn != 1.0f;
-        }
-        if (need_cos) u.wc = (float)((double)u.w_new * pixel_cosine(Nrec.x, Nrec.y, Nrec.z));
-        // ---------------- memory: volume reads of item j-1, stores of item j-1-DEPTH
-        {
-            // Dead lanes re-read the voxel of the item's first live lane (a line that is being fetched anyway); an
-            // item without a live lane reads the first voxel of the slab (cache-resident): no traffic is added and the
-            // loads stay unconditional, so hipcc keeps the counted s_waitcnt of the pipelined loop.
-            const int j2 = j - 1;
-            const unsigned code2 = __builtin_amdgcn_readlane(code_v, (j2 >= 0 && j2 < cnt) ? j2 : 0);
-            const unsigned long long live2 = __ballot(u.live);
-            const long long base2 = live2 ? (long long)(code2 >> 6) * m + (long long)(code2 & 63u) * 64 : 0ll;
-            const int first2 = live2 ? (int)__ffsll((long long)live2) - 1 : 0;
-            int sel = u.live ? lane : first2;
+            u.d_new = d; u.w_new = wn; u.wc = __uint_as_float(N.w); u.rgb = P.w;
+            u.live = okm; u.band = bandm;
+            const unsigned code2 = gin.code;
+            u.code = code2;
+            long long base2 = (long long)(code2 >> 6) * m + (long long)(code2 & 63u) * 64;
 #if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 64) sel = lane;                   // timing experiment only (with base 0 below): cache-resident volume reads
+            if (p.debug & 64) base2 = 0;                                        // timing experiment only: cache-resident volume reads
 #endif
-            const float2* __restrict__ dwb = dw + ((TSDF_INTEGRATE_DEBUG && (p.debug & 64)) ? 0ll : base2);
-#if TSDF_INTEGRATE_NT_DW
-            {
-                typedef float nt_f2 __attribute__((ext_vector_type(2)));
-                const nt_f2 o2 = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(dwb) + sel);
-                u.old = make_float2(o2.x, o2.y);
-            }
-#else
-            u.old = dwb[sel];                                    // {D,W}: the tracker re-reads these lines -> keep them cached
-#endif
-#if TSDF_INTEGRATE_NT
+            u.off8 = select_by_mask(okm, lane8, dropped);
+            const __amdgpu_buffer_rsrc_t seg_dw = __builtin_amdgcn_make_buffer_rsrc(dw + base2, 0, 64 * (int)sizeof(float2), kRsrcWord3);
+            u.old = __builtin_amdgcn_raw_buffer_load_b64(seg_dw, (int)u.off8, 0, 0);   // {D,W}: the tracker re-reads these lines -> keep them cached
             if (COLOR) {   // colour is streamed once per frame and never read by the tracker: non-temporal
-                typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                const nt_f4 c4 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(crgb + ((TSDF_INTEGRATE_DEBUG && (p.debug & 64)) ? 0ll : base2)) + sel);
-                u.col = make_float4(c4.x, c4.y, c4.z, c4.w);
-            }
-#else
-            if (COLOR) u.col = (crgb + base2)[sel];
-#endif
-        }
-        // Stores of item j-1-DEPTH.  `if (live) store`: hipcc wraps the stores and the arithmetic feeding them in a branch
-        // over EXEC == 0, so the number of memory operations in flight depends on the path and every counted
-        // s_waitcnt vmcnt(N) behind the join is computed for the path WITHOUT the two stores -- two too small whenever
-        // they were issued: the wait for the pixel record of the next item then also waits for the two volume reads
-        // issued at the end of the previous step.  TSDF_INTEGRATE_BUFFER_STORES=1 issues the stores unconditionally
-        // instead (buffer stores whose dead lanes carry an out-of-range offset that the bounds check of the item's
-        // 512-byte / 1 KiB segment descriptor drops): the counted waits become exact (vmcnt(7) / (6) for the record,
-        // vmcnt(4) for the volume data) -- and the launch got 2.4 us SLOWER (134.6 against 132.3 us, same box, three
-        // runs each; bit-identical results), also with two or three items of volume reads in flight.  The exposed
-        // latency was not what the kernel waits for; the branch at least skips the divisions of items without a live lane.
-        bool do_store = uin.live;
-        bool st_dw = true, st_col = true;
-#if TSDF_INTEGRATE_DEBUG
-        // timing experiments only: 32 no stores, 128 no {D,W} store, 256 no colour store, 512 every lane of a listed item stores
-        if (p.debug & 32) do_store = false;
-        if (p.debug & 512) do_store = j3 >= 0 && j3 < cnt;
-        st_dw = !(p.debug & 128); st_col = !(p.debug & 256);
-#endif
-#if !TSDF_INTEGRATE_BUFFER_STORES
-        if (do_store) {
-            if (st_dw) (dw + base3)[lane] = make_float2(d_out, w_sum);
-            if (COLOR && st_col) {
-                typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                nt_f4 c4; c4.x = c_out.x; c4.y = c_out.y; c4.z = c_out.z; c4.w = c_out.w;
-                __builtin_nontemporal_store(c4, reinterpret_cast<nt_f4*>(crgb + base3) + lane);
+                const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base2, 0, 64 * (int)sizeof(float4), kRsrcWord3);
+                u.col = __builtin_amdgcn_raw_buffer_load_b128(seg_c, (int)(u.off8 << 1), 0, 2);
             }
         }
-#else
+    };
+    auto stage3 = [&](const UpdateState& uin /*item j-1-DEPTH, volume data arrived*/) {
+        // ---------------- S3(j-1-DEPTH): running averages + stores
         {
-            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            constexpr int kDropped = 0x7fffffff;                       // beyond every segment: the lane stores nothing
-            constexpr int kRsrcWord3 = 0x00020000;                     // raw buffer, 32-bit data format (gfx9 family)
+            const unsigned code3 = uin.code;
+            const unsigned row3 = code3 >> 6;
+            const bool owned3 = row3 >= own_row0 && row3 < own_row1;            // wave-uniform; rows of the owned x layers
+            long long base3 = (long long)row3 * m + (long long)(code3 & 63u) * 64;
+#if TSDF_INTEGRATE_DEBUG
+            if (p.debug & 1024) base3 = (long long)(blockIdx.x & 255) * 4096 + wv * 64;   // timing experiment only: stores to a cache-resident region
+#endif
+            const unsigned n_live = (unsigned)__popcll(uin.live);
+            n_own += owned3 ? n_live : 0u;
+            n_halo += owned3 ? 0u : n_live;
+            // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
+            const float W = __uint_as_float(uin.old.y), D = __uint_as_float(uin.old.x);
+            const float cx = __uint_as_float(uin.col.x);
+            float wc = uin.wc;
+            if (COLOR && uin.band != 0ull) {
+                const double cosd = __hiloint2double((int)uin.C.y, (int)uin.C.x);
+                wc = __uint_as_float(select_by_mask(uin.band, __float_as_uint((float)((double)uin.w_new * cosd)), __float_as_uint(wc)));
+            }
+            v2f sum1, num1, num2 = v2f{0.f, 0.f};
+            sum1.x = W + uin.w_new;
+            num1.x = W * D + uin.w_new * uin.d_new;
+            if (COLOR) {
+                const float pr = (float)(uin.rgb & 255u), pg = (float)((uin.rgb >> 8) & 255u), pb = (float)((uin.rgb >> 16) & 255u);
+                sum1.y = cx + wc;
+                num1.y = cx * __uint_as_float(uin.col.y) + wc * pr;
+                num2 = v2f{cx, cx} * v2f{__uint_as_float(uin.col.z), __uint_as_float(uin.col.w)} + v2f{wc, wc} * v2f{pg, pb};
+            } else {
+                sum1.y = 1.0f; num1.y = 0.0f;
+            }
+            // Correctly rounded n / b: hipcc's own sequence for `/` (v_rcp_f32, two Newton FMAs, quotient, two residual
+            // corrections) WITHOUT its v_div_scale / v_div_fixup wrappers, two quotients per packed instruction.  The
+            // wrappers only act when b, 1/b, n/b or the residuals leave the normal range; with b = W + w in
+            // [0.25, 2^64), 0 <= Color_W < 2^64 and every numerator zero or at least 2^-100 in magnitude none of that can happen
+            // (|quotients| stay within [2^-164, 2^128)... checked per lane below; a wavefront with a lane outside
+            // the proven range divides with `/`.
+            v2f q1, q2 = v2f{0.f, 0.f};
+            {
+                v2f r = v2f{__builtin_amdgcn_rcpf(sum1.x), __builtin_amdgcn_rcpf(sum1.y)};
+                const v2f one = v2f{1.0f, 1.0f};
+                r = __builtin_elementwise_fma(__builtin_elementwise_fma(-sum1, r, one), r, r);
+                q1 = num1 * r;
+                q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-sum1, q1, num1), r, q1);
+                q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-sum1, q1, num1), r, q1);
+                if (COLOR) {
+                    const v2f rc = v2f{r.y, r.y}, bc = v2f{sum1.y, sum1.y};
+                    q2 = num2 * rc;
+                    q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(-bc, q2, num2), rc, q2);
+                    q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(-bc, q2, num2), rc, q2);
+                }
+            }
+            {
+                // range guard.  Numerators: n * 2^-26 is subnormal exactly for 0 < |n| < 2^-100 (zero stays zero).
+                // State words as integers: 0 <= x < 2^64 <=> bits(x) < bits(2^64) (negative, inf, NaN are larger).
+                const v2f t1 = num1 * v2f{0x1p-26f, 0x1p-26f};
+                unsigned long long bad = lanes_subnormal(t1.x) | lanes(uin.old.y >= 0x5f800000u);
+                if (COLOR) {
+                    const v2f t2 = num2 * v2f{0x1p-26f, 0x1p-26f};
+                    bad |= lanes_subnormal(t1.y) | lanes_subnormal(t2.x) | lanes_subnormal(t2.y) | lanes(uin.col.x >= 0x5f800000u);
+                }
+                if (__builtin_expect((bad & uin.live) != 0ull, 0)) {
+                    q1.x = num1.x / sum1.x;
+                    if (COLOR) { q1.y = num1.y / sum1.y; q2.x = num2.x / sum1.y; q2.y = num2.y / sum1.y; }
+                }
+            }
             const __amdgpu_buffer_rsrc_t seg_dw = __builtin_amdgcn_make_buffer_rsrc(dw + base3, 0, 64 * (int)sizeof(float2), kRsrcWord3);
-            u32x2 o2; o2.x = __float_as_uint(d_out); o2.y = __float_as_uint(w_sum);
-            __builtin_amdgcn_raw_buffer_store_b64(o2, seg_dw, (do_store && st_dw) ? lane * (int)sizeof(float2) : kDropped, 0,
-                                                  TSDF_INTEGRATE_NT_DW ? 2 : 0);
+            u32x2 o2; o2.x = __float_as_uint(q1.x); o2.y = __float_as_uint(sum1.x);
+            unsigned off8 = uin.off8;
+#if TSDF_INTEGRATE_DEBUG
+            if (p.debug & 32) off8 = dropped;                                   // timing experiment only: no stores
+#endif
+            __builtin_amdgcn_raw_buffer_store_b64(o2, seg_dw, (int)off8, 0, 0);
             if (COLOR) {
                 const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base3, 0, 64 * (int)sizeof(float4), kRsrcWord3);
-                u32x4 c4; c4.x = __float_as_uint(c_out.x); c4.y = __float_as_uint(c_out.y); c4.z = __float_as_uint(c_out.z); c4.w = __float_as_uint(c_out.w);
-                __builtin_amdgcn_raw_buffer_store_b128(c4, seg_c, (do_store && st_col) ? lane * (int)sizeof(float4) : kDropped, 0,
-                                                       TSDF_INTEGRATE_NT ? 2 : 0);   // aux 2 = nt: colour is streamed
+                u32x4 c4; c4.x = __float_as_uint(sum1.y); c4.y = __float_as_uint(q1.y); c4.z = __float_as_uint(q2.x); c4.w = __float_as_uint(q2.y);
+                __builtin_amdgcn_raw_buffer_store_b128(c4, seg_c, (int)(off8 << 1), 0, 2);   // dropped stays out of range; aux 2 = nt: colour is streamed
             }
         }
+    };
+    auto step = [&](int j, GatherState& g, const GatherState& gin, UpdateState& u, const UpdateState& uin) {
+#if TSDF_INTEGRATE_ORDER == 132
+        stage1(j, g); stage3(uin); stage2(gin, u);
+#elif TSDF_INTEGRATE_ORDER == 213
+        stage2(gin, u); stage1(j, g); stage3(uin);
+#else
+        stage1(j, g); stage2(gin, u); stage3(uin);
 #endif
     };
 
-    for (unsigned blk = wg_first; blk < wg_last; blk += 64u * NW) {
-        // this wavefront's items of the round: blk + wv, blk + wv + NW, ... (at most 64)
-        const unsigned left = wg_last - blk;
-        cnt = left > (unsigned)wv ? (int)((left - (unsigned)wv + NW - 1u) / NW) : 0;
-        cnt = cnt > 64 ? 64 : cnt;
-        // lane l fetches the wavefront's l-th item and its row constants: one round of memory latency per 64 items;
-        // the stages broadcast them with v_readlane (no further scalar/vector loads per item)
-        code_v = 0; s0_v = s1_v = s2_v = 0.0;
-        if (lane < cnt) {
-            code_v = list[blk + (unsigned)wv + NW * (unsigned)lane];
-            // the row's share of rot_inv * g: its first two terms in Eigen's order ((r0*gx + r1*gy) + r2*gz), the same
-            // for every k of the row (get_global_coordinates, sdf.h:153-157: (extent/(float)m) * (i + 0.5) + origin)
-            const int r = (int)(code_v >> 6);
-            int il, jr;
-            if (tl.log2m >= 0) { il = r >> tl.log2m; jr = r & (m - 1); }
-            else { il = r / m; jr = r - il * m; }
-            const double gx = (double)p.g.cell_w * ((double)(il + p.g.xs) + 0.5) + p.g.origin[0];
-            const double gy = (double)p.g.cell_h * ((double)jr + 0.5) + p.g.origin[1];
-            s0_v = p.rot_inv[0] * gx + p.rot_inv[1] * gy;
-            s1_v = p.rot_inv[3] * gx + p.rot_inv[4] * gy;
-            s2_v = p.rot_inv[6] * gx + p.rot_inv[7] * gy;
-        }
-        // Wait for them HERE (vmcnt(0) only): otherwise hipcc puts a vmcnt(0) at their first use inside the
-        // pipelined loop, where it would drain the pipeline on every step.
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        // Software pipeline over the items of this block, unrolled over one full rotation of the state registers so
-        // that in-flight registers never have to be copied (a copy would force the wait):
-        //   step j:  S1(j) request pixel record | S2(j-1) request {D,W}/colour | S3(j-1-DEPTH) average + store
-        // DEPTH = steps between the volume request of an item and its use: DEPTH + 1 update states rotate, i.e.
-        // DEPTH items' worth of HBM reads (1.5 KB each) stay in flight per wavefront.  Measured at 512^3: DEPTH 1 / 2 /
-        // 3 = 138.5 / 138.1 / 140.4 us per launch (119 / 127 VGPRs for 2 / 3, still 4 waves per SIMD) -- the launch is
-        // not bound by bytes in flight but by L1 transactions and f64 issue per item; 1 it stays.
-        constexpr int NU = TSDF_INTEGRATE_DEPTH + 1, NG = 2;
-        constexpr int PERIOD = (NU % 2 == 0) ? NU : 2 * NU;
-        GatherState G[NG];
-        UpdateState U[NU];
+    // Software pipeline over the wavefront's items, unrolled over one full rotation of the state registers so
+    // that in-flight registers never have to be copied (a copy would force the wait):
+    //   step j:  S1(j) request pixel record | S2(j-1) request {D,W}/colour | S3(j-1-DEPTH) average + store
+    // DEPTH = steps between the volume request of an item and its use: DEPTH + 1 update states rotate, i.e.
+    // DEPTH items' worth of HBM reads (1.5 KB each) stay in flight per wavefront.
+    constexpr int NU = TSDF_INTEGRATE_DEPTH + 1, NG = 2;
+    constexpr int PERIOD = (NU % 2 == 0) ? NU : 2 * NU;
+    GatherState G[NG];
+    UpdateState U[NU];
 #pragma unroll
-        for (int q = 0; q < NG; ++q) {
-            G[q].live = false;
-            G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
-            G[q].P = make_float4(0.f, 0.f, 0.f, 0.f); G[q].N = G[q].P;
-        }
-#pragma unroll
-        for (int q = 0; q < NU; ++q) {
-            U[q].live = false;
-            U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].wc = 0.f; U[q].rgb = 0u;
-            U[q].old = make_float2(0.f, 1.f); U[q].col = make_float4(1.f, 0.f, 0.f, 0.f);
-        }
-        for (int j = 0; j < cnt + 1 + TSDF_INTEGRATE_DEPTH; j += PERIOD) {
-#pragma unroll
-            for (int q = 0; q < PERIOD; ++q)
-                // S1(j+q) -> G[q%2];  S2(j+q-1): G[(q+1)%2] -> U[q%NU];  S3(j+q-1-DEPTH): U[(q+1)%NU] (the oldest)
-                step(j + q, G[q % NG], G[(q + 1) % NG], U[q % NU], U[(q + 1) % NU]);
-        }
-        // (steps run up to j >= cnt + DEPTH, so S3 has retired item cnt-1 inside the loop: nothing to drain)
+    for (int q = 0; q < NG; ++q) {
+        G[q].live = 0ull; G[q].code = 0u;
+        G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
+        G[q].A = u32x4{0u, 0u, 0u, 0u}; G[q].B = G[q].A; G[q].roff = kDroppedOffset;
     }
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        U[q].live = 0ull; U[q].band = 0ull; U[q].code = 0u; U[q].C = u32x2{0u, 0u};
+        U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].wc = 0.f; U[q].rgb = 0u; U[q].off8 = kDroppedOffset;
+        U[q].old = u32x2{0u, 0x3f800000u}; U[q].col = u32x4{0x3f800000u, 0u, 0u, 0u};
+    }
+    for (int j = 0; j < cnt + 1 + TSDF_INTEGRATE_DEPTH; j += PERIOD) {
+#pragma unroll
+        for (int q = 0; q < PERIOD; ++q)
+            // S1(j+q) -> G[q%2];  S2(j+q-1): G[(q+1)%2] -> U[q%NU];  S3(j+q-1-DEPTH): U[(q+1)%NU] (the oldest)
+            step(j + q, G[q % NG], G[(q + 1) % NG], U[q % NU], U[(q + 1) % NU]);
+    }
+    // (steps run up to j >= cnt + DEPTH, so S3 has retired item cnt-1 inside the loop: nothing to drain)
 
-    // Update counts: wave shuffle, LDS across the waves, then the workgroup adds to ITS OWN pair of cumulative words
-    // (plain read-modify-write, nobody else touches them; the host adds the pairs up when somebody asks).  A thousand
-    // workgroups finishing together with an atomic on one shared word each were a serial tail of the launch.
-#if TSDF_INTEGRATE_DEBUG
-    if ((p.debug & 2048) && (blockIdx.x % 251) == 0 && tid == 0) {   // shader clock during the launch: cycles per 100 MHz tick
-        const unsigned long long dc = __builtin_readcyclecounter() - dbg_c0, dr = __builtin_amdgcn_s_memrealtime() - dbg_r0;
-        printf("integrate wg %u: %llu cycles in %llu ticks of 10 ns = %.0f MHz\n", blockIdx.x, dc, dr, dr ? 100.0 * (double)dc / (double)dr : 0.0);
-    }
-#endif
+    // Update counts (wave-uniform already): LDS across the waves, then the workgroup adds to ITS OWN pair of cumulative
+    // words (plain read-modify-write, nobody else touches them; the host adds the pairs up when somebody asks).
     __shared__ unsigned s_cnt[2][kIntegrateBlock / 64];
-    for (int off = 32; off > 0; off >>= 1) {
-        n_own += __shfl_xor(n_own, off);
-        n_halo += __shfl_xor(n_halo, off);
-    }
     if (lane == 0) { s_cnt[0][tid >> 6] = n_own; s_cnt[1][tid >> 6] = n_halo; }
     __syncthreads();
     if (tid == 0) {
@@ -675,21 +787,18 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         for (int q = 0; q < kIntegrateBlock / 64; ++q) { a += s_cnt[0][q]; b += s_cnt[1][q]; }
         if (a) counters[2 * blockIdx.x + 0] += (unsigned long long)a;
         if (b) counters[2 * blockIdx.x + 1] += (unsigned long long)b;
-#if TSDF_INTEGRATE_DEBUG
-        // load-balance experiment: the halo word accumulates the workgroup's running time (10 ns ticks) instead
-        if (p.debug & 4096) counters[2 * blockIdx.x + 1] += (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
-#endif
     }
 }
 
 size_t integrate_worklist_entries(const Grid& g) {
     return (size_t)(g.xe - g.xs) * g.m * ((g.m + 63) / 64);
 }
+size_t integrate_worklist_bytes(const Grid& g) { return (integrate_worklist_entries(g) + 8) * sizeof(ItemDesc); }   // + slack: idle wavefronts read one descriptor past their share
 size_t integrate_row_entries(const Grid& g) { return (size_t)(g.xe - g.xs) * g.m; }
 
 int integrate_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true, true>, kIntegrateBlock, 0) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true, true, true>, kIntegrateBlock, 512 * 24) != hipSuccess || n < 1)
         n = TSDF_INTEGRATE_MIN_WAVES;
     return n;
 }
@@ -698,7 +807,7 @@ size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords; }
 
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            unsigned* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
+                            void* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
                             unsigned launch_parity, unsigned long long* wg_counts) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
@@ -710,27 +819,36 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     tl.clip = (p.K[6] == 0.0 && p.K[7] == 0.0 && p.K[8] > 0.0) ? 1 : 0;
     tl.k_std = (p.K[1] == 0.0 && p.K[3] == 0.0 && p.K[6] == 0.0 && p.K[7] == 0.0 && p.K[8] == 1.0) ? 1 : 0;
     if (p.debug & 4) tl.k_std = 0;
+    // the fixed-point quotients need (dim + 1) << 20 in 32 bits and K * 2^20 finite; anything else divides
+    tl.fastq = (p.width <= kMaxFastDim && p.height <= kMaxFastDim) ? 1 : 0;
+    for (int a = 0; a < 6; ++a) if (!(fabs(p.K[a]) < 1.0e200)) tl.fastq = 0;
+    if (p.debug & 8) tl.fastq = 0;
     if (tl.n_rows >= (1ll << 26)) return hipErrorInvalidValue;       // row index must fit the 26-bit item code
     // two bookkeeping sets used alternately (see kBinSetWords)
     unsigned* const cur = work_count + (launch_parity & 1) * kBinSetWords;
     unsigned* const nxt = work_count + ((launch_parity + 1) & 1) * kBinSetWords;
+    ItemDesc* const list = static_cast<ItemDesc*>(worklist);
     hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
     clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(tl.n_rows, rowinfo, cur, worklist, counters);
+    scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, list, counters);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 1/16
+    // weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 0.04
     const double span = (double)p.g.delta - (double)p.g.epsilon;
-    const bool exp_poly = span >= 0.0 && 0.5 * span * span <= 0.0625;
-#define TSDF_LAUNCH_INTEGRATE(C, KS, EP) \
-    integrate_kernel<C, KS, EP><<<dim3(n_blocks), dim3(kIntegrateBlock), 0, s>>>(p, tl, worklist, cur, dw, crgb, pn, wg_counts)
-#define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE(C, KS, true); else TSDF_LAUNCH_INTEGRATE(C, KS, false); } while (0)
+    const bool exp_poly = span >= 0.0 && 0.5 * span * span <= 0.04;
+    const bool ktab = m <= 1024;                                       // 24 bytes of LDS per k
+    const size_t lds = ktab ? (size_t)m * 24 : 0;
+#define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) \
+    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, dw, crgb, pn, wg_counts)
+#define TSDF_LAUNCH_INTEGRATE3(C, KS, EP) do { if (ktab) TSDF_LAUNCH_INTEGRATE(C, KS, EP, true); else TSDF_LAUNCH_INTEGRATE(C, KS, EP, false); } while (0)
+#define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE3(C, KS, true); else TSDF_LAUNCH_INTEGRATE3(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
     else { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(false, true); else TSDF_LAUNCH_INTEGRATE2(false, false); }
 #undef TSDF_LAUNCH_INTEGRATE2
+#undef TSDF_LAUNCH_INTEGRATE3
 #undef TSDF_LAUNCH_INTEGRATE
     return hipGetLastError();
 }
