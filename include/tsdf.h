@@ -44,7 +44,9 @@
 extern "C" {
 #endif
 
-#define TSDF_ABI_VERSION 1
+/* 2: tsdf_config.carry_threads, tsdf_preproc_params.grid_filter (the struct layouts changed: a caller built against
+ * version 1 must be rebuilt; tsdf_abi_version() lets a loader refuse a mismatched library) */
+#define TSDF_ABI_VERSION 2
 
 typedef enum tsdf_status {
     TSDF_OK = 0,
@@ -73,6 +75,10 @@ typedef struct tsdf_config {
     float   w_h;                /* rotation step, radians                (0.01)                          */
     int32_t pixel_stride;       /* tracker sampling stride               camera_tracking.cpp:162-163 (3) */
     int32_t stale_carry;        /* 1 = reproduce the carry-over of camera_tracking.cpp:156-159,261-268   */
+    int32_t carry_threads;      /* the OpenMP thread count of the reference run to reproduce (>= 1): the  */
+                                /* carry state is thread-local and resets at the first sample of each of  */
+                                /* the static-schedule column chunks (camera_tracking.cpp:72-76,146-162); */
+                                /* 1 = one thread visits every column (the canonical order)               */
     int32_t with_color;         /* 1 = also keep Color_W,R,G,B           sdf.cpp:294-304                 */
     /* placement: which part of the volume this handle owns, and where it lives */
     int32_t slab_x0, slab_x1;   /* owned x range [x0,x1); 0,m (or 0,0) = whole volume                    */

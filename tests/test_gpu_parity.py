@@ -163,6 +163,69 @@ def test_accumulate_stale_carry_with_out_of_grid_samples():
     assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
 
 
+CARRY_THREADS = [1, 2, 3, 8, 16]
+
+
+@pytest.mark.parametrize("threads", CARRY_THREADS)
+def test_accumulate_reproduces_the_reference_at_its_thread_count(threads):
+    """camera_tracking.cpp:72-76,146-162: the carry state is thread-local and starts fresh in every OpenMP thread's column
+    chunk, so the real binary on an n-core host produces the np = n sums.  tsdf_config.carry_threads reproduces them
+    (oracle: real OpenMP threads, static schedule): identical counts, A and b to 1e-11."""
+    m = 48
+    vol = dict(width=2.4, height=2.4, depth=2.4, origin=(-1.2, -3.0, -0.2), delta=0.3, epsilon=0.025)
+    seq, fr = frames(3, holes=0.03, width=320, height=240)
+    oo, ot = make_oracle(m, seq.K, vol)
+    go, gt = make_gpu(m, seq.K, vol, carry_threads=threads)
+    for k in range(2):
+        xyz, nrm, rgb = fr[k]
+        ot.set_camera_transformation(seq.R[k], seq.t[k])
+        oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+    go.upload(oo.D, oo.W)
+    ot.set_camera_transformation(seq.R[2], seq.t[2])
+    gt.set_camera_transformation(seq.R[2], seq.t[2])
+    xyz = fr[2][0]
+    A_o, b_o, st_o = ot.accumulate(oo, orc.Cloud(xyz), threads=threads, stale_carry=True)
+    A_1, b_1, st_1 = ot.accumulate(oo, orc.Cloud(xyz), threads=1, stale_carry=True)
+    go.set_frame(xyz)
+    A_g, b_g, st_g = gt.accumulate()
+    if threads > 1:
+        assert st_o["n_terms"] < st_1["n_terms"]            # chunk starts really cut runs on this frame
+    assert st_g["n_terms"] == st_o["n_terms"] and st_g["n_oog"] == st_o["n_oog"] and st_g["n_ok"] == st_o["n_ok"]
+    assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
+
+
+@pytest.mark.parametrize("threads", [2, 3, 7, 16, 64])
+def test_long_out_of_grid_run_is_cut_at_chunk_starts(threads):
+    """The run of test_long_out_of_grid_run_spans_workgroups (one valid sample, 900 out-of-grid ones over 30 columns,
+    a valid one) under np threads: the run ends with the first thread's columns; a sample behind a chunk start without a
+    valid predecessor in its own chunk adds nothing."""
+    m = 32
+    vol = dict(width=3.2, height=3.2, depth=3.2, origin=(0.0, 0.0, 0.0), delta=0.3, epsilon=0.025)
+    K = scaled_K(64, 48)
+    oo, ot = make_oracle(m, K, vol)
+    oo.create_circle(1.0, 1.6, 1.6, 1.6)
+    go, gt = make_gpu(m, K, vol, carry_threads=threads)
+    go.upload(oo.D, oo.W)
+    eye, zero = np.eye(3), np.zeros(3)
+    ot.set_camera_transformation(eye, zero)
+    gt.set_camera_transformation(eye, zero)
+    ncol, nrow = 40, 30
+    xyz = np.full((3 * nrow - 2, 3 * ncol - 2, 3), np.nan, dtype=np.float32)
+    samp = np.full((ncol, nrow, 3), [-5.0, 1.0, 1.0], dtype=np.float32)      # all out of grid
+    samp[0, 5] = (1.7, 1.5, 1.4)
+    samp[0, 7] = (np.nan, 0, 0)
+    samp[13, 29] = (1.5, 1.6, 1.7)             # last sample of a column: its run starts in the next column
+    samp[30, 2] = (1.2, 1.9, 1.6)
+    for c in range(ncol):
+        for r in range(nrow):
+            xyz[3 * r, 3 * c] = samp[c, r]
+    A_o, b_o, st_o = ot.accumulate(oo, orc.Cloud(xyz), threads=threads, stale_carry=True)
+    go.set_frame(xyz)
+    A_g, b_g, st_g = gt.accumulate()
+    assert st_g["n_terms"] == st_o["n_terms"] and st_g["n_ok"] == st_o["n_ok"]
+    assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
+
+
 def test_long_out_of_grid_run_spans_workgroups():
     """One valid sample followed by > 3 workgroups' worth of out-of-grid samples, then a valid one."""
     m = 32

@@ -51,9 +51,11 @@ def main():
                     sdf.update(want_stats=False)
                 tm, cn = sdf.read_timing(), sdf.read_counters()
                 ms = tm["integrate_ms"] / tm["integrate_launches"]
+                cms = tm["color_ms"] / tm["color_launches"] if tm.get("color_launches") else 0.0
                 if rep > 0 and (best is None or ms < best[0]):
-                    best = (ms, cn["n_updated"] / tm["integrate_launches"], cn["integrate_items"] / tm["integrate_launches"])
+                    best = (ms, cn["n_updated"] / tm["integrate_launches"], cn["integrate_items"] / tm["integrate_launches"], cms)
             print(json.dumps({"scene": scene, "debug": v, "integrate_launch_us": round(best[0] * 1e3, 2),
+                              "color_sweep_us": round(best[3] * 1e3, 2),
                               "updated_per_launch": best[1], "items_per_launch": best[2]}), flush=True)
             del trk, sdf
 

@@ -38,7 +38,7 @@ class Config(C.Structure):
     _fields_ = [("m", C.c_int32), ("width", C.c_float), ("height", C.c_float), ("depth", C.c_float),
                 ("origin", C.c_double * 3), ("delta", C.c_float), ("epsilon", C.c_float),
                 ("gn_max_iter", C.c_int32), ("max_twist_diff", C.c_float), ("v_h", C.c_float), ("w_h", C.c_float),
-                ("pixel_stride", C.c_int32), ("stale_carry", C.c_int32), ("with_color", C.c_int32),
+                ("pixel_stride", C.c_int32), ("stale_carry", C.c_int32), ("carry_threads", C.c_int32), ("with_color", C.c_int32),
                 ("slab_x0", C.c_int32), ("slab_x1", C.c_int32), ("halo", C.c_int32), ("device", C.c_int32)]
 
 
@@ -272,13 +272,13 @@ class SDF:
 
     def __init__(self, m=256, width=6.0, height=6.0, depth=3.5, sdf_origin=(-3.0, -3.0, -0.5),
                  distance_delta=0.3, distance_epsilon=0.025, *, with_color=True, slab=None, halo=0,
-                 device=0, stale_carry=True, gn_max_iter=20, max_twist_diff=0.001, v_h=1.0, w_h=0.01,
+                 device=0, stale_carry=True, carry_threads=1, gn_max_iter=20, max_twist_diff=0.001, v_h=1.0, w_h=0.01,
                  pixel_stride=3):
         L = lib()
         cfg = default_config(m=int(m), width=float(width), height=float(height), depth=float(depth),
                              origin=sdf_origin, delta=float(distance_delta), epsilon=float(distance_epsilon),
                              with_color=1 if with_color else 0, halo=int(halo), device=int(device),
-                             stale_carry=1 if stale_carry else 0, gn_max_iter=int(gn_max_iter),
+                             stale_carry=1 if stale_carry else 0, carry_threads=int(carry_threads), gn_max_iter=int(gn_max_iter),
                              max_twist_diff=float(max_twist_diff), v_h=float(v_h), w_h=float(w_h),
                              pixel_stride=int(pixel_stride))
         if slab is not None:

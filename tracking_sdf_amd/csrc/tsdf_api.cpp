@@ -387,7 +387,7 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     int rc = timed_begin(h, 1, &ep, st);
     if (rc) return rc;
     HIP_TRY(h, launch_pack(st, xyz, nrm, rgb, h->fw, h->fh, h->cfg.pixel_stride, h->pix_su, h->pix_sv,
-                           h->pn_buf[nb], h->samples_buf[nb], h->ncols, h->nrows));
+                           h->pn_buf[nb], h->samples_buf[nb], h->ncols, h->nrows, h->cfg.with_color ? 1 : 0));
     rc = timed_end(h, ep, st);
     if (rc) return rc;
     if (side) {
@@ -411,6 +411,8 @@ void fill_track_params(const tsdf_handle* h, TrackParams& p) {
     p.wh2 = h->wh2;
     p.n_samples = h->n_samples;
     p.stale_carry = h->cfg.stale_carry;
+    p.carry_threads = h->cfg.carry_threads > 1 ? h->cfg.carry_threads : 1;
+    p.ncols = h->ncols; p.nrows = h->nrows;
 }
 
 constexpr size_t kVolumePadFront = 16;   // voxels of {0,0} padding in front of the volume (128 bytes)
@@ -627,6 +629,7 @@ void tsdf_default_config(tsdf_config* c) {
     c->gn_max_iter = 20; c->max_twist_diff = 0.001f; c->v_h = 1.0f; c->w_h = 0.01f;   // :88
     c->pixel_stride = 3;                                                   // camera_tracking.cpp:162-163
     c->stale_carry = 1;
+    c->carry_threads = 1;
     c->with_color = 1;
     c->slab_x0 = 0; c->slab_x1 = 0; c->halo = 0; c->device = 0;
 }

@@ -80,6 +80,8 @@ struct TrackParams {
     float wh2;               // 2 * w_h as a float product (camera_tracking.cpp:331)
     int32_t n_samples;
     int32_t stale_carry;
+    int32_t carry_threads;   // >= 1: OpenMP threads of the reference run whose carry resets are reproduced
+    int32_t ncols, nrows;    // sample grid: sample n = col * nrows + row (columns outer, camera_tracking.cpp:162-163)
 };
 
 // mesh extraction (mesh_kernels.hip): cubes with base voxel layer i in [ci0, ci1), j,k in [1, m-2]
@@ -96,7 +98,8 @@ enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntItems = 2, kNumCou
 hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0);
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
                        int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
-                       float4* pn, float4* samples, int32_t ncols, int32_t nrows);
+                       float4* pn, float4* samples, int32_t ncols, int32_t nrows,
+                       int32_t color_layout /* 1: 32-byte records + f64 cosine plane (volume with colour), 0: 24-byte {P,N} records */);
 // worklist: integrate_worklist_entries(g) unsigned; work_count: integrate_bookkeeping_words() unsigned, zero before the
 // first launch; rowinfo: one unsigned per row (integrate_row_entries(g)); n_blocks: persistent grid size (CUs x
 // integrate_blocks_per_cu()).

@@ -66,8 +66,9 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 }
 
 // ------------------------------------------------------------------------------------------------
-// frame packing.  Pixel record = 2 x float4: {Px,Py,Pz, rgb bits} {Nx,Ny,Nz, 0}.  One 32-byte
-// sector per projected voxel instead of three scattered plane reads.  Records are stored row-major
+// frame packing.  Per pixel one record {Px,Py,Pz, rgb bits} {Nx,Ny,Nz, (float)cosine} (32 bytes; 24 bytes {P,N} for a
+// volume without colour) + the f64 cosine in a plane behind the records (kPixelRecordBytes per pixel in all).  One record
+// per projected voxel instead of scattered plane reads.  Records are stored row-major
 // or column-major (pix_su / pix_sv), whichever makes the pixels hit by 64 consecutive k of one voxel
 // row neighbours in memory: a k-row projects to a near-vertical image line for an upright camera,
 // and with row-major records every lane of the gather then pulls its own 128-byte line through L2
@@ -77,7 +78,7 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz, const float* __restrict__ nrm,
                                                     const uint8_t* __restrict__ rgb, int width, int height,
                                                     int stride, int pix_su, int pix_sv, float4* __restrict__ pn,
-                                                    float4* __restrict__ samples, int ncols, int nrows) {
+                                                    float4* __restrict__ samples, int ncols, int nrows, int color_layout) {
     // 16 x 16 pixel tiles; consecutive threads follow the direction in which the records are contiguous, so a
     // wavefront writes four runs of 512 bytes whichever layout is chosen (the plane reads of a tile stay within
     // a few cache lines per image row either way)
@@ -94,13 +95,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
     unsigned c = 0;
     if (rgb) c = (unsigned)rgb[3 * pix + 0] | ((unsigned)rgb[3 * pix + 1] << 8) | ((unsigned)rgb[3 * pix + 2] << 16);
     const long long rec = (long long)col * pix_su + (long long)row * pix_sv;   // row- or column-major records
-    pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
-    // sdf.cpp:294: cosine = |cam_vect . n| / |n| depends on the pixel only.  Its f32 rounding rides in the
-    // record: for the common weight w_new == 1 the colour weight (float)(w_new * cosine) is exactly that.
-    const double cosine = pixel_cosine(nx, ny, nz);
-    pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)cosine);
-    // ... and its f64 value in a plane behind the records, for the voxels whose weight is not 1 (the exp() band)
-    reinterpret_cast<double*>(pn + 2 * (long long)width * height)[rec] = cosine;
+    if (color_layout) {
+        // with colour: 32-byte records {Px,Py,Pz, rgb bits} {Nx,Ny,Nz, (float)cosine}.  sdf.cpp:294: cosine =
+        // |cam_vect . n| / |n| depends on the pixel only; its f32 rounding rides in the record: for the common weight
+        // w_new == 1 the colour weight (float)(w_new * cosine) is exactly that ...
+        const double cosine = pixel_cosine(nx, ny, nz);
+        pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
+        pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)cosine);
+        // ... and its f64 value in a plane behind the records, for the voxels whose weight is not 1 (the exp() band)
+        reinterpret_cast<double*>(pn + 2 * (long long)width * height)[rec] = cosine;
+    } else {
+        // without colour: 24-byte records {Px,Py,Pz, Nx,Ny,Nz} (a quarter fewer cache lines per gathered pixel run)
+        float* const r6 = reinterpret_cast<float*>(pn) + rec * 6;
+        r6[0] = px; r6[1] = py; r6[2] = pz; r6[3] = nx; r6[4] = ny; r6[5] = nz;
+    }
     if (col % stride == 0 && row % stride == 0) {
         const int ci = col / stride, rj = row / stride;
         if (ci < ncols && rj < nrows) samples[ci * nrows + rj] = make_float4(px, py, pz, 0.0f);
@@ -109,10 +117,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
 
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
                        int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
-                       float4* pn, float4* samples, int32_t ncols, int32_t nrows) {
+                       float4* pn, float4* samples, int32_t ncols, int32_t nrows, int32_t color_layout) {
     const int tiles = ((width + 15) >> 4) * ((height + 15) >> 4);
     pack_kernel<<<dim3(tiles), dim3(256), 0, s>>>(xyz, nrm, rgb, width, height, stride, pix_su, pix_sv, pn,
-                                                   samples, ncols, nrows);
+                                                   samples, ncols, nrows, color_layout);
     return hipGetLastError();
 }
 
@@ -172,10 +180,14 @@ __device__ __forceinline__ void clip_affine(double a, double b, double& lo, doub
 // Work-list bookkeeping of one launch: [0] = number of items, [1 .. kBins] = items per image band, [kBins + 1 ..
 // 2 kBins] = scatter cursors.  Two such sets are used alternately: the clip kernel of a launch re-zeroes the set the
 // NEXT launch will use (nobody touches it during this launch), which saves a memset per frame.
-constexpr int kBins = 64;
+#ifndef TSDF_BANDS
+#define TSDF_BANDS 64
+#endif
+constexpr int kBins = TSDF_BANDS;
+static_assert(kBins >= 8 && kBins <= 4096 && (kBins & (kBins - 1)) == 0, "bands: a power of two that fits the row word");
 constexpr int kBinSetWords = 2 * kBins + 2;
 
-// rowinfo word: bit 31 = the row has items, bits 16..21 = band, bits 8..15 = number of chunks, bits 0..7 = first chunk
+// rowinfo word: bit 31 = the row has items, bits 16..27 = band, bits 8..15 = number of chunks, bits 0..7 = first chunk
 __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
                                                                 unsigned* __restrict__ rowinfo,
                                                                 unsigned* __restrict__ set,
@@ -183,9 +195,9 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
     const int m = p.g.m;
     const int tid = threadIdx.x;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
-    if (blockIdx.x == 0 && tid < kBinSetWords) next_set[tid] = 0u;
+    if (blockIdx.x == 0) for (int t = tid; t < kBinSetWords; t += kClipBlock) next_set[t] = 0u;
     __shared__ unsigned s_hist[kBins];
-    if (tid < kBins) s_hist[tid] = 0u;
+    for (int t = tid; t < kBins; t += kClipBlock) s_hist[t] = 0u;
     __syncthreads();
     int c0 = 0, n = 0, bin = 0;
     if (row < tl.n_rows) {
@@ -243,9 +255,9 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
     // only the band counters are touched here (no-return adds on up to 64 different words): a total that every
     // workgroup adds to is one hot word, and a thousand returning atomics on one word cost ~12 us by themselves;
     // the scatter pass gets the total out of its scan of the bands
-    if (tid < kBins) {
-        const unsigned hcnt = s_hist[tid];
-        if (hcnt) atomicAdd(&set[1 + tid], hcnt);
+    for (int t = tid; t < kBins; t += kClipBlock) {
+        const unsigned hcnt = s_hist[t];
+        if (hcnt) atomicAdd(&set[1 + t], hcnt);
     }
 }
 
@@ -268,32 +280,50 @@ __global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(IntegrateParam
                                                                    const unsigned* __restrict__ rowinfo,
                                                                    unsigned* __restrict__ set, ItemDesc* __restrict__ list,
                                                                    unsigned long long* __restrict__ counters) {
-    static_assert(kBins == 64, "one wavefront scans the bands");
     __shared__ unsigned s_start[kBins], s_wg[kBins], s_base[kBins];
+    __shared__ unsigned s_wave[kClipBlock / 64];
     const int tid = threadIdx.x;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
-    if (tid < kBins) {
-        const unsigned hcnt = set[1 + tid];
-        unsigned incl = hcnt;
+    {
+        // exclusive scan of the band counts: every thread takes BPT consecutive bands, the workgroup scans the thread sums
+        constexpr int BPT = (kBins + kClipBlock - 1) / kClipBlock;
+        unsigned cntb[BPT], tsum = 0u;
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const int bq = tid * BPT + q;
+            cntb[q] = bq < kBins ? set[1 + bq] : 0u;
+            tsum += cntb[q];
+        }
+        unsigned incl = tsum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned t = __shfl_up(incl, off);
-            if (tid >= off) incl += t;
+            if ((tid & 63) >= off) incl += t;
         }
-        s_start[tid] = incl - hcnt;
-        s_wg[tid] = 0u;
-        if (blockIdx.x == 0 && tid == kBins - 1) {          // the launch's item count, for integrate_kernel and the statistics
-            set[0] = incl;
-            if (incl) atomicAdd(&counters[kCntItems], (unsigned long long)incl);
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        unsigned before = 0u, total = 0u;
+#pragma unroll
+        for (int w = 0; w < kClipBlock / 64; ++w) { if (w < (tid >> 6)) before += s_wave[w]; total += s_wave[w]; }
+        unsigned run = before + incl - tsum;
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const int bq = tid * BPT + q;
+            if (bq < kBins) { s_start[bq] = run; s_wg[bq] = 0u; }
+            run += cntb[q];
+        }
+        if (blockIdx.x == 0 && tid == 0) {                  // the launch's item count, for integrate_kernel and the statistics
+            set[0] = total;
+            if (total) atomicAdd(&counters[kCntItems], (unsigned long long)total);
         }
     }
     __syncthreads();
     const unsigned info = row < tl.n_rows ? rowinfo[row] : 0u;
-    const unsigned n = (info >> 8) & 0xFFu, c0 = info & 0xFFu, bin = (info >> 16) & 0x3Fu;
+    const unsigned n = (info >> 8) & 0xFFu, c0 = info & 0xFFu, bin = (info >> 16) & 0xFFFu;
     unsigned rank = 0u;
     if (info) rank = atomicAdd(&s_wg[bin], n);
     __syncthreads();
-    if (tid < kBins) s_base[tid] = s_wg[tid] ? atomicAdd(&set[1 + kBins + tid], s_wg[tid]) : 0u;
+    for (int t = tid; t < kBins; t += kClipBlock) s_base[t] = s_wg[t] ? atomicAdd(&set[1 + kBins + t], s_wg[t]) : 0u;
     __syncthreads();
     if (info) {
         const int m = p.g.m;
@@ -363,6 +393,7 @@ __device__ __forceinline__ double exp_taylor8(double x) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kFixShift = 20;                        // pixel coordinates in 2^-20 units
@@ -370,6 +401,11 @@ constexpr unsigned kFixOne = 1u << kFixShift;
 constexpr int kMaxFastDim = 2047;                    // (dim + 1) << 20 must fit 32 bits
 constexpr unsigned kDroppedOffset = 0x7fffffffu;     // beyond every buffer: the lane loads zeros / stores nothing
 constexpr int kRsrcWord3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
+
+// Per-pixel data of a frame, written by pack_kernel into ONE buffer of kPixelRecordBytes per pixel (record index
+// rec = col*pix_su + row*pix_sv):  with colour  [0, 32 npix) records {Px,Py,Pz,rgb}{Nx,Ny,Nz,(float)cosine},
+// [32 npix, 40 npix) the cosine in f64;  without colour  [0, 24 npix) records {Px,Py,Pz,Nx,Ny,Nz}.
+static_assert(kPixelRecordBytes == 40, "pixel planes");
 
 // v_cvt_i32_f64 as the hardware does it (saturating, NaN -> 0); a C cast of an out-of-range value is undefined
 __device__ __forceinline__ int cvt_i32_f64_sat(double x) {
@@ -398,11 +434,143 @@ __device__ __forceinline__ unsigned select_by_mask(unsigned long long mask, unsi
     return r;
 }
 
+// What both integrate kernels need to turn an item into pixel indices: constants of the launch in registers.
+struct ProjConst {
+    double Ks[6];            // K rows 0 and 1 times 2^20 (exact): ij0, ij1 come out in 2^-20 pixel units
+    double K2[3];            // K row 2
+    double t[3];             // rot_inv_trans
+    double r2[3];            // rot_inv[2], [5], [8]   (only without the LDS table)
+    double oz, cd;
+    unsigned lim_u, lim_w;
+    unsigned su, sv;         // record index of pixel (col,row) = col*su + row*sv
+    unsigned last_chunk;
+    unsigned long long tail_mask;
+    unsigned tab_lane;       // lane * 24: byte offset of the lane's entry in a chunk of the k table
+    float width_f, height_f;
+    int width, height;
+    bool fastq;
+};
+
+__device__ __forceinline__ void make_proj_const(const IntegrateParams& p, const IntegrateTiling& tl, int lane, ProjConst& c) {
+    const double fix = (double)kFixOne;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) c.Ks[a] = p.K[a] * fix;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { c.K2[a] = p.K[6 + a]; c.t[a] = p.rot_inv_trans[a]; c.r2[a] = p.rot_inv[3 * a + 2]; }
+    c.oz = p.g.origin[2]; c.cd = (double)p.g.cell_d;
+    c.lim_u = ((unsigned)p.width + 1u) * kFixOne + 2u; c.lim_w = ((unsigned)p.height + 1u) * kFixOne + 2u;
+    c.su = (unsigned)p.pix_su; c.sv = (unsigned)p.pix_sv;
+    // lanes of the last chunk that lie inside the grid when m is not a multiple of 64 (scalar select per item)
+    c.last_chunk = (unsigned)(p.g.m - 1) >> 6;
+    c.tail_mask = (p.g.m & 63) ? ((1ull << (p.g.m & 63)) - 1ull) : ~0ull;
+    c.tab_lane = (unsigned)lane * 24u;
+    c.width = p.width; c.height = p.height;
+    c.fastq = tl.fastq != 0;
+}
+
+// the k table in LDS: {rot_inv[2], rot_inv[5], rot_inv[8]} * gz(k), k = 0..m-1 (the same for every voxel row)
+__device__ __forceinline__ void build_k_table(const IntegrateParams& p, double* s_tab, int tid, int nthreads) {
+    const double oz = p.g.origin[2], cd = (double)p.g.cell_d;
+    for (int k = tid; k < p.g.m; k += nthreads) {
+        // get_global_coordinates (sdf.h:153-157): (extent/(float)m) * (k + 0.5) + origin; third term of rot_inv * g
+        const double gz = cd * ((double)k + 0.5) + oz;
+        s_tab[3 * k + 0] = p.rot_inv[2] * gz;
+        s_tab[3 * k + 1] = p.rot_inv[5] * gz;
+        s_tab[3 * k + 2] = p.rot_inv[8] * gz;
+    }
+    __syncthreads();
+}
+
+// One item -> camera-frame voxel centres, the lanes that can be updated as far as geometry goes (sdf.cpp:244-256), and
+// the lanes' pixels as a BIASED record index pixb = (col+1)*su + (row+1)*sv (callers shift their plane bases).
+template <bool KSTD, bool KTAB>
+__device__ __forceinline__ void project_item(const ProjConst& c, const ItemDesc& ds, const double* s_tab, int lane,
+                                             double& pcx, double& pcy, double& pcz, unsigned long long& okm, unsigned& pixb) {
+    const unsigned chunk = ds.code & 63u;
+    double a0, a1, a2;
+    if (KTAB) {
+        const double* t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_tab) + (c.tab_lane + chunk * (64u * 24u)));
+        a0 = t[0]; a1 = t[1]; a2 = t[2];
+    } else {
+        const double gz = c.cd * ((double)((int)(chunk * 64u) + lane) + 0.5) + c.oz;
+        a0 = c.r2[0] * gz; a1 = c.r2[1] * gz; a2 = c.r2[2] * gz;
+    }
+    // get_global_coordinates (sdf.h:153-157) + project_world_to_camera (camera_tracking.cpp:51-54)
+    pcx = (ds.s0 + a0) + c.t[0];
+    pcy = (ds.s1 + a1) + c.t[1];
+    pcz = (ds.s2 + a2) + c.t[2];
+    okm = lanes(!(pcz < 0)) & (chunk == c.last_chunk ? c.tail_mask : ~0ull);              // sdf.cpp:247-249
+    // project_camera_to_image_plane, camera_tracking.cpp:40-47, rows 0 and 1 scaled by 2^20 (exact).  With
+    // K = [[fx,0,cx],[0,fy,cy],[0,0,1]] the dropped terms are +-0 products: (fx*x + 0*y) + cx*z == fx*x + cx*z
+    // and (0*x + 0*y) + 1*z == z bit for bit (up to the sign of a zero, which no later step can observe).
+    double ij0, ij1, ij2;
+    if (KSTD) {
+        ij0 = c.Ks[0] * pcx + c.Ks[2] * pcz;
+        ij1 = c.Ks[4] * pcy + c.Ks[5] * pcz;
+        ij2 = pcz;
+    } else {
+        ij0 = row3(&c.Ks[0], pcx, pcy, pcz);
+        ij1 = row3(&c.Ks[3], pcx, pcy, pcz);
+        ij2 = row3(&c.K2[0], pcx, pcy, pcz);
+    }
+    // (int)(ij0/ij2), (int)(ij1/ij2) and the range tests of sdf.cpp:250-256 without dividing: ij2's reciprocal
+    // from v_rcp_f32 (1 ulp) and one Newton step in f64 is good to 2^-43, so q = ij * rd is within
+    // |q| 2^-42 <= 2^-11 units (|q| < 2^31 units) of the true quotient, and so is the reference's rounded
+    // quotient (2^-53 relative).  A lane whose q lies within 2 units of a multiple of 2^20 (an integer pixel
+    // coordinate: truncation and both range tests switch only there), or whose ij2 is not a plain positive
+    // number, sends the wavefront through the reference's divisions.
+    const float zf = (float)ij2;
+    double rd = (double)__builtin_amdgcn_rcpf(zf);
+    rd = __builtin_fma(__builtin_fma(-ij2, rd, 1.0), rd, rd);
+    const unsigned tu = (unsigned)cvt_i32_f64_sat(ij0 * rd) + (kFixOne + 2u);
+    const unsigned tw = (unsigned)cvt_i32_f64_sat(ij1 * rd) + (kFixOne + 2u);
+    unsigned long long inrm = lanes(tu < c.lim_u) & lanes(tw < c.lim_w);
+    unsigned iu1 = max(tu >> kFixShift, 1u), iw1 = max(tw >> kFixShift, 1u);              // pixel column + 1, row + 1
+    const unsigned long long doubtm =
+        okm & (lanes(!(zf > 1.0e-6f)) | lanes(min(tu & (kFixOne - 1u), tw & (kFixOne - 1u)) < 5u));
+    if (__builtin_expect(!c.fastq || doubtm != 0ull, 0)) {
+        // rows 0 and 1 unscaled again (exact: powers of two), then the reference's divisions
+        const double unfix = 1.0 / (double)kFixOne;
+        const double uu = (ij0 * unfix) / ij2, ww = (ij1 * unfix) / ij2;
+        // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
+        // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
+        const bool inr = uu > -1.0 && uu < (double)c.width && ww > -1.0 && ww < (double)c.height;
+        iu1 = inr ? (unsigned)((int)uu + 1) : 1u;
+        iw1 = inr ? (unsigned)((int)ww + 1) : 1u;
+        inrm = lanes(inr);
+    }
+    okm &= inrm;
+    pixb = __umul24(iu1, c.su) + __umul24(iw1, c.sv);
+}
+
+// Correctly rounded n / b for two quotients at a time: hipcc's own sequence for `/` (v_rcp_f32, two Newton FMAs,
+// quotient, two residual corrections) WITHOUT its v_div_scale / v_div_fixup wrappers.  The wrappers only act when b,
+// 1/b, n/b or a residual leaves the normal range; callers check the operands (div_guard) and use `/` otherwise.
+__device__ __forceinline__ v2f rcp_refined(v2f b) {
+    v2f r = v2f{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-b, r, v2f{1.0f, 1.0f}), r, r);
+}
+__device__ __forceinline__ v2f div_core(v2f n, v2f b, v2f r) {
+    v2f q = n * r;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-b, q, n), r, q);
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-b, q, n), r, q);
+    return q;
+}
+// Range guard of the division core.  Numerators: n * 2^-26 is subnormal exactly for 0 < |n| < 2^-100 (zero stays zero).
+// State words (W, Color_W) as integers: 0 <= x < 2^64 <=> bits(x) < bits(2^64) (negative, inf, NaN are larger); the
+// new weight added to them lies in [0, 1], so b = state + weight stays within [0, 2^64] -- and b = 0 means n = 0 too
+// (both products vanish), which the core turns into the same NaN as 0/0.
+__device__ __forceinline__ unsigned long long tiny_lanes(v2f n) {
+    const v2f t = n * v2f{0x1p-26f, 0x1p-26f};
+    return lanes_subnormal(t.x) | lanes_subnormal(t.y);
+}
+constexpr unsigned kBits2p64 = 0x5f800000u;
+
 struct GatherState {        // stage 1 done: pixel record requested
     unsigned long long live;   // lane mask (wave-uniform)
     unsigned code;          // the item (wave-uniform)
     double pcx, pcy, pcz;   // camera-frame voxel centre
-    unsigned roff;          // byte offset of the lane's pixel record (kDroppedOffset when dead)
+    unsigned pix8;          // 8 * biased record index of the lane's pixel (colour: offset into the f64 cosine plane)
     u32x4 A, B;             // halves of the pixel records of lanes 0..31 (A) and 32..63 (B): lane l holds half l&1 of the
                             // record of lane l>>1 (A) / 32 + (l>>1) (B)                 (in flight until stage 2)
 };
@@ -410,349 +578,226 @@ struct UpdateState {        // stage 2 done: volume reads requested
     unsigned long long live;   // lane mask (wave-uniform)
     unsigned long long band;   // lanes whose weight went through exp() (wave-uniform)
     unsigned code;          // the item (wave-uniform)
-    float d_new, w_new, wc;
-    u32x2 C;                // f64 cosine of the pixel, band lanes only (in flight until stage 3)
-    unsigned rgb;
+    float d_new, w_new;
+    unsigned rgb;           // colour: the pixel's packed rgb
+    float wc1;              // colour: (float)cosine, the colour weight for w_new == 1
+    u32x2 C;                // colour: f64 cosine of the pixel, band lanes only  (in flight until stage 3)
     unsigned off8;          // byte offset of the lane's {D,W} in the item's segment, kDroppedOffset when dead
     u32x2 old;              // {D, W}            (in flight until stage 3)
-    u32x4 col;              // {Color_W, R, G, B} (in flight until stage 3)
+    u32x4 col;              // {Color_W, R, G, B} (fused colour; in flight until stage 3)
 };
 
 #ifndef TSDF_INTEGRATE_DEPTH
 #define TSDF_INTEGRATE_DEPTH 1      // volume reads in flight per wavefront, in items (see the pipeline loop)
 #endif
-#ifndef TSDF_INTEGRATE_ORDER
-#define TSDF_INTEGRATE_ORDER 123    // order of the three stages inside a pipeline step (timing experiments: 132, 213)
-#endif
 #ifndef TSDF_INTEGRATE_DEBUG
 #define TSDF_INTEGRATE_DEBUG 0      // 1 compiles the p.debug timing experiments in
 #endif
 
+// weight of sdf.cpp:277-279 for the lanes of the band (others: garbage, dropped by the caller)
+template <bool EXPPOLY>
+__device__ __forceinline__ float band_weight(float d, float eps) {
+    const float a = d - eps;
+    const double xarg = (-0.5 * (double)a) * (double)a;
+    return EXPPOLY ? (float)exp_taylor8(xarg) : (float)exp(xarg);
+}
+
 template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ count,
-    float2* __restrict__ dw, float4* __restrict__ crgb,
-    const float4* __restrict__ pn, unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */) {
-    extern __shared__ double s_tab[];                         // KTAB: {rot_inv[2], rot_inv[5], rot_inv[8]} * gz(k), k = 0..m-1
+    float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
+    unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */) {
+    constexpr int kRec = COLOR ? 32 : 24, kHalf = kRec / 2;        // bytes of a pixel record / of the piece a lane fetches
+    extern __shared__ double s_tab[];
     const int m = p.g.m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const double oz = p.g.origin[2];
-    const double cd = (double)p.g.cell_d;
     const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
     const unsigned n_items = *count;
     constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
-    if (KTAB) {
-        for (int k = tid; k < m; k += kIntegrateBlock) {
-            // get_global_coordinates (sdf.h:153-157): (extent/(float)m) * (k + 0.5) + origin; third term of rot_inv * g
-            const double gz = cd * ((double)k + 0.5) + oz;
-            s_tab[3 * k + 0] = p.rot_inv[2] * gz;
-            s_tab[3 * k + 1] = p.rot_inv[5] * gz;
-            s_tab[3 * k + 2] = p.rot_inv[8] * gz;
-        }
-        __syncthreads();
-    }
+    if (KTAB) build_k_table(p, s_tab, tid, kIntegrateBlock);
+    ProjConst pc;
+    make_proj_const(p, tl, lane, pc);
     // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
     // list = one band of the image, so the pixel records it gathers stay in its own L2.
     const unsigned vblock = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // The workgroup's contiguous share of the work list, dealt to its wavefronts ITEM BY ITEM: at any moment the NW
-    // wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring voxel rows, which project to the
-    // same few image columns -- the pixel-record lines one wavefront pulls into the CU's L1 serve the others.
+    // wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring voxel rows.
     const unsigned wg_first = (unsigned)(((unsigned long long)n_items * vblock) / gridDim.x);
     const unsigned wg_last = (unsigned)(((unsigned long long)n_items * (vblock + 1)) / gridDim.x);
     const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
     unsigned n_own = 0, n_halo = 0;
 
-    // scaled intrinsics: K rows 0 and 1 times 2^20 (exact), so that ij0, ij1 come out in 2^-20 pixel units
-    const double fix = (double)kFixOne, unfix = 1.0 / (double)kFixOne;
-    double Ks[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) Ks[a] = p.K[a] * fix;
-    const unsigned lim_u = ((unsigned)p.width + 1u) * kFixOne + 2u, lim_w = ((unsigned)p.height + 1u) * kFixOne + 2u;
-    const bool fastq = tl.fastq != 0;
-    // lanes of the last chunk that lie inside the grid when m is not a multiple of 64 (scalar select per item)
-    const unsigned last_chunk = (unsigned)(m - 1) >> 6;
-    const unsigned long long tail_mask = (m & 63) ? ((1ull << (m & 63)) - 1ull) : ~0ull;
-    // record offsets: the index of pixel (iu, iw) is iu*pix_su + iw*pix_sv; stage 1 works with iu+1, iw+1
-    const unsigned rs_u = (unsigned)p.pix_su * 32u, rs_w = (unsigned)p.pix_sv * 32u;
+    // planes of the frame's pixel data, their bases shifted by the bias of the record index
     const long long npix = (long long)p.width * p.height;
-    const char* rec_base = reinterpret_cast<const char*>(pn) - ((long long)rs_u + rs_w);
-    const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(rec_base), 0, (int)(npix * 32 + rs_u + rs_w), kRsrcWord3);
-    const char* cos_base = reinterpret_cast<const char*>(pn) + npix * 32 - (((long long)rs_u + rs_w) >> 2);
+    const long long bias = (long long)pc.su + pc.sv;
+    const __amdgpu_buffer_rsrc_t pn_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(pn - bias * kRec), 0, (int)((npix + bias) * kRec), kRsrcWord3);
     const __amdgpu_buffer_rsrc_t cos_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(cos_base), 0, (int)(npix * 8 + ((rs_u + rs_w) >> 2)), kRsrcWord3);
+        const_cast<char*>(pn + npix * 32 - bias * 8), 0, COLOR ? (int)((npix + bias) * 8) : 0, kRsrcWord3);
     const unsigned lane8 = (unsigned)lane * 8u;
-    const unsigned half16 = (unsigned)(lane & 1) * 16u;
+    const unsigned half_off = (unsigned)(lane & 1) * (unsigned)kHalf;
     __shared__ u32x4 s_pieces[kIntegrateBlock / 64][128];      // wave-private un-shuffle buffer of the paired gather
-    const unsigned tab_lane = (unsigned)lane * 24u;
     const unsigned dropped = kDroppedOffset;
-
     const unsigned own_row0 = (unsigned)((p.g.own_x0 - p.g.xs) * m), own_row1 = (unsigned)((p.g.own_x1 - p.g.xs) * m);   // rows < 2^26
 
-    // One pipeline step = S1(j) | S2(j-1) | S3(j-1-DEPTH): three independent instruction streams.  Order inside the step:
+    // One pipeline step = S1(j) | S2(j-1) | S3(j-1-DEPTH): three independent instruction streams.
     // S1 requests the pixel record of item j, S2 consumes the record requested a step earlier and requests the volume data,
     // S3 consumes the volume data requested DEPTH steps earlier -- every request has (at least) a whole step to complete.
     auto stage1 = [&](int j, GatherState& g /*out: item j*/) {
-        // ---------------- S1(j): geometry, request the pixel record
-        {
-            const bool have = j < cnt;
-            const ItemDesc ds = list[wg_first + (unsigned)wv + NW * (unsigned)(have ? j : 0)];
-            const unsigned chunk = ds.code & 63u;
-            double a0, a1, a2;
-            if (KTAB) {
-                const double* t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_tab) + (tab_lane + chunk * (64u * 24u)));
-                a0 = t[0]; a1 = t[1]; a2 = t[2];
-            } else {
-                const double gz = cd * ((double)((int)(chunk * 64u) + lane) + 0.5) + oz;
-                a0 = p.rot_inv[2] * gz; a1 = p.rot_inv[5] * gz; a2 = p.rot_inv[8] * gz;
-            }
-            // get_global_coordinates (sdf.h:153-157) + project_world_to_camera (camera_tracking.cpp:51-54)
-            g.pcx = (ds.s0 + a0) + p.rot_inv_trans[0];
-            g.pcy = (ds.s1 + a1) + p.rot_inv_trans[1];
-            g.pcz = (ds.s2 + a2) + p.rot_inv_trans[2];
-            unsigned long long okm = lanes(!(g.pcz < 0)) & (chunk == last_chunk ? tail_mask : ~0ull);   // sdf.cpp:247-249
-            if (!have) okm = 0ull;
-            // project_camera_to_image_plane, camera_tracking.cpp:40-47, rows 0 and 1 scaled by 2^20 (exact).  With
-            // K = [[fx,0,cx],[0,fy,cy],[0,0,1]] the dropped terms are +-0 products: (fx*x + 0*y) + cx*z == fx*x + cx*z
-            // and (0*x + 0*y) + 1*z == z bit for bit (up to the sign of a zero, which no later step can observe).
-            double ij0, ij1, ij2;
-            if (KSTD) {
-                ij0 = Ks[0] * g.pcx + Ks[2] * g.pcz;
-                ij1 = Ks[4] * g.pcy + Ks[5] * g.pcz;
-                ij2 = g.pcz;
-            } else {
-                ij0 = row3(&Ks[0], g.pcx, g.pcy, g.pcz);
-                ij1 = row3(&Ks[3], g.pcx, g.pcy, g.pcz);
-                ij2 = row3(&p.K[6], g.pcx, g.pcy, g.pcz);
-            }
-            // (int)(ij0/ij2), (int)(ij1/ij2) and the range tests of sdf.cpp:250-256 without dividing: ij2's reciprocal
-            // from v_rcp_f32 (1 ulp) and one Newton step in f64 is good to 2^-43, so q = ij * rd is within
-            // |q| 2^-42 <= 2^-11 units (|q| < 2^31 units) of the true quotient, and so is the reference's rounded
-            // quotient (2^-53 relative).  A lane whose q lies within 2 units of a multiple of 2^20 (an integer pixel
-            // coordinate: truncation and both range tests switch only there), or whose ij2 is not a plain positive
-            // number, sends the wavefront through the reference's divisions.
-            const float zf = (float)ij2;
-            double rd = (double)__builtin_amdgcn_rcpf(zf);
-            rd = __builtin_fma(__builtin_fma(-ij2, rd, 1.0), rd, rd);
-            const unsigned tu = (unsigned)cvt_i32_f64_sat(ij0 * rd) + (kFixOne + 2u);
-            const unsigned tw = (unsigned)cvt_i32_f64_sat(ij1 * rd) + (kFixOne + 2u);
-            unsigned long long inrm = lanes(tu < lim_u) & lanes(tw < lim_w);
-            unsigned iu1 = max(tu >> kFixShift, 1u), iw1 = max(tw >> kFixShift, 1u);      // pixel column + 1, row + 1
-            const unsigned long long doubtm =
-                okm & (lanes(!(zf > 1.0e-6f)) | lanes(min(tu & (kFixOne - 1u), tw & (kFixOne - 1u)) < 5u));
-            if (__builtin_expect(!fastq || doubtm != 0ull, 0)) {
-                // rows 0 and 1 unscaled again (exact: powers of two), then the reference's divisions
-                const double uu = (ij0 * unfix) / ij2, ww = (ij1 * unfix) / ij2;
-                // (int) truncation toward zero + unsigned compare (sdf.cpp:251-256): pixel c is hit by
-                // u in (c-1, c+1) for c = 0 and [c, c+1) otherwise; NaN / inf / overflow are rejected.
-                const bool inr = uu > -1.0 && uu < (double)p.width && ww > -1.0 && ww < (double)p.height;
-                iu1 = inr ? (unsigned)((int)uu + 1) : 1u;
-                iw1 = inr ? (unsigned)((int)ww + 1) : 1u;
-                inrm = lanes(inr);
-            }
-            okm &= inrm;
-            unsigned roff = __umul24(iu1, rs_u) + __umul24(iw1, rs_w);          // byte offset of the record (+ the bias in rec_base)
+        const bool have = j < cnt;
+        const ItemDesc ds = list[wg_first + (unsigned)wv + NW * (unsigned)(have ? j : 0)];
+        unsigned long long okm;
+        unsigned pixb;
+        project_item<KSTD, KTAB>(pc, ds, s_tab, lane, g.pcx, g.pcy, g.pcz, okm, pixb);
+        if (!have) okm = 0ull;
 #if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 1) roff = __builtin_amdgcn_readfirstlane(roff);       // timing experiment only: one record per wave
+        if (p.debug & 1) pixb = __builtin_amdgcn_readfirstlane(pixb);       // timing experiment only: one record per wave
 #endif
-            roff = select_by_mask(okm, roff, dropped);
-            // Pixel-record gather, paired: the vector L1 serves a wave's gather about one lane-address at a time, and the
-            // two 16-byte halves of a 32-byte record are two instructions.  Instead the first load fetches both halves of
-            // the records of lanes 0..31 (lane l: record of lane l/2, half l%2), the second those of lanes 32..63: lane pairs
-            // share a line, so the look-ups of an item are halved (measured, round 3: 74 of 185 us of the launch were the
-            // three unpaired gather instructions).  Stage 2 un-shuffles the pieces through a wave-private LDS buffer.
-            g.roff = roff;
-            const unsigned ra = (unsigned)__shfl((int)roff, lane >> 1) + half16;
-            const unsigned rb = (unsigned)__shfl((int)roff, 32 + (lane >> 1)) + half16;
-            g.A = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (int)ra, 0, 0);      // piece for LDS slot lane
-            g.B = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (int)rb, 0, 0);      // piece for LDS slot 64 + lane
-#if TSDF_INTEGRATE_DEBUG
-            // issue-cost experiments: 32 extra scalar / vector / f64 instructions per step
-            if (p.debug & 2048) {
-                unsigned x = ds.code;
-                asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
-                             "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
-                             "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
-                             "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1" : "+s"(x) :: "scc");
-                n_halo += x & 0u;
-            }
-            if (p.debug & 4096) {
-                unsigned x = roff;
-                asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
-                             "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
-                             "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
-                             "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1" : "+v"(x));
-                g.roff += x & 0u;
-            }
-            if (p.debug & 8192) {
-                double x = g.pcx;
-                asm volatile("v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n"
-                             "v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n"
-                             "v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n"
-                             "v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0\n v_add_f64 %0, %0, 1.0" : "+v"(x));
-                if (x == 12345.678) g.roff += 1u;
-            }
-#endif
-            g.live = okm;
-            g.code = ds.code;
+        // Pixel-record gather, paired: the vector L1 serves a wave's gather about one lane-address at a time, and the
+        // two halves of a record are two instructions.  Instead the first load fetches both halves of
+        // the records of lanes 0..31 (lane l: record of lane l/2, half l%2), the second those of lanes 32..63: lane pairs
+        // share a line, so the look-ups of an item are halved.  Stage 2 un-shuffles the pieces through a wave-private
+        // LDS buffer.  Dead lanes carry an offset beyond the plane: no look-up at all.
+        const unsigned roff = select_by_mask(okm, COLOR ? pixb << 5 : __umul24(pixb, (unsigned)kRec), dropped);
+        const unsigned ra = (unsigned)__shfl((int)roff, lane >> 1) + half_off;
+        const unsigned rb = (unsigned)__shfl((int)roff, 32 + (lane >> 1)) + half_off;
+        if (COLOR) {
+            g.A = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)ra, 0, 0);      // piece for LDS slot lane
+            g.B = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)rb, 0, 0);      // piece for LDS slot 64 + lane
+            g.pix8 = roff >> 2;                                                      // (a dropped offset stays beyond the plane)
+        } else {
+            const u32x3 a3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)ra, 0, 0);
+            const u32x3 b3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)rb, 0, 0);
+            g.A = u32x4{a3.x, a3.y, a3.z, 0u}; g.B = u32x4{b3.x, b3.y, b3.z, 0u};
         }
+        g.live = okm;
+        g.code = ds.code;
     };
     auto stage2 = [&](const GatherState& gin /*item j-1, record arrived*/, UpdateState& u /*out: item j-1*/) {
-        // ---------------- S2(j-1): distance + weight from the pixel record; request {D,W} (+ colour)
-        {
-            u32x4* stage = s_pieces[wv];
-            stage[lane] = gin.A;
-            stage[64 + lane] = gin.B;
-            // other LANES read what this lane wrote: the compiler's memory model is per thread, so without a
-            // wavefront-scope fence it may (and did) hoist the reads above the second write.  No instruction is
-            // emitted: LDS operations of one wave execute in order.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const u32x4 P = stage[2 * lane + 0];              // own record: {Px,Py,Pz,rgb}
-            const u32x4 N = stage[2 * lane + 1];              //             {Nx,Ny,Nz,(float)cosine}
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads above stay before the next step's writes
-            __builtin_amdgcn_wave_barrier();
-            const float Px = __uint_as_float(P.x), Py = __uint_as_float(P.y), Pz = __uint_as_float(P.z);
-            const float Nx = __uint_as_float(N.x), Ny = __uint_as_float(N.y), Nz = __uint_as_float(N.z);
-            // sdf.cpp:260: NaN in P.x, P.y or the normal
-            const unsigned long long nanm = lanes(__builtin_isunordered(Px, Py)) | lanes(__builtin_isunordered(Nx, Ny)) | lanes(is_nan(Nz));
-            // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
-            const double dx = (double)Px - gin.pcx, dy = (double)Py - gin.pcy, dz = (double)Pz - gin.pcz;
-            const double p2p = dx * (double)Nx + (dy * (double)Ny + dz * (double)Nz);
-            float d = (float)p2p;                                               // sdf.cpp:274
-            unsigned long long okm = gin.live & ~nanm & ~lanes(d > delta);   // sdf.cpp:280-283
-            const unsigned long long bandm = okm & lanes(d >= eps);          // sdf.cpp:277-279 (d <= delta holds in okm)
-            float wn = 1.0f;
-            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  For w_new == 1 that is the pre-rounded cosine of the record;
-            // the lanes of the exp() band fetch the pixel's f64 cosine here and stage 3 forms the product.
-            if (COLOR) u.C = __builtin_amdgcn_raw_buffer_load_b64(cos_rsrc, (int)select_by_mask(bandm, gin.roff >> 2, dropped), 0, 0);
-            if (bandm != 0ull) {
-                const float a = d - eps;
-                const double xarg = (-0.5 * (double)a) * (double)a;
-                float e;
-                if (EXPPOLY) e = (float)exp_taylor8(xarg);                      // (lanes outside the band compute garbage, dropped below)
-                else e = (float)exp(xarg);
-                wn = __uint_as_float(select_by_mask(bandm, __float_as_uint(e), 0x3f800000u));
-            }
-            d = d < neg_delta ? neg_delta : d;                                  // sdf.cpp:285-287
+        u32x4* stage = s_pieces[wv];
+        if (COLOR) { stage[lane] = gin.A; stage[64 + lane] = gin.B; }
+        else {
+            *reinterpret_cast<u32x3*>(&stage[lane]) = u32x3{gin.A.x, gin.A.y, gin.A.z};
+            *reinterpret_cast<u32x3*>(&stage[64 + lane]) = u32x3{gin.B.x, gin.B.y, gin.B.z};
+        }
+        // other LANES read what this lane wrote: the compiler's memory model is per thread, so without a
+        // wavefront-scope fence it may (and did) hoist the reads above the second write.  No instruction is
+        // emitted: LDS operations of one wave execute in order.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32x4 P, N;                                            // own record: {Px,Py,Pz,rgb} {Nx,Ny,Nz,(float)cosine}
+        if (COLOR) { P = stage[2 * lane + 0]; N = stage[2 * lane + 1]; }
+        else {
+            const u32x3 p3 = *reinterpret_cast<const u32x3*>(&stage[2 * lane + 0]), n3 = *reinterpret_cast<const u32x3*>(&stage[2 * lane + 1]);
+            P = u32x4{p3.x, p3.y, p3.z, 0u}; N = u32x4{n3.x, n3.y, n3.z, 0u};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads above stay before the next step's writes
+        __builtin_amdgcn_wave_barrier();
+        const float Px = __uint_as_float(P.x), Py = __uint_as_float(P.y), Pz = __uint_as_float(P.z);
+        const float Nx = __uint_as_float(N.x), Ny = __uint_as_float(N.y), Nz = __uint_as_float(N.z);
+        // sdf.cpp:260: NaN in P.x, P.y or the normal
+        const unsigned long long nanm = lanes(__builtin_isunordered(Px, Py)) | lanes(__builtin_isunordered(Nx, Ny)) | lanes(is_nan(Nz));
+        // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
+        const double dx = (double)Px - gin.pcx, dy = (double)Py - gin.pcy, dz = (double)Pz - gin.pcz;
+        const double p2p = dx * (double)Nx + (dy * (double)Ny + dz * (double)Nz);
+        float d = (float)p2p;                                               // sdf.cpp:274
+        unsigned long long okm = gin.live & ~nanm & ~lanes(d > delta);      // sdf.cpp:280-283
+        const unsigned long long bandm = okm & lanes(d >= eps);             // sdf.cpp:277-279 (d <= delta holds in okm)
 #if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 2) okm = 0ull;                                        // timing experiment only: no volume RMW
+        if (p.debug & 2) okm = 0ull;                                        // timing experiment only: no volume RMW
 #endif
-            u.d_new = d; u.w_new = wn; u.wc = __uint_as_float(N.w); u.rgb = P.w;
-            u.live = okm; u.band = bandm;
-            const unsigned code2 = gin.code;
-            u.code = code2;
-            long long base2 = (long long)(code2 >> 6) * m + (long long)(code2 & 63u) * 64;
+        if (COLOR) {
+            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  For w_new == 1 that is the pre-rounded cosine of the
+            // record; the lanes of the exp() band also fetch the pixel's f64 cosine and stage 3 forms the product.
+            u.C = __builtin_amdgcn_raw_buffer_load_b64(cos_rsrc, (int)select_by_mask(bandm, gin.pix8, dropped), 0, 0);
+            u.rgb = P.w; u.wc1 = __uint_as_float(N.w);
+        }
+        float wn = 1.0f;
+        if (bandm != 0ull)
+            wn = __uint_as_float(select_by_mask(bandm, __float_as_uint(band_weight<EXPPOLY>(d, eps)), 0x3f800000u));
+        d = d < neg_delta ? neg_delta : d;                                  // sdf.cpp:285-287
+        u.d_new = d; u.w_new = wn;
+        u.live = okm; u.band = bandm;
+        const unsigned code2 = gin.code;
+        u.code = code2;
+        long long base2 = (long long)(code2 >> 6) * m + (long long)(code2 & 63u) * 64;
 #if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 64) base2 = 0;                                        // timing experiment only: cache-resident volume reads
+        if (p.debug & 64) base2 = 0;                                        // timing experiment only: cache-resident volume reads
 #endif
-            u.off8 = select_by_mask(okm, lane8, dropped);
-            const __amdgpu_buffer_rsrc_t seg_dw = __builtin_amdgcn_make_buffer_rsrc(dw + base2, 0, 64 * (int)sizeof(float2), kRsrcWord3);
-            u.old = __builtin_amdgcn_raw_buffer_load_b64(seg_dw, (int)u.off8, 0, 0);   // {D,W}: the tracker re-reads these lines -> keep them cached
-            if (COLOR) {   // colour is streamed once per frame and never read by the tracker: non-temporal
-                const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base2, 0, 64 * (int)sizeof(float4), kRsrcWord3);
-                u.col = __builtin_amdgcn_raw_buffer_load_b128(seg_c, (int)(u.off8 << 1), 0, 2);
-            }
+        u.off8 = select_by_mask(okm, lane8, dropped);
+        const __amdgpu_buffer_rsrc_t seg_dw = __builtin_amdgcn_make_buffer_rsrc(dw + base2, 0, 64 * (int)sizeof(float2), kRsrcWord3);
+        const unsigned ld8 = u.off8;
+        u.old = __builtin_amdgcn_raw_buffer_load_b64(seg_dw, (int)ld8, 0, 0);   // {D,W}: the tracker re-reads these lines -> keep them cached
+        if (COLOR) {   // colour is streamed once per frame and never read by the tracker: non-temporal
+            const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base2, 0, 64 * (int)sizeof(float4), kRsrcWord3);
+            u.col = __builtin_amdgcn_raw_buffer_load_b128(seg_c, (int)(ld8 << 1), 0, 2);
         }
     };
     auto stage3 = [&](const UpdateState& uin /*item j-1-DEPTH, volume data arrived*/) {
-        // ---------------- S3(j-1-DEPTH): running averages + stores
-        {
-            const unsigned code3 = uin.code;
-            const unsigned row3 = code3 >> 6;
-            const bool owned3 = row3 >= own_row0 && row3 < own_row1;            // wave-uniform; rows of the owned x layers
-            long long base3 = (long long)row3 * m + (long long)(code3 & 63u) * 64;
+        const unsigned code3 = uin.code;
+        const unsigned row3 = code3 >> 6;
+        const bool owned3 = row3 >= own_row0 && row3 < own_row1;            // wave-uniform; rows of the owned x layers
+        long long base3 = (long long)row3 * m + (long long)(code3 & 63u) * 64;
 #if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 1024) base3 = (long long)(blockIdx.x & 255) * 4096 + wv * 64;   // timing experiment only: stores to a cache-resident region
+        if (p.debug & 1024) base3 = (long long)(blockIdx.x & 255) * 4096 + wv * 64;   // timing experiment only: stores to a cache-resident region
 #endif
-            const unsigned n_live = (unsigned)__popcll(uin.live);
-            n_own += owned3 ? n_live : 0u;
-            n_halo += owned3 ? 0u : n_live;
-            // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
-            const float W = __uint_as_float(uin.old.y), D = __uint_as_float(uin.old.x);
-            const float cx = __uint_as_float(uin.col.x);
-            float wc = uin.wc;
-            if (COLOR && uin.band != 0ull) {
+        const unsigned n_live = (unsigned)__popcll(uin.live);
+        n_own += owned3 ? n_live : 0u;
+        n_halo += owned3 ? 0u : n_live;
+        // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
+        const float W = __uint_as_float(uin.old.y), D = __uint_as_float(uin.old.x);
+        const float cx = __uint_as_float(uin.col.x);
+        float wc = 0.f;
+        if (COLOR) {
+            wc = uin.wc1;
+            if (uin.band != 0ull) {
                 const double cosd = __hiloint2double((int)uin.C.y, (int)uin.C.x);
                 wc = __uint_as_float(select_by_mask(uin.band, __float_as_uint((float)((double)uin.w_new * cosd)), __float_as_uint(wc)));
             }
-            v2f sum1, num1, num2 = v2f{0.f, 0.f};
-            sum1.x = W + uin.w_new;
-            num1.x = W * D + uin.w_new * uin.d_new;
-            if (COLOR) {
-                const float pr = (float)(uin.rgb & 255u), pg = (float)((uin.rgb >> 8) & 255u), pb = (float)((uin.rgb >> 16) & 255u);
-                sum1.y = cx + wc;
-                num1.y = cx * __uint_as_float(uin.col.y) + wc * pr;
-                num2 = v2f{cx, cx} * v2f{__uint_as_float(uin.col.z), __uint_as_float(uin.col.w)} + v2f{wc, wc} * v2f{pg, pb};
-            } else {
-                sum1.y = 1.0f; num1.y = 0.0f;
-            }
-            // Correctly rounded n / b: hipcc's own sequence for `/` (v_rcp_f32, two Newton FMAs, quotient, two residual
-            // corrections) WITHOUT its v_div_scale / v_div_fixup wrappers, two quotients per packed instruction.  The
-            // wrappers only act when b, 1/b, n/b or the residuals leave the normal range; with b = W + w in
-            // [0.25, 2^64), 0 <= Color_W < 2^64 and every numerator zero or at least 2^-100 in magnitude none of that can happen
-            // (|quotients| stay within [2^-164, 2^128)... checked per lane below; a wavefront with a lane outside
-            // the proven range divides with `/`.
-            v2f q1, q2 = v2f{0.f, 0.f};
-            {
-                v2f r = v2f{__builtin_amdgcn_rcpf(sum1.x), __builtin_amdgcn_rcpf(sum1.y)};
-                const v2f one = v2f{1.0f, 1.0f};
-                r = __builtin_elementwise_fma(__builtin_elementwise_fma(-sum1, r, one), r, r);
-                q1 = num1 * r;
-                q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-sum1, q1, num1), r, q1);
-                q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-sum1, q1, num1), r, q1);
-                if (COLOR) {
-                    const v2f rc = v2f{r.y, r.y}, bc = v2f{sum1.y, sum1.y};
-                    q2 = num2 * rc;
-                    q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(-bc, q2, num2), rc, q2);
-                    q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(-bc, q2, num2), rc, q2);
-                }
-            }
-            {
-                // range guard.  Numerators: n * 2^-26 is subnormal exactly for 0 < |n| < 2^-100 (zero stays zero).
-                // State words as integers: 0 <= x < 2^64 <=> bits(x) < bits(2^64) (negative, inf, NaN are larger).
-                const v2f t1 = num1 * v2f{0x1p-26f, 0x1p-26f};
-                unsigned long long bad = lanes_subnormal(t1.x) | lanes(uin.old.y >= 0x5f800000u);
-                if (COLOR) {
-                    const v2f t2 = num2 * v2f{0x1p-26f, 0x1p-26f};
-                    bad |= lanes_subnormal(t1.y) | lanes_subnormal(t2.x) | lanes_subnormal(t2.y) | lanes(uin.col.x >= 0x5f800000u);
-                }
-                if (__builtin_expect((bad & uin.live) != 0ull, 0)) {
-                    q1.x = num1.x / sum1.x;
-                    if (COLOR) { q1.y = num1.y / sum1.y; q2.x = num2.x / sum1.y; q2.y = num2.y / sum1.y; }
-                }
-            }
-            const __amdgpu_buffer_rsrc_t seg_dw = __builtin_amdgcn_make_buffer_rsrc(dw + base3, 0, 64 * (int)sizeof(float2), kRsrcWord3);
-            u32x2 o2; o2.x = __float_as_uint(q1.x); o2.y = __float_as_uint(sum1.x);
-            unsigned off8 = uin.off8;
-#if TSDF_INTEGRATE_DEBUG
-            if (p.debug & 32) off8 = dropped;                                   // timing experiment only: no stores
-#endif
-            __builtin_amdgcn_raw_buffer_store_b64(o2, seg_dw, (int)off8, 0, 0);
-            if (COLOR) {
-                const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base3, 0, 64 * (int)sizeof(float4), kRsrcWord3);
-                u32x4 c4; c4.x = __float_as_uint(sum1.y); c4.y = __float_as_uint(q1.y); c4.z = __float_as_uint(q2.x); c4.w = __float_as_uint(q2.y);
-                __builtin_amdgcn_raw_buffer_store_b128(c4, seg_c, (int)(off8 << 1), 0, 2);   // dropped stays out of range; aux 2 = nt: colour is streamed
-            }
         }
-    };
-    auto step = [&](int j, GatherState& g, const GatherState& gin, UpdateState& u, const UpdateState& uin) {
-#if TSDF_INTEGRATE_ORDER == 132
-        stage1(j, g); stage3(uin); stage2(gin, u);
-#elif TSDF_INTEGRATE_ORDER == 213
-        stage2(gin, u); stage1(j, g); stage3(uin);
-#else
-        stage1(j, g); stage2(gin, u); stage3(uin);
+        v2f sum1, num1, num2 = v2f{0.f, 0.f};
+        sum1.x = W + uin.w_new;
+        num1.x = W * D + uin.w_new * uin.d_new;
+        if (COLOR) {
+            const unsigned rgb = uin.rgb;
+            const float pr = (float)(rgb & 255u), pg = (float)((rgb >> 8) & 255u), pb = (float)((rgb >> 16) & 255u);
+            sum1.y = cx + wc;
+            num1.y = cx * __uint_as_float(uin.col.y) + wc * pr;
+            num2 = v2f{cx, cx} * v2f{__uint_as_float(uin.col.z), __uint_as_float(uin.col.w)} + v2f{wc, wc} * v2f{pg, pb};
+        } else {
+            sum1.y = 1.0f; num1.y = 0.0f;
+        }
+        const v2f r = rcp_refined(sum1);
+        v2f q1 = div_core(num1, sum1, r), q2 = v2f{0.f, 0.f};
+        if (COLOR) q2 = div_core(num2, v2f{sum1.y, sum1.y}, v2f{r.y, r.y});
+        unsigned long long bad = tiny_lanes(num1) | lanes(uin.old.y >= kBits2p64);
+        if (COLOR) bad |= tiny_lanes(num2) | lanes(uin.col.x >= kBits2p64);
+        if (__builtin_expect((bad & uin.live) != 0ull, 0)) {
+            q1.x = num1.x / sum1.x;
+            if (COLOR) { q1.y = num1.y / sum1.y; q2.x = num2.x / sum1.y; q2.y = num2.y / sum1.y; }
+        }
+        const __amdgpu_buffer_rsrc_t seg_dw = __builtin_amdgcn_make_buffer_rsrc(dw + base3, 0, 64 * (int)sizeof(float2), kRsrcWord3);
+        u32x2 o2; o2.x = __float_as_uint(q1.x); o2.y = __float_as_uint(sum1.x);
+        unsigned off8 = uin.off8;
+#if TSDF_INTEGRATE_DEBUG
+        if (p.debug & 32) off8 = dropped;                                   // timing experiment only: no stores
 #endif
+        __builtin_amdgcn_raw_buffer_store_b64(o2, seg_dw, (int)off8, 0, 0);
+        if (COLOR) {
+            const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base3, 0, 64 * (int)sizeof(float4), kRsrcWord3);
+            u32x4 c4; c4.x = __float_as_uint(sum1.y); c4.y = __float_as_uint(q1.y); c4.z = __float_as_uint(q2.x); c4.w = __float_as_uint(q2.y);
+            __builtin_amdgcn_raw_buffer_store_b128(c4, seg_c, (int)(off8 << 1), 0, 2);   // dropped stays out of range; nt: colour is streamed
+        }
+
     };
 
     // Software pipeline over the wavefront's items, unrolled over one full rotation of the state registers so
     // that in-flight registers never have to be copied (a copy would force the wait):
     //   step j:  S1(j) request pixel record | S2(j-1) request {D,W}/colour | S3(j-1-DEPTH) average + store
     // DEPTH = steps between the volume request of an item and its use: DEPTH + 1 update states rotate, i.e.
-    // DEPTH items' worth of HBM reads (1.5 KB each) stay in flight per wavefront.
+    // DEPTH items' worth of HBM reads stay in flight per wavefront.
     constexpr int NU = TSDF_INTEGRATE_DEPTH + 1, NG = 2;
     constexpr int PERIOD = (NU % 2 == 0) ? NU : 2 * NU;
     GatherState G[NG];
@@ -761,19 +806,22 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     for (int q = 0; q < NG; ++q) {
         G[q].live = 0ull; G[q].code = 0u;
         G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
-        G[q].A = u32x4{0u, 0u, 0u, 0u}; G[q].B = G[q].A; G[q].roff = kDroppedOffset;
+        G[q].A = u32x4{0u, 0u, 0u, 0u}; G[q].B = G[q].A; G[q].pix8 = kDroppedOffset;
     }
 #pragma unroll
     for (int q = 0; q < NU; ++q) {
-        U[q].live = 0ull; U[q].band = 0ull; U[q].code = 0u; U[q].C = u32x2{0u, 0u};
-        U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].wc = 0.f; U[q].rgb = 0u; U[q].off8 = kDroppedOffset;
+        U[q].live = 0ull; U[q].band = 0ull; U[q].code = 0u; U[q].C = u32x2{0u, 0u}; U[q].rgb = 0u; U[q].wc1 = 0.f;
+        U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].off8 = kDroppedOffset;
         U[q].old = u32x2{0u, 0x3f800000u}; U[q].col = u32x4{0x3f800000u, 0u, 0u, 0u};
     }
     for (int j = 0; j < cnt + 1 + TSDF_INTEGRATE_DEPTH; j += PERIOD) {
 #pragma unroll
-        for (int q = 0; q < PERIOD; ++q)
+        for (int q = 0; q < PERIOD; ++q) {
             // S1(j+q) -> G[q%2];  S2(j+q-1): G[(q+1)%2] -> U[q%NU];  S3(j+q-1-DEPTH): U[(q+1)%NU] (the oldest)
-            step(j + q, G[q % NG], G[(q + 1) % NG], U[q % NU], U[(q + 1) % NU]);
+            stage1(j + q, G[q % NG]);
+            stage2(G[(q + 1) % NG], U[q % NU]);
+            stage3(U[(q + 1) % NU]);
+        }
     }
     // (steps run up to j >= cnt + DEPTH, so S3 has retired item cnt-1 inside the loop: nothing to drain)
 
@@ -805,14 +853,9 @@ int integrate_blocks_per_cu() {
 
 size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords; }
 
-hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
-                            const float4* pn, unsigned long long* counters,
-                            void* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts) {
+static bool make_tiling(const IntegrateParams& p, IntegrateTiling& tl) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
-    if (nx <= 0 || m <= 0) return hipSuccess;
-    IntegrateTiling tl;
     tl.n_rows = (long long)nx * m;
     tl.log2m = -1;
     for (int b = 0; b < 31; ++b) if ((1 << b) == m) tl.log2m = b;
@@ -823,7 +866,23 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     tl.fastq = (p.width <= kMaxFastDim && p.height <= kMaxFastDim) ? 1 : 0;
     for (int a = 0; a < 6; ++a) if (!(fabs(p.K[a]) < 1.0e200)) tl.fastq = 0;
     if (p.debug & 8) tl.fastq = 0;
-    if (tl.n_rows >= (1ll << 26)) return hipErrorInvalidValue;       // row index must fit the 26-bit item code
+    return tl.n_rows < (1ll << 26);                                    // row index must fit the 26-bit item code
+}
+// weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 0.04
+static bool use_exp_poly(const IntegrateParams& p) {
+    const double span = (double)p.g.delta - (double)p.g.epsilon;
+    return span >= 0.0 && 0.5 * span * span <= 0.04;
+}
+
+hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
+                            const float4* pn, unsigned long long* counters,
+                            void* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
+                            unsigned launch_parity, unsigned long long* wg_counts) {
+    const int m = p.g.m;
+    const int nx = p.g.xe - p.g.xs;
+    if (nx <= 0 || m <= 0) return hipSuccess;
+    IntegrateTiling tl;
+    if (!make_tiling(p, tl)) return hipErrorInvalidValue;
     // two bookkeeping sets used alternately (see kBinSetWords)
     unsigned* const cur = work_count + (launch_parity & 1) * kBinSetWords;
     unsigned* const nxt = work_count + ((launch_parity + 1) & 1) * kBinSetWords;
@@ -836,13 +895,12 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, list, counters);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // weight exponent x = -(d-eps)^2/2 with eps <= d <= delta: the Taylor path is valid while |x| <= 0.04
-    const double span = (double)p.g.delta - (double)p.g.epsilon;
-    const bool exp_poly = span >= 0.0 && 0.5 * span * span <= 0.04;
+    const bool exp_poly = use_exp_poly(p);
     const bool ktab = m <= 1024;                                       // 24 bytes of LDS per k
     const size_t lds = ktab ? (size_t)m * 24 : 0;
+    const char* planes = reinterpret_cast<const char*>(pn);
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) \
-    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, dw, crgb, pn, wg_counts)
+    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, dw, crgb, planes, wg_counts)
 #define TSDF_LAUNCH_INTEGRATE3(C, KS, EP) do { if (ktab) TSDF_LAUNCH_INTEGRATE(C, KS, EP, true); else TSDF_LAUNCH_INTEGRATE(C, KS, EP, false); } while (0)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE3(C, KS, true); else TSDF_LAUNCH_INTEGRATE3(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
@@ -1053,6 +1111,20 @@ __device__ __forceinline__ void voxel_of(const TrackParams& p, const double* R, 
     vz = (wz - p.g.origin[2]) * (double)p.g.m_div_d - 0.5;
 }
 
+// End (exclusive, as a sample index) of the OpenMP column chunk that holds sample n.  The reference's carry state
+// (is_interpolated, SDF_derivative, int_dist) is thread-local and starts fresh in every thread (camera_tracking.cpp:
+// 148-159); `#pragma omp for` over the ncols image columns (:160-162) with GCC's default static schedule gives thread
+// t < r = ncols % np the columns [t (q+1), (t+1)(q+1)) and the others q = ncols / np columns each.  A run of
+// out-of-grid samples therefore never extends past the end of its chunk.  Geometry only: the same on every rank.
+__device__ __forceinline__ int chunk_end_sample(const TrackParams& p, int n) {
+    if (p.carry_threads <= 1) return p.n_samples;
+    const int col = n / p.nrows;
+    const int q = p.ncols / p.carry_threads, r = p.ncols % p.carry_threads;
+    const int big = r * (q + 1);
+    const int end_col = col < big ? (col / (q + 1) + 1) * (q + 1) : big + ((col - big) / q + 1) * q;   // (col >= big implies q >= 1)
+    return (end_col < p.ncols ? end_col : p.ncols) * p.nrows;
+}
+
 struct TrackFold {               // in-launch fan-in of the per-workgroup rows
     unsigned* ctr;               // kTrackShards shard counters + 1 top counter, one 128-byte line each, zero between passes
     double* shard_rows;          // kTrackShards x kPartWidth
@@ -1128,19 +1200,22 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         const unsigned long long own_in = s_in[0] & kOwnMask;
         bool need_tail = false;
         unsigned tail = 0;
+        int tail_limit = p.n_samples;
         if (own_in) {
-            // it reaches the window end iff no in-grid bit follows it
+            // it reaches the window end iff no in-grid bit follows it and its column chunk goes on behind the window
             const int last_own = 63 - __clzll((long long)own_in);
             const unsigned long long above = last_own == 63 ? 0ull : ~0ull << (last_own + 1);
-            need_tail = (s_in[0] & above) == 0ull;
+            tail_limit = chunk_end_sample(p, base + last_own);
+            need_tail = (s_in[0] & above) == 0ull && tail_limit > base + 64;
         }
         if (need_tail) {
             bool found = false;
-            for (int pos = base + 64; !found && pos < p.n_samples; pos += kTrackBlock) {
+            for (int pos = base + 64; !found && pos < tail_limit; pos += kTrackBlock) {
                 SampleGeom tmp;
                 const int c2 = classify(p, samples, pos + tid, tmp);
-                const unsigned long long i2 = __ballot(c2 == kClsIn);
-                const unsigned long long o2 = __ballot(c2 == kClsOog);
+                const bool inside = pos + tid < tail_limit;         // the run ends with its chunk
+                const unsigned long long i2 = __ballot(inside && c2 == kClsIn);
+                const unsigned long long o2 = __ballot(inside && c2 == kClsOog);
                 __syncthreads();                        // previous round's readers are done
                 if (lane == 0) { s_in2[wv] = i2; s_oog2[wv] = o2; }
                 __syncthreads();
@@ -1157,14 +1232,17 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             }
         }
         if (cls == kClsIn) {
-            const unsigned long long above = g == 63 ? 0ull : ~0ull << (g + 1);
+            // window positions of the sample's own column chunk
+            const int lim = chunk_end_sample(p, n) - base;
+            const unsigned long long chunk = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+            const unsigned long long above = (g == 63 ? 0ull : ~0ull << (g + 1)) & chunk;
             unsigned cnt = 0;
             const unsigned long long mi = s_in[0] & above;
             if (mi) {
                 const int nxt = __ffsll((long long)mi) - 1;
                 cnt = __popcll(s_oog[0] & above & ((1ull << nxt) - 1ull));
             } else {
-                cnt = __popcll(s_oog[0] & above) + tail;
+                cnt = __popcll(s_oog[0] & above) + (lim > 64 ? tail : 0u);
             }
             mult = 1u + cnt;
         }
