@@ -74,3 +74,10 @@ mock_rccl:
 	gcc -O2 -Wall -Wextra -shared -fPIC -I/opt/rocm/include -o $(ROOT)build/libmock_rccl.so $(ROOT)tests/mock_rccl/mock_rccl.c \
 	    -L/opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib
 .PHONY: mock_rccl
+
+# field writes / constructor constants / cloud-reuse token of the exact-type shim (tests/test_cpp_shim.py, GPU)
+shim_fields_demo: $(LIB)
+	@mkdir -p $(ROOT)build
+	g++ -std=c++11 -O2 -Wall -Wextra -DTSDF_WITH_EIGEN_PCL -DTSDF_WITH_ROS -I$(ROOT)tests/mock -I$(ROOT)include \
+	    -o $(ROOT)build/shim_fields_demo $(ROOT)tests/mock/shim_fields_demo.cpp -L$(LIBDIR) -ltsdf_hip -Wl,-rpath,$(LIBDIR)
+.PHONY: shim_fields_demo

@@ -67,6 +67,9 @@ public:
     SDF(int m_, float width, float height, float depth, const Vec3& sdf_origin, float distance_delta,
         float distance_epsilon, const tsdf_config* base = nullptr)
         : m(m_), m_div_height(m_ / height), m_div_width(m_ / width), m_div_depth(m_ / depth) {
+        if (tsdf_abi_version() != TSDF_ABI_VERSION)       // struct layouts differ between versions
+            throw Error(TSDF_E_BADARG, "libtsdf_hip.so has ABI version " + std::to_string(tsdf_abi_version()) +
+                                       ", this header is version " + std::to_string(TSDF_ABI_VERSION) + ": rebuild");
         tsdf_config cfg;
         if (base) cfg = *base; else tsdf_default_config(&cfg);
         cfg.m = m_; cfg.width = width; cfg.height = height; cfg.depth = depth;
@@ -140,15 +143,13 @@ public:
     Vec3 trans{}, rot_inv_trans{};
     bool isKFilled = false;
 
-    // definition order of the reference: (gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf)
+    // definition order of the reference: (gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf).  The reference
+    // takes any constants here (camera_tracking.cpp:3-18); the native handle got its own when the SDF was created, so
+    // the ones given here reconfigure it.
     CameraTracking(int gauss_newton_max_iteration, float maximum_twist_diff, float v_h, float w_h, SDF* sdf)
         : sdf_(sdf) {
-        tsdf_config c;
-        tsdf_get_config(sdf->handle(), &c);
-        if (c.gn_max_iter != gauss_newton_max_iteration || c.max_twist_diff != maximum_twist_diff || c.v_h != v_h ||
-            c.w_h != w_h)
-            throw Error(TSDF_E_BADARG, "CameraTracking: constants differ from the ones the SDF handle was created with "
-                                       "(pass them through the tsdf_config given to SDF)");
+        sdf->check(tsdf_set_tracker_params(sdf->handle(), gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h),
+                   "tsdf_set_tracker_params");
         sync();
     }
 
@@ -324,7 +325,7 @@ public:
         : isKFilled(false), impl_(gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf) { pull(); }
     virtual ~CameraTracking() {}
 
-    void set_K(const Eigen::Matrix3d& k) { impl_.set_K(to_rows(k)); K = k; isKFilled = true; }
+    void set_K(const Eigen::Matrix3d& k) { impl_.set_K(to_rows(k)); K = k; seen_K_ = k; isKFilled = true; }
     // camera_tracking.h:84
     void set_camera_transformation(Eigen::Matrix3d& r, Eigen::Vector3d& t) {
         impl_.set_camera_transformation(to_rows(r), Vec3{{t(0), t(1), t(2)}});
@@ -332,23 +333,26 @@ public:
     }
     // camera_tracking.h:101
     void estimate_new_position(const SDF* sdf, const pcl::PointCloud<pcl::PointXYZRGB>::Ptr& point_cloud) {
-        tracked_points_ = nullptr;
+        push(sdf);
+        token_ = FrameToken();
         sdf->check(tsdf_set_frame_aos(sdf->handle(), point_cloud->points.data(), nullptr, &pcl_layout(),
                                       (int32_t)point_cloud->width, (int32_t)point_cloud->height), "tsdf_set_frame_aos");
-        tracked_points_ = point_cloud->points.data(); tracked_w_ = point_cloud->width; tracked_h_ = point_cloud->height;
+        token_ = FrameToken(*point_cloud, tsdf_frame_serial(sdf->handle()));
         try { impl_.estimate_new_position(sdf); } catch (...) { pull(); throw; }
         pull();
     }
     // The reference hands the cloud it has just tracked to SDF::update (sdf_reconstruction.cpp:70,74): its points are
-    // in HBM already, update() then uploads the normals only.  One-shot: true once per tracked cloud.  Define
-    // TSDF_SHIM_NO_CLOUD_REUSE if the caller changes the points between the two calls.
-    bool take_tracked(const pcl::PointCloud<pcl::PointXYZRGB>& c) {
+    // in HBM already, update() then uploads the normals only -- when the frame in the library is still that upload
+    // (tsdf_frame_serial) and the cloud is still that cloud: same array, same size and the same bytes in a sample of
+    // its points (a cloud changed in place, or another one allocated at the same address, does not pass for it).
+    // One-shot: true once per tracked cloud.  TSDF_SHIM_NO_CLOUD_REUSE switches the reuse off altogether.
+    bool take_tracked(const SDF* sdf, const pcl::PointCloud<pcl::PointXYZRGB>& c) {
 #ifdef TSDF_SHIM_NO_CLOUD_REUSE
-        (void)c;
+        (void)sdf; (void)c;
         return false;
 #else
-        const bool same = tracked_points_ && tracked_points_ == c.points.data() && tracked_w_ == c.width && tracked_h_ == c.height;
-        tracked_points_ = nullptr;
+        const bool same = token_.valid && token_ == FrameToken(c, tsdf_frame_serial(sdf->handle()));
+        token_ = FrameToken();
         return same;
 #endif
     }
@@ -357,18 +361,54 @@ public:
         impl_.sync();
         from_rows(impl_.rot, rot); from_rows(impl_.rot_inv, rot_inv);
         for (int a = 0; a < 3; ++a) { trans(a) = impl_.trans[a]; rot_inv_trans(a) = impl_.rot_inv_trans[a]; }
+        seen_rot_ = rot; seen_trans_ = trans; seen_rot_inv_ = rot_inv; seen_rot_inv_trans_ = rot_inv_trans;
+    }
+    // The public fields are plain members in the reference (camera_tracking.h:43-59) and the tracker / SDF::update read
+    // them directly, so a caller may simply assign them.  Here they mirror the native handle: before every hot call
+    // a pose or K that no longer equals what was last pulled is written through (rot / trans by
+    // set_camera_transformation, which also renews rot_inv / rot_inv_trans as camera_tracking.cpp:59-65 does).
+    // Assigning rot_inv / rot_inv_trans alone -- a pose and an inverse that do not belong together -- has no
+    // counterpart in the native handle and is refused.
+    void push(const SDF* sdf) {
+        if (isKFilled && !(K == seen_K_)) set_K(Eigen::Matrix3d(K));
+        if (!(rot == seen_rot_) || !(trans == seen_trans_)) {
+            Eigen::Matrix3d r = rot; Eigen::Vector3d t = trans;
+            set_camera_transformation(r, t);
+        } else if (!(rot_inv == seen_rot_inv_) || !(rot_inv_trans == seen_rot_inv_trans_)) {
+            throw Error(TSDF_E_BADARG, "CameraTracking: rot_inv / rot_inv_trans were assigned without rot / trans");
+        }
+        (void)sdf;
     }
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 
 private:
+    struct FrameToken {                    // identifies "the cloud estimate_new_position uploaded"
+        bool valid;
+        const void* points; uint32_t w, h; int64_t serial; uint64_t sum;
+        FrameToken() : valid(false), points(nullptr), w(0), h(0), serial(-1), sum(0) {}
+        FrameToken(const pcl::PointCloud<pcl::PointXYZRGB>& c, int64_t serial_)
+            : valid(true), points(c.points.data()), w(c.width), h(c.height), serial(serial_), sum(0) {
+            const size_t n = c.points.size();
+            const unsigned char* b = reinterpret_cast<const unsigned char*>(c.points.data());
+            for (int k = 0; k < 32 && n; ++k) {            // 32 points spread over the array: FNV-1a over their 16 payload bytes
+                const size_t i = (n - 1) * (size_t)k / 31;
+                for (size_t q = 0; q < 16; ++q) sum = (sum ^ b[i * sizeof(pcl::PointXYZRGB) + q]) * 1099511628211ull;
+            }
+        }
+        bool operator==(const FrameToken& o) const {
+            return valid && o.valid && points == o.points && w == o.w && h == o.h && serial == o.serial && sum == o.sum;
+        }
+    };
     tsdf_shim::CameraTracking impl_;
-    const void* tracked_points_ = nullptr;
-    uint32_t tracked_w_ = 0, tracked_h_ = 0;
+    FrameToken token_;
+    Eigen::Matrix3d seen_rot_, seen_rot_inv_, seen_K_;
+    Eigen::Vector3d seen_trans_, seen_rot_inv_trans_;
 };
 
 inline void SDF::update(CameraTracking* camera_tracking, pcl::PointCloud<pcl::PointXYZRGB>::Ptr cloud_filtered,
                         pcl::PointCloud<pcl::Normal>::Ptr normals) {
-    const bool reuse = camera_tracking && camera_tracking->take_tracked(*cloud_filtered);
+    if (camera_tracking) camera_tracking->push(this);
+    const bool reuse = camera_tracking && camera_tracking->take_tracked(this, *cloud_filtered);
     check(tsdf_set_frame_aos(handle(), reuse ? nullptr : cloud_filtered->points.data(), normals->points.data(), &pcl_layout(),
                              (int32_t)cloud_filtered->width, (int32_t)cloud_filtered->height), "tsdf_set_frame_aos");
     tsdf_shim::SDF::update(camera_tracking ? camera_tracking->impl() : nullptr);

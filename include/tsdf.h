@@ -125,6 +125,10 @@ int  tsdf_get_config(const tsdf_handle *h, tsdf_config *cfg);
 /* ---- camera state ------------------------------------------------------------------------ */
 int tsdf_set_intrinsics(tsdf_handle *h, const double K[9]);
 int tsdf_set_camera_transformation(tsdf_handle *h, const double rot[9], const double trans[3]);
+/* The four constants of CameraTracking::CameraTracking (camera_tracking.cpp:3-18, definition order: iterations,
+ * signed stop threshold, v_h in voxels, w_h in radians) after creation: the reference takes them in the tracker's
+ * constructor, i.e. after the SDF exists.  On a sharded volume a larger w_h needs a larger halo (TSDF_E_HALO says so). */
+int tsdf_set_tracker_params(tsdf_handle *h, int32_t gn_max_iter, float max_twist_diff, float v_h, float w_h);
 int tsdf_get_pose(const tsdf_handle *h, double rot[9], double trans[3],
                   double rot_inv[9], double rot_inv_trans[3]);    /* any pointer may be NULL */
 
@@ -141,6 +145,10 @@ int tsdf_set_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uin
                    int32_t width, int32_t height);
 int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb,
                           int32_t width, int32_t height);
+/* Number of frames made current so far (every successful tsdf_set_frame* / tsdf_set_depth_frame adds one; -1 for a
+ * NULL handle): lets a caller that uploads a cloud for estimate_new_position check, at SDF::update time
+ * (sdf_reconstruction.cpp:70,74), that the frame in the library is still that upload. */
+int64_t tsdf_frame_serial(const tsdf_handle *h);
 
 /* The frame in the reference's OWN format: arrays of point structs, as pcl::PointCloud<pcl::PointXYZRGB>::points and
  * pcl::PointCloud<pcl::Normal>::points hold them (sdf_reconstruction.cpp:33-49; PCL pads both to 32 bytes) -- any

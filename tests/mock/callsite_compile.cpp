@@ -50,6 +50,19 @@ struct Node {
         (void)sdf->m; (void)sdf->m_div_width; (void)sdf->get_number_of_voxels();
         (void)this->camera_tracking->rot_inv(0, 0); (void)this->camera_tracking->rot_inv_trans(0); (void)this->camera_tracking->K(2, 2);
     }
+
+    // not in sdf_reconstruction.cpp, but legal against the reference's headers: the pose fields are plain public members
+    // (camera_tracking.h:43-59), the tracker takes any constants (camera_tracking.cpp:3-4)
+    void other_callers(pcl::PointCloud<pcl::PointXYZRGB>::Ptr cloud_filtered, pcl::PointCloud<pcl::Normal>::Ptr normals,
+                       Matrix3d rotMat, Vector3d trans) {
+        this->camera_tracking->rot = rotMat;                                             // written through at the next hot call
+        this->camera_tracking->trans = trans;
+        this->camera_tracking->K(0, 0) = 520.0;
+        sdf->update(this->camera_tracking, cloud_filtered, normals);
+        CameraTracking* coarse = new CameraTracking(5, 0.002, 0.5, 0.02, sdf);           // other constants than the SDF's defaults
+        coarse->estimate_new_position(sdf, cloud_filtered);
+        delete coarse;
+    }
 };
 
 int main() {

@@ -11,13 +11,17 @@ import numpy as np
 F = np.float32
 
 
+MAX_DEPTH = F(1000.0)          # a depth is a measurement when 0 < z < MAX_DEPTH (zero / negative / NaN / +inf / absurd: no reading)
+SPLAT_MAX_DEPTH_CELLS = 4096
+
+
 def depth_to_z(depth, scale):
     if depth.dtype == np.uint16:
         z = depth.astype(F) * F(scale)
-        z[depth == 0] = np.nan
     else:
         z = depth.astype(F).copy()
-        z[~(z > 0)] = np.nan
+    with np.errstate(invalid="ignore"):
+        z[~((z > 0) & (z < MAX_DEPTH))] = np.nan
     return z
 
 
@@ -72,6 +76,13 @@ def bilateral_grid(z, sigma_s, sigma_r):
         return z.copy()
     zv = z[valid]
     zmin, zmax = zv.min(), zv.max()
+    nz_limit = F(SPLAT_MAX_DEPTH_CELLS - 1 - 2 * P)
+    if not F(zmax - zmin) / sr < nz_limit:
+        # the range does not fit the depth cells of a cell column: keep the near part, drop the pixels behind it
+        zmax = F(zmin + F(sr * F(nz_limit - F(1.0))))
+        with np.errstate(invalid="ignore"):
+            valid = valid & (z < zmax)
+        zv = z[valid]
     gx = int(F(w - 1) / ss) + 1 + 2 * P
     gy = int(F(h - 1) / ss) + 1 + 2 * P
     gz = int(F(zmax - zmin) / sr) + 1 + 2 * P

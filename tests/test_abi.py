@@ -31,8 +31,9 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_struct_layouts_match_header():
     # tsdf_config: 4+3*4 = 16, origin (8-aligned) 24, then 4*... -> check against a hand computation
-    assert C.sizeof(ts.Config) == 96
-    assert ts.Config.origin.offset == 16 and ts.Config.delta.offset == 40 and ts.Config.device.offset == 88
+    assert C.sizeof(ts.Config) == 96           # (carry_threads took the padding word in front of the 8-aligned end)
+    assert ts.Config.origin.offset == 16 and ts.Config.delta.offset == 40 and ts.Config.carry_threads.offset == 72
+    assert ts.Config.device.offset == 92
     assert C.sizeof(ts.IntegrateStats) == 24 and C.sizeof(ts.AccumStats) == 48
     assert C.sizeof(ts.TrackStats) == 64 and C.sizeof(ts.Timing) == 48 and C.sizeof(ts.Counters) == 72
 
@@ -44,7 +45,7 @@ def test_default_config_is_the_reference_constants():
     assert c.delta == np.float32(0.3) and c.epsilon == np.float32(0.025)
     assert (c.gn_max_iter, c.v_h, c.pixel_stride) == (20, 1.0, 3)                # :88, camera_tracking.cpp:162
     assert c.max_twist_diff == np.float32(0.001) and c.w_h == np.float32(0.01)
-    assert c.stale_carry == 1 and c.with_color == 1
+    assert c.stale_carry == 1 and c.carry_threads == 1 and c.with_color == 1
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -67,6 +67,19 @@ def test_exact_type_call_sites_give_the_same_trajectory_as_the_plain_shim(tmp_pa
 
 
 @pytest.mark.gpu
+def test_exact_type_shim_field_writes_constructor_constants_and_cloud_token(tmp_path):
+    """Traps beyond sdf_reconstruction.cpp's own statements (camera_tracking.h:43-63): assigning the public pose / K fields,
+    a CameraTracking built with other constants than the SDF's, a cloud modified in place between the two hot calls."""
+    from dump_frames import dump
+    subprocess.check_call(["make", "-C", ROOT, "-s", "shim_fields_demo"])
+    frames_bin = str(tmp_path / "frames.bin")
+    dump(frames_bin, n=2, width=160, height=120, step=2)
+    p = subprocess.run([os.path.join(ROOT, "build", "shim_fields_demo"), frames_bin, "64"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("ok ") == 3 and "FAIL" not in p.stdout
+
+
+@pytest.mark.gpu
 def test_shim_demo_frame_loop_matches_oracle(tmp_path):
     import oracle as orc
     from dump_frames import dump

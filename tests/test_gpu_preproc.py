@@ -86,6 +86,37 @@ def test_float_depth_input_and_pipeline_runs_from_depth_only():
     s.close()
 
 
+@pytest.mark.parametrize("grid_filter", [1, 0])
+def test_infinite_and_far_depths_are_no_readings(grid_filter):
+    """ROS float depth images mark 'too far' with +inf (REP-117); one such pixel, or one at 2000 m, must not cost the
+    frame: they are treated like NaN / 0.  A finite outlier whose range needs more depth cells than a cell column of
+    the bilateral grid holds (here 300 m at sigma_r 0.05) drops out of the filter, the near scene is still filtered --
+    all of it exactly as the NumPy statement does."""
+    import tracking_sdf_amd as ts
+    w, h = 96, 72
+    seq, z, rgb = depth_image(w, h, to_u16=False)
+    z = z.copy()
+    z[3, 5] = np.inf; z[4, 7] = -np.inf; z[10, 11] = 2000.0; z[20, 30] = 300.0; z[21, 31] = np.nan
+    s = ts.SDF(32)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    params = dict(sigma_s=4.0, sigma_r=0.05, radius=6, normal_radius=2, grid_filter=grid_filter)
+    s.set_depth_frame(z, rgb, **params)
+    xyz, nrm = s.get_preprocessed()
+    want_xyz, want_n = ref.preprocess(z, seq.K, depth_scale=1.0, **params)
+    for (r, c) in ((3, 5), (4, 7), (10, 11), (21, 31)):
+        assert np.isnan(xyz[r, c, 2])
+    assert np.array_equal(np.isnan(xyz[..., 2]), np.isnan(want_xyz[..., 2]))
+    ok = ~np.isnan(want_xyz[..., 2])
+    assert ok.mean() > 0.8
+    if grid_filter:
+        assert np.isnan(xyz[20, 30, 2])                       # beyond the grid's depth cells: dropped
+        assert np.array_equal(xyz[..., 2][ok], want_xyz[..., 2][ok])
+    else:
+        assert np.max(np.abs(xyz[..., 2][ok] - want_xyz[..., 2][ok]) / want_xyz[..., 2][ok]) < 2e-6
+    s.close()
+
+
 def test_preproc_argument_checks():
     import tracking_sdf_amd as ts
     s = ts.SDF(32)
@@ -102,9 +133,9 @@ def test_preproc_argument_checks():
             s.set_depth_frame(d, **bad)
         assert ei.value.code == ts.E_BADARG
     deep = np.zeros((48, 64), dtype=np.float32); deep[0, 0] = 1.0; deep[1, 1] = np.inf
-    with pytest.raises(ts.TsdfError) as ei:
-        s.set_depth_frame(deep)                            # an infinite depth range is not a grid
-    assert ei.value.code == ts.E_BADARG
+    s.set_depth_frame(deep)                                # +inf is 'no reading' (REP-117), not an infinite depth range
+    xyzd, _ = s.get_preprocessed()
+    assert xyzd[0, 0, 2] == np.float32(1.0) and np.isnan(xyzd[..., 2]).sum() == 48 * 64 - 1
     one = np.zeros((48, 64), dtype=np.uint16); one[20, 30] = 5000
     s.set_depth_frame(one)                                 # a single valid pixel filters to itself
     xyz1, _ = s.get_preprocessed()

@@ -87,3 +87,22 @@ def test_separable_box_sums_equal_the_window_sums():
         if m @ xyz[y, x] > 0:
             m = -m
         assert np.dot(m, n[y, x]) > 1 - 1e-5
+
+
+def test_infinite_and_far_depths_are_no_readings():
+    """+inf / -inf / absurd ranges are 'no reading' like 0 and NaN; an outlier that needs more depth cells than the grid has
+    is dropped from the grid filter and the rest of the image is filtered as if it were not there."""
+    rng = np.random.default_rng(3)
+    z = (1.5 + 0.01 * rng.standard_normal((40, 50))).astype(np.float32)
+    z0 = ref.depth_to_z(z.copy(), 1.0)
+    base = ref.bilateral_grid(z0, 4.0, 0.05)
+    z[2, 3] = np.inf; z[5, 6] = -np.inf; z[7, 8] = 2000.0; z[9, 10] = 0.0
+    zz = ref.depth_to_z(z, 1.0)
+    assert np.isnan(zz[2, 3]) and np.isnan(zz[5, 6]) and np.isnan(zz[7, 8]) and np.isnan(zz[9, 10])
+    assert np.isfinite(zz).sum() == z.size - 4
+    z[20, 30] = 300.0                                   # (300 - 1.5) / 0.05 = 5970 cells > 4091
+    zz = ref.depth_to_z(z, 1.0)
+    out = ref.bilateral_grid(zz, 4.0, 0.05)
+    assert np.isnan(out[20, 30]) and np.isfinite(out).sum() == z.size - 5
+    ok = np.isfinite(out)
+    assert np.max(np.abs(out[ok] - base[ok])) < 2e-3     # the rest of the image is filtered as before (blur reach aside)

@@ -25,6 +25,7 @@ OK, E_BADARG, E_NO_DEVICE, E_HIP, E_NO_INTRINSICS, E_NO_FRAME, E_SINGULAR, E_NO_
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 RED_WIDTH = 34
 RED_ALLREDUCE = 30
+ABI_VERSION = 2          # TSDF_ABI_VERSION of include/tsdf.h this module mirrors (struct layouts)
 
 
 class TsdfError(RuntimeError):
@@ -101,7 +102,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p
 # every symbol include/tsdf.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
-    "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_get_pose", "tsdf_set_frame",
+    "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_set_tracker_params", "tsdf_get_pose", "tsdf_set_frame",
+    "tsdf_frame_serial",
     "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
@@ -134,6 +136,9 @@ def lib():
         raise TsdfError(E_NO_DEVICE, f"{_LIB_PATH} not built: run `make` (hipcc --offload-arch=gfx950); "
                                      "there is no CPU fallback")
     L = C.CDLL(_LIB_PATH)
+    L.tsdf_abi_version.restype = C.c_int
+    if L.tsdf_abi_version() != ABI_VERSION:      # struct layouts differ between versions: refuse a mismatched library
+        raise TsdfError(E_BADARG, f"{_LIB_PATH} has ABI version {L.tsdf_abi_version()}, this binding is for {ABI_VERSION}: rebuild (`make`)")
     H = C.c_void_p
     dp, fp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
     sig = {
@@ -146,6 +151,8 @@ def lib():
         "tsdf_get_config": (C.c_int, [H, C.POINTER(Config)]),
         "tsdf_set_intrinsics": (C.c_int, [H, dp]),
         "tsdf_set_camera_transformation": (C.c_int, [H, dp, dp]),
+        "tsdf_set_tracker_params": (C.c_int, [H, C.c_int32, C.c_float, C.c_float, C.c_float]),
+        "tsdf_frame_serial": (C.c_int64, [H]),
         "tsdf_get_pose": (C.c_int, [H, dp, dp, dp, dp]),
         "tsdf_set_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
         "tsdf_set_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
@@ -556,8 +563,8 @@ class CameraTracking:
     """The reference's ``class CameraTracking`` (camera_tracking.h:12-105).
 
     Constructor arguments follow the *definition* (camera_tracking.cpp:3-4):
-    ``(gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf)``; the steps are applied when the
-    volume handle is created, so they are taken from ``sdf`` and only checked here.
+    ``(gauss_newton_max_iteration, maximum_twist_diff, v_h, w_h, sdf)``; constants that differ from the ones the
+    volume handle was created with reconfigure it (tsdf_set_tracker_params), as the reference's constructor accepts any.
     Pose state lives in the same native handle as the volume.
     """
 
@@ -568,7 +575,8 @@ class CameraTracking:
         want = (int(gauss_newton_max_iteration), np.float32(maximum_twist_diff), np.float32(v_h), np.float32(w_h))
         have = (int(c.gn_max_iter), np.float32(c.max_twist_diff), np.float32(c.v_h), np.float32(c.w_h))
         if want != have:
-            raise ValueError(f"tracker constants {want} differ from the ones the volume was created with {have}")
+            sdf._check(lib().tsdf_set_tracker_params(sdf._h, want[0], C.c_float(want[1]), C.c_float(want[2]), C.c_float(want[3])))
+            lib().tsdf_get_config(sdf._h, C.byref(sdf.cfg))
         self.sdf = sdf
         self.isKFilled = False
 

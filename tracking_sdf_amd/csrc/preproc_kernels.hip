@@ -41,6 +41,11 @@ constexpr int kSplatMaxDepthCells = 4096; // depth cells of one (x, y) cell colu
 
 __device__ __forceinline__ bool nan_f(float f) { return f != f; }
 
+// A depth is a measurement when it is a positive number below kMaxDepthMetres: zero / negative / NaN mean "no
+// reading", and so do +inf ("too far" in ROS float images, REP-117) and absurd ranges.
+constexpr float kMaxDepthMetres = 1000.0f;
+__device__ __forceinline__ bool depth_ok(float v) { return v > 0.0f && v < kMaxDepthMetres; }
+
 // ---- depth (uint16 * scale, or float metres) -> z plane
 __global__ __launch_bounds__(256) void depth_to_z_kernel(const uint16_t* __restrict__ d16, const float* __restrict__ dflt,
                                                           float scale, int n, float* __restrict__ z) {
@@ -48,9 +53,9 @@ __global__ __launch_bounds__(256) void depth_to_z_kernel(const uint16_t* __restr
     if (i >= n) return;
     const float qnan = __int_as_float(0x7fc00000);
     float v;
-    if (d16) { const uint16_t r = d16[i]; v = r ? (float)r * scale : qnan; }
-    else { v = dflt[i]; if (!(v > 0.0f)) v = qnan; }
-    z[i] = v;
+    if (d16) { const uint16_t r = d16[i]; v = (float)r * scale; }
+    else v = dflt[i];
+    z[i] = depth_ok(v) ? v : qnan;
 }
 
 // ---- the same, plus min / max of the valid depths (positive floats order like their bit patterns):
@@ -68,12 +73,13 @@ __global__ __launch_bounds__(256) void depth_to_z_minmax_kernel(const uint16_t* 
             const unsigned r[4] = {q.x, q.y, q.z, q.w};
             for (int k = 0; k < 4; ++k) {
                 const unsigned a = r[k] & 0xffffu, b = r[k] >> 16;
-                v[2 * k] = a ? (float)a * scale : qnan; v[2 * k + 1] = b ? (float)b * scale : qnan;
+                v[2 * k] = (float)a * scale; v[2 * k + 1] = (float)b * scale;
             }
+            for (int k = 0; k < 8; ++k) if (!depth_ok(v[k])) v[k] = qnan;
         } else {
             const float4 a = *reinterpret_cast<const float4*>(dflt + i0), b = *reinterpret_cast<const float4*>(dflt + i0 + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            for (int k = 0; k < 8; ++k) if (!(v[k] > 0.0f)) v[k] = qnan;
+            for (int k = 0; k < 8; ++k) if (!depth_ok(v[k])) v[k] = qnan;
         }
         *reinterpret_cast<float4*>(z + i0) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(z + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -81,8 +87,8 @@ __global__ __launch_bounds__(256) void depth_to_z_minmax_kernel(const uint16_t* 
         for (int k = 0; k < 8; ++k) {
             v[k] = qnan;
             if (i0 + k < n) {
-                if (d16) { const uint16_t r = d16[i0 + k]; if (r) v[k] = (float)r * scale; }
-                else { const float f = dflt[i0 + k]; if (f > 0.0f) v[k] = f; }
+                const float f = d16 ? (float)d16[i0 + k] * scale : dflt[i0 + k];
+                if (depth_ok(f)) v[k] = f;
                 z[i0 + k] = v[k];
             }
         }
@@ -357,10 +363,25 @@ hipError_t launch_depth_to_z(hipStream_t s, const uint16_t* d16, const float* df
     return hipGetLastError();
 }
 
+// pixels at or beyond zcut become "no reading" (a frame whose depth range needs more cells than one cell column holds)
+__global__ __launch_bounds__(256) void clip_far_kernel(float* __restrict__ z, int n, float zcut) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && z[i] >= zcut) z[i] = __int_as_float(0x7fc00000);
+}
+
 bool bilateral_grid_plan(int w, int h, float sigma_s, float sigma_r, float zmin, float zmax, BilateralGrid* g) {
-    if (!(sigma_s >= 1.0f) || !(sigma_s <= 30.0f) || !(sigma_r > 0.0f) || !(zmax >= zmin)) return false;
-    const float nz = (zmax - zmin) / sigma_r;
-    if (!(nz < (float)(kSplatMaxDepthCells - 1 - 2 * kGridPad)) || !(zmax < 1024.0f)) return false;
+    if (!(sigma_s >= 1.0f) || !(sigma_s <= 30.0f) || !(sigma_r > 0.0f) || !(zmax >= zmin) || !(zmax < 1024.0f)) return false;
+    float nz = (zmax - zmin) / sigma_r;
+    const float nz_limit = (float)(kSplatMaxDepthCells - 1 - 2 * kGridPad);
+    g->cut = 0; g->zcut = zmax;
+    if (!(nz < nz_limit)) {
+        // the range does not fit the depth cells of a cell column: keep the near part, drop the pixels behind it
+        // (one outlier at 300 m must not cost the frame) -- same rule in tests/preproc_ref.py
+        g->cut = 1;
+        g->zcut = zmin + sigma_r * (nz_limit - 1.0f);
+        nz = (g->zcut - zmin) / sigma_r;
+        if (!(nz < nz_limit)) return false;
+    }
     g->gx = (int)((float)(w - 1) / sigma_s) + 1 + 2 * kGridPad;
     g->gy = (int)((float)(h - 1) / sigma_s) + 1 + 2 * kGridPad;
     g->gz = (int)nz + 1 + 2 * kGridPad;
@@ -376,6 +397,7 @@ hipError_t launch_preproc(hipStream_t s, int w, int h, const float* K /*fx fy cx
     hipError_t e;
     const dim3 grid((w + kTile - 1) / kTile, (h + kTile - 1) / kTile);
     if (bg && R > 0) {
+        if (bg->cut) clip_far_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(const_cast<float*>(z), n, bg->zcut);
         const int cells = bg->gx * bg->gy * bg->gz;
         grid_splat_kernel<<<dim3(bg->gx, bg->gy), dim3(256), (size_t)bg->gz * 12, s>>>(z, w, h, sigma_s, sigma_r, bg->zmin, bg->gy, bg->gz, grid_a);
         grid_blur_kernel<<<dim3((cells + 255) / 256), dim3(256), 0, s>>>(grid_a, grid_b, bg->gx, bg->gy, bg->gz, 0);

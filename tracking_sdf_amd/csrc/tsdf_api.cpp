@@ -116,6 +116,7 @@ struct tsdf_handle {
     unsigned long long* counters_host = nullptr;  // pinned
     unsigned long long* wg_counts = nullptr;      // device: {owned, halo} voxels updated, cumulative, per integrate workgroup
     unsigned long long* wg_counts_host = nullptr; // pinned mirror
+    int64_t frame_serial = 0;      // frames made current so far (tsdf_frame_serial)
     void* worklist = nullptr;      // integrate work items (32-byte descriptors: row << 6 | chunk, the row's share of rot_inv * g)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
     unsigned* rowinfo = nullptr;      // per voxel row: first chunk, chunk count, image band
@@ -396,6 +397,7 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     }
     h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
     h->have_frame = true;
+    h->frame_serial++;
     h->frame_has_nrm = nrm != nullptr;
     h->frame_has_rgb = rgb != nullptr;
     return TSDF_OK;
@@ -864,6 +866,16 @@ int tsdf_set_camera_transformation(tsdf_handle* h, const double rot[9], const do
     return TSDF_OK;
 }
 
+int tsdf_set_tracker_params(tsdf_handle* h, int32_t gn_max_iter, float max_twist_diff, float v_h, float w_h) {
+    if (!h) return TSDF_E_BADARG;
+    if (gn_max_iter < 0 || !(v_h > 0.0f) || !(w_h > 0.0f) || !(max_twist_diff == max_twist_diff))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_tracker_params: bad argument (iterations %d, v_h %g, w_h %g)", gn_max_iter, (double)v_h, (double)w_h);
+    h->cfg.gn_max_iter = gn_max_iter; h->cfg.max_twist_diff = max_twist_diff; h->cfg.v_h = v_h; h->cfg.w_h = w_h;
+    return TSDF_OK;
+}
+
+int64_t tsdf_frame_serial(const tsdf_handle* h) { return h ? h->frame_serial : -1; }
+
 int tsdf_get_pose(const tsdf_handle* h, double rot[9], double trans[3], double rot_inv[9], double rot_inv_trans[3]) {
     if (!h) return TSDF_E_BADARG;
     if (rot) std::memcpy(rot, h->pose.rot, sizeof h->pose.rot);
@@ -877,10 +889,17 @@ int tsdf_get_pose(const tsdf_handle* h, double rot[9], double trans[3], double r
 
 namespace {
 // Is this host pointer page-locked memory HIP can copy from directly (hipHostMalloc / hipHostRegister)?
-bool is_pinned_host(const void* p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+// true when the whole range [p, p + bytes) is page-locked host memory: both ends are asked (a buffer of which only the
+// first part lies in a hipHostRegister'ed range must go through the staging copy)
+bool is_pinned_host(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    const void* ends[2] = {p, static_cast<const char*>(p) + (bytes - 1)};
+    for (const void* q : ends) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
 }
 
 HostPool* host_pool(tsdf_handle* h) {
@@ -946,7 +965,7 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     // Page-locked caller buffers are copied from directly (no staging pass through the library's own pinned buffers:
     // at 640x480 that memcpy is 8.3 MB per frame, longer than the frame's GPU work); the copies are complete when the
     // call returns, so the buffers are borrowed for the call only, as for pageable ones.
-    const bool direct = is_pinned_host(xyz) && (!nrm || is_pinned_host(nrm)) && (!rgb || is_pinned_host(rgb));
+    const bool direct = is_pinned_host(xyz, npix * 12) && (!nrm || is_pinned_host(nrm, npix * 12)) && (!rgb || is_pinned_host(rgb, npix * 3));
     // the pinned staging buffers may still feed the previous frame's async copies (frame stream only: the
     // integration of the previous frame keeps running on the main stream meanwhile)
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
@@ -1070,7 +1089,7 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
     const size_t dbytes = npix * (depth16 ? sizeof(uint16_t) : sizeof(float));
     const void* dsrc = depth16 ? (const void*)depth16 : (const void*)depthf;
     // page-locked caller buffers are copied from directly, as in tsdf_set_frame
-    const bool direct = is_pinned_host(dsrc) && (!rgb || is_pinned_host(rgb));
+    const bool direct = is_pinned_host(dsrc, dbytes) && (!rgb || is_pinned_host(rgb, npix * 3));
     if (!direct) std::memcpy(h->pin_depth, dsrc, dbytes);
     HIP_TRY(h, hipMemcpyAsync(h->pre_depth, direct ? dsrc : h->pin_depth, dbytes, hipMemcpyHostToDevice, h->fstream));
     HIP_TRY(h, launch_depth_to_z(h->fstream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,

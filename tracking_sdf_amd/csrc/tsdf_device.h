@@ -129,7 +129,8 @@ size_t track_partials_doubles(int32_t n_samples);
 // depth -> z plane; with `minmax` (2 words) also min bits / ~max bits of the valid depths (0xffffffff = none)
 hipError_t launch_depth_to_z(hipStream_t s, const uint16_t* d16, const float* dflt, float scale, int n, float* z,
                              unsigned* minmax);
-struct BilateralGrid { int gx, gy, gz; float zmin; };     // cells per axis (padding included), depth of cell 2
+struct BilateralGrid { int gx, gy, gz; float zmin; int cut; float zcut; };   // cells per axis (padding included), depth of cell 2;
+                                                                              // cut: pixels at or beyond zcut are dropped first
 // false: sigma_s outside [1, 30], or a depth range / sigma_r that is not a sane cell count
 bool bilateral_grid_plan(int w, int h, float sigma_s, float sigma_r, float zmin, float zmax, BilateralGrid* g);
 // bg = nullptr: windowed bilateral of radius R; else the bilateral grid in grid_a / grid_b (gx*gy*gz cells each)
