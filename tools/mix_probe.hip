@@ -1,0 +1,72 @@
+// What does the memory system give for integrate_kernel's access mix with NO arithmetic at all?  (round 3 diagnosis)
+// Per item (as the plant scene at 512^3, profiles/r03_*): two paired record gathers (32 records of 32 bytes each, the
+// records of a run of pixels 1..2 apart in an L2-resident 9.8 MB table), an 8-byte {D,W} load and a 16-byte colour
+// load of a contiguous run of ~34 of the 64 voxels of a random 64-voxel segment of 1 GiB / 2 GiB arrays, and the two
+// stores.  198.8k items over 1280 workgroups x 4 wavefronts, like the kernel.  Modes: 0 = everything, 1 = no gathers,
+// 2 = no volume traffic, 3 = gathers + loads (no stores).  PIPE = 1 prefetches the next item's gathers.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned rnd(unsigned& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+
+template <int MODE, int PIPE>
+__global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned nrec, u2* __restrict__ dw, u4* __restrict__ col,
+                                           unsigned nseg, int items_per_wave, unsigned* __restrict__ out) {
+    const unsigned lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned seed = wave * 2654435761u + 12345u, acc = 0;
+    auto gather_addr = [&](unsigned base, unsigned half_of) {      // record of lane pair, 1..2 records apart
+        const unsigned pair = half_of * 32 + (lane >> 1);
+        return (size_t)((base + pair + (pair >> 1)) % nrec) * 2 + (lane & 1);
+    };
+    unsigned base = rnd(seed) % nrec;
+    u4 ga = u4{0, 0, 0, 0}, gb = ga;
+    if (MODE != 1 && PIPE) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
+    for (int it = 0; it < items_per_wave; ++it) {
+        if (MODE != 1 && !PIPE) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
+        const unsigned seg = __builtin_amdgcn_readfirstlane(rnd(seed) % nseg);
+        const unsigned first = __builtin_amdgcn_readfirstlane(rnd(seed) % 30u);
+        const bool live = lane >= first && lane < first + 34u;
+        acc ^= ga.x + gb.w;                                        // consume the gathers
+        const unsigned nbase = rnd(seed) % nrec;
+        u4 na = u4{0, 0, 0, 0}, nb = na;
+        if (MODE != 1 && PIPE && it + 1 < items_per_wave) { na = rec[gather_addr(nbase, 0)]; nb = rec[gather_addr(nbase, 1)]; }
+        if (MODE != 2) {
+            u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
+            if (live) { d = dw[(size_t)seg * 64 + lane]; c = __builtin_nontemporal_load(&col[(size_t)seg * 64 + lane]); }
+            d.x += acc; c.y ^= d.y;
+            if (MODE != 3 && live) { dw[(size_t)seg * 64 + lane] = d; __builtin_nontemporal_store(c, &col[(size_t)seg * 64 + lane]); }
+            if (MODE == 3) acc ^= d.x + c.y;
+        }
+        base = nbase; ga = na; gb = nb;
+    }
+    if (acc == 0x12345678u) out[wave] = acc;
+}
+
+int main() {
+    const unsigned nrec = 307200, nseg = 2097152;                  // 512^3 / 64 segments
+    u4 *rec, *col; u2* dw; unsigned* out;
+    CHECK(hipMalloc(&rec, (size_t)nrec * 32)); CHECK(hipMalloc(&dw, (size_t)nseg * 512)); CHECK(hipMalloc(&col, (size_t)nseg * 1024));
+    CHECK(hipMalloc(&out, 1 << 20));
+    CHECK(hipMemset(rec, 1, (size_t)nrec * 32)); CHECK(hipMemset(dw, 0, (size_t)nseg * 512)); CHECK(hipMemset(col, 0, (size_t)nseg * 1024));
+    const int blocks = 1280, ipw = 39;                             // 1280 x 4 x 39 = 199.7k items
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    const char* names[4] = {"all", "no_gathers", "no_volume", "no_stores"};
+    for (int rep = 0; rep < 3; ++rep)
+        for (int pipe = 0; pipe < 2; ++pipe)
+            for (int mode = 0; mode < 4; ++mode) {
+                CHECK(hipEventRecord(a));
+                for (int k = 0; k < 10; ++k) {
+#define L(M, P) mix<M, P><<<blocks, 256>>>(rec, nrec, dw, col, nseg, ipw, out)
+                    if (pipe == 0) { if (mode == 0) L(0, 0); if (mode == 1) L(1, 0); if (mode == 2) L(2, 0); if (mode == 3) L(3, 0); }
+                    else { if (mode == 0) L(0, 1); if (mode == 1) L(1, 1); if (mode == 2) L(2, 1); if (mode == 3) L(3, 1); }
+                }
+                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+                if (rep == 2) printf("{\"mode\": \"%s\", \"prefetch_next_gather\": %d, \"us_per_launch\": %.1f}\n", names[mode], pipe, ms * 100.0);
+            }
+    return 0;
+}
