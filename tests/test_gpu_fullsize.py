@@ -108,6 +108,26 @@ def test_slab_of_512_matches_whole_volume_layers():
     slab.close()
 
 
+def surface_samples(s, seq, xyz, m):
+    """SDF values at the voxel positions of a grid of valid pixels of the fused frame, and which of those pixels lie on
+    a smooth piece of surface (no depth step within 3 pixels: a silhouette pixel sees distances of two surfaces mixed)."""
+    rows, cols = np.arange(0, xyz.shape[0], 97), np.arange(0, xyz.shape[1], 89)
+    z = xyz[..., 2]
+    pts, smooth = [], []
+    for r in rows:
+        for c in cols:
+            if not np.isfinite(xyz[r, c, 0]):
+                continue
+            win = z[max(r - 3, 0):r + 4, max(c - 3, 0):c + 4]
+            pts.append(xyz[r, c])
+            smooth.append(bool(np.all(np.isfinite(win)) and np.ptp(win) < 0.03))
+    pts = np.asarray(pts)
+    world = pts.astype(np.float64) @ seq.R[0].T + seq.t[0]
+    vox = (world - np.array([-3.0, -3.0, -0.5])) * (m / np.array([6.0, 6.0, 3.5])) - 0.5
+    val, ok = s.interpolate_distance(vox)
+    return val, ok, np.asarray(smooth)
+
+
 def test_config5_shapes_1280x960_at_1024():
     """Config 5's image size against a 1024^3 volume (8 GiB of D/W on one GPU, no colour lanes): counters and
     samples only -- the volume never leaves the device."""
@@ -121,14 +141,11 @@ def test_config5_shapes_1280x960_at_1024():
     st2 = s.update(t, fr[0][0], fr[0][1])
     assert st1["n_updated"] == st2["n_updated"] and 0.03 < st1["n_updated"] / m ** 3 < 0.2
     # sample the SDF at the voxel positions of some valid pixels: |value| must be below one truncation distance
-    xyz = fr[0][0]
-    pts = xyz[::97, ::89].reshape(-1, 3)
-    pts = pts[np.isfinite(pts[:, 0])]
-    world = pts.astype(np.float64) @ seq.R[0].T + seq.t[0]
-    vox = (world - np.array([-3.0, -3.0, -0.5])) * (m / np.array([6.0, 6.0, 3.5])) - 0.5
-    val, ok = s.interpolate_distance(vox)
-    # surface points sit near the zero crossing (one frame fused; silhouette pixels of the foliage see mixed distances)
-    assert ok.mean() > 0.95 and np.percentile(np.abs(val[ok]), 90) < 0.05 and np.all(np.abs(val[ok]) <= 0.3)
+    val, ok, smooth = surface_samples(s, seq, fr[0][0], m)
+    # surface points sit at the zero crossing (one frame fused): away from silhouettes well inside one voxel diagonal,
+    # everywhere within the truncation distance
+    assert ok.mean() > 0.95 and smooth.mean() > 0.6
+    assert np.all(np.abs(val[ok & smooth]) < 0.03) and np.all(np.abs(val[ok]) <= 0.3)
     s.set_frame(fr[1][0])
     A, b, st = t.accumulate()
     assert st["n_samples"] == 427 * 320 and st["n_ok"] > 100000 and np.array_equal(A, A.T)
@@ -149,13 +166,9 @@ def test_config5_2048_cubed_on_one_gpu():
     st2 = s.update(t, fr[0][0], fr[0][1])
     assert st1["n_voxels"] == m ** 3 and st1["n_updated"] == st2["n_updated"]
     assert 0.03 < st1["n_updated"] / m ** 3 < 0.2
-    xyz = fr[0][0]
-    pts = xyz[::97, ::89].reshape(-1, 3)
-    pts = pts[np.isfinite(pts[:, 0])]
-    world = pts.astype(np.float64) @ seq.R[0].T + seq.t[0]
-    vox = (world - np.array([-3.0, -3.0, -0.5])) * (m / np.array([6.0, 6.0, 3.5])) - 0.5
-    val, ok = s.interpolate_distance(vox)
-    assert ok.mean() > 0.95 and np.percentile(np.abs(val[ok]), 90) < 0.05 and np.all(np.abs(val[ok]) <= 0.3)
+    val, ok, smooth = surface_samples(s, seq, fr[0][0], m)
+    assert ok.mean() > 0.95 and smooth.mean() > 0.6
+    assert np.all(np.abs(val[ok & smooth]) < 0.03) and np.all(np.abs(val[ok]) <= 0.3)
     # voxels at the far corner of the volume (linear index > 2^31) keep their constructor value
     far = np.array([[m - 1.0, m - 1.0, m - 1.0], [m - 2.0, m - 1.0, 5.0]])
     val, ok = s.interpolate_distance(far)

@@ -1543,8 +1543,11 @@ int tsdf_save(tsdf_handle* h, const char* path) {
     hd.width = h->cfg.width; hd.height = h->cfg.height; hd.depth = h->cfg.depth;
     hd.delta = h->cfg.delta; hd.epsilon = h->cfg.epsilon;
     std::memcpy(hd.origin, h->cfg.origin, sizeof hd.origin);
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return fail(h, TSDF_E_BADARG, "tsdf_save: cannot open %s", path);
+    // written next to the destination and renamed over it once complete: a failed save leaves neither a truncated file
+    // with a valid header nor a destroyed earlier checkpoint
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(h, TSDF_E_BADARG, "tsdf_save: cannot open %s", tmp.c_str());
     bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1;
     float* host[4] = {buf.data(), buf.data() + n, buf.data() + 2 * n, buf.data() + 3 * n};
     if (ok) {
@@ -1555,9 +1558,16 @@ int tsdf_save(tsdf_handle* h, const char* path) {
         rc = volume_io(h, true, true, 0, (int64_t)n, host);
         ok = rc == TSDF_OK && std::fwrite(buf.data(), sizeof(float), 4 * n, f) == 4 * n;
     }
+    ok = (std::fflush(f) == 0) && ok;
     ok = (std::fclose(f) == 0) && ok;
-    if (rc) return rc;
-    if (!ok) return fail(h, TSDF_E_BADARG, "tsdf_save: short write to %s", path);
+    if (rc || !ok) {
+        std::remove(tmp.c_str());
+        return rc ? rc : fail(h, TSDF_E_BADARG, "tsdf_save: short write to %s", tmp.c_str());
+    }
+    if (std::rename(tmp.c_str(), path) != 0) {
+        std::remove(tmp.c_str());
+        return fail(h, TSDF_E_BADARG, "tsdf_save: cannot rename %s to %s", tmp.c_str(), path);
+    }
     return TSDF_OK;
 }
 
@@ -1596,6 +1606,17 @@ int tsdf_load(tsdf_handle* h, const char* path) {
     const size_t n = (size_t)h->n_stored;
     const long long mm = (long long)g.m * g.m;
     const long long plane_floats = (long long)(hd.xe - hd.xs) * mm, first = (long long)(g.xs - hd.xs) * mm;
+    {
+        // the whole file must be there BEFORE anything is uploaded: a file cut inside its colour part must not leave the
+        // handle with new D / W and old colour
+        const long long want = (long long)sizeof(VolHeader) + plane_floats * (long long)sizeof(float) * (hd.has_color ? 6 : 2);
+        long long have = -1;
+        if (fseeko(f, 0, SEEK_END) == 0) have = (long long)ftello(f);
+        if (have < want || fseeko(f, (off_t)sizeof(VolHeader), SEEK_SET) != 0) {
+            std::fclose(f);
+            return fail(h, TSDF_E_BADARG, "tsdf_load: %s is truncated (%lld of %lld bytes); nothing was loaded", path, have, want);
+        }
+    }
     std::vector<float> buf;
     try { buf.resize(n * 4); } catch (...) { std::fclose(f); return fail(h, TSDF_E_NOMEM, "tsdf_load: out of host memory"); }
     float* host[4] = {buf.data(), buf.data() + n, buf.data() + 2 * n, buf.data() + 3 * n};
@@ -1700,8 +1721,15 @@ int tsdf_comm_init_shm(tsdf_handle* h, int32_t nranks, int32_t rank, const char*
             for (unsigned spins = 0;; ++spins) {
                 if (!joined && __atomic_load_n(shm_hdr(base, kShmHdrMagic), __ATOMIC_ACQUIRE) == kShmMagic) {
                     if (*shm_hdr(base, kShmHdrRanks) != (unsigned long long)nranks) {
-                        munmap(base, bytes);
-                        return fail(h, TSDF_E_COMM, "tsdf_comm_init_shm(%s): segment was made for another number of ranks", name);
+                        // a leftover of a crashed job of another size that rank 0 has not replaced yet: wait for the
+                        // replacement (restart) and fail only if the name still designates this object when time is up
+                        if (replaced()) { restart = true; break; }
+                        if (expired()) {
+                            munmap(base, bytes);
+                            return fail(h, TSDF_E_COMM, "tsdf_comm_init_shm(%s): segment was made for another number of ranks", name);
+                        }
+                        nap();
+                        continue;
                     }
                     gen = *shm_hdr(base, kShmHdrGen);
                     __atomic_store_n(shm_hdr(base, kShmHdrJoined + rank), gen, __ATOMIC_RELEASE);
