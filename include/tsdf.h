@@ -145,6 +145,18 @@ int tsdf_set_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uin
                    int32_t width, int32_t height);
 int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb,
                           int32_t width, int32_t height);
+/* Two-deep frame queue: upload and pack the NEXT frame while the current one is still being tracked and integrated
+ * (the reference's callback has the next cloud in its subscriber queue while it works on the current one,
+ * sdf_reconstruction.cpp:89: queue size 1).  tsdf_queue_frame / tsdf_queue_frame_aos return at once: page-locked
+ * plane buffers are read by the DMA engine, pageable ones (and PCL-style arrays of structs) by a library thread that
+ * repacks them into pinned staging planes with the TSDF_HOST_THREADS pool -- either way the caller's buffers are
+ * BORROWED UNTIL tsdf_next_frame RETURNS and must not change meanwhile.  The hot calls in between (tsdf_track,
+ * tsdf_integrate, tsdf_track_and_integrate) keep working on the current frame.  tsdf_next_frame makes the queued frame
+ * the current one (device-side wait, no host block beyond the end of the host-side repack).  One frame can be queued
+ * at a time, of the same size as the current one; tsdf_set_frame* while a frame is queued is an error.
+ * tsdf_queue_frame_aos needs the points (it has no 'normals only' form). */
+int tsdf_queue_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uint8_t *rgb, int32_t width, int32_t height);
+int tsdf_next_frame(tsdf_handle *h);
 /* Number of frames made current so far (every successful tsdf_set_frame* / tsdf_set_depth_frame adds one; -1 for a
  * NULL handle): lets a caller that uploads a cloud for estimate_new_position check, at SDF::update time
  * (sdf_reconstruction.cpp:70,74), that the frame in the library is still that upload. */
@@ -165,6 +177,8 @@ typedef struct tsdf_aos_layout {
 } tsdf_aos_layout;
 int tsdf_set_frame_aos(tsdf_handle *h, const void *points, const void *normals, const tsdf_aos_layout *layout,
                        int32_t width, int32_t height);
+int tsdf_queue_frame_aos(tsdf_handle *h, const void *points, const void *normals, const tsdf_aos_layout *layout,
+                         int32_t width, int32_t height);   /* see tsdf_queue_frame */
 
 /* ---- optional: depth pre-processing on the GPU.  Replaces, for callers that have a raw
  * depth image instead of PCL clouds, the host-side steps of sdf_reconstruction.cpp:29-49 (cloud conversion,

@@ -131,3 +131,60 @@ def test_staging_thread_count_does_not_change_the_result():
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                                    cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip())
     assert outs[0] and outs[0] == outs[1] == outs[2], outs
+
+
+def run_queued(kind, n=5):
+    """The frame loop with the two-deep queue: frame k+1 is queued before frame k is tracked and integrated."""
+    import torch
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=n, width=W, height=H, noise=True, holes=0.02, step=4)
+    frames = []
+    for k in range(n):
+        xyz, nrm, rgb = seq.frame(k)
+        if kind == "pinned":
+            hold = [torch.from_numpy(a.copy()).pin_memory() for a in (xyz, nrm, rgb)]
+            frames.append(tuple(t.numpy() for t in hold) + (hold,))
+        elif kind == "aos":
+            frames.append(clouds(xyz, nrm, rgb))
+        else:
+            frames.append((np.ascontiguousarray(xyz), np.ascontiguousarray(nrm), np.ascontiguousarray(rgb)))
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+
+    def queue(k):
+        if kind == "aos":
+            s.queue_frame_aos(*frames[k])
+        else:
+            s.queue_frame(*frames[k][:3])
+    poses = []
+    queue(0)
+    for k in range(n):
+        s.next_frame()                            # frame k becomes current
+        if k + 1 < n:
+            queue(k + 1)                          # ... and frame k+1 is staged while k is tracked and integrated
+            with pytest.raises(ts.TsdfError):     # the queue is two deep
+                queue(k + 1)
+        if k > 0:
+            t.estimate_new_position()
+        s.update()
+        poses.append((t.rot.copy(), t.trans.copy()))
+    with pytest.raises(ts.TsdfError):
+        s.next_frame()                            # nothing queued
+    D, Wt = s.download()
+    col = s.download_color()
+    s.close()
+    return poses, D, Wt, col
+
+
+@pytest.mark.parametrize("kind", ["pageable", "pinned", "aos"])
+def test_queued_frames_give_the_same_trajectory_and_volume(kind):
+    """tsdf_queue_frame / tsdf_next_frame: the next frame is uploaded under the current frame's tracker passes and
+    integration; poses and volume must equal the plain set_frame loop bit for bit."""
+    want = run_sequence(planar, n=5)
+    got = run_queued(kind, n=5)
+    for (r0, t0), (r1, t1) in zip(want[0], got[0]):
+        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+    assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2])
+    for a, b in zip(want[3], got[3]):
+        assert np.array_equal(a, b)

@@ -103,7 +103,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p
 ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_set_tracker_params", "tsdf_get_pose", "tsdf_set_frame",
-    "tsdf_frame_serial",
+    "tsdf_frame_serial", "tsdf_queue_frame", "tsdf_queue_frame_aos", "tsdf_next_frame",
     "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
@@ -153,6 +153,9 @@ def lib():
         "tsdf_set_camera_transformation": (C.c_int, [H, dp, dp]),
         "tsdf_set_tracker_params": (C.c_int, [H, C.c_int32, C.c_float, C.c_float, C.c_float]),
         "tsdf_frame_serial": (C.c_int64, [H]),
+        "tsdf_queue_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
+        "tsdf_queue_frame_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32]),
+        "tsdf_next_frame": (C.c_int, [H]),
         "tsdf_get_pose": (C.c_int, [H, dp, dp, dp, dp]),
         "tsdf_set_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
         "tsdf_set_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
@@ -408,6 +411,39 @@ class SDF:
             raise ValueError("organized clouds of shape (height, width) are needed")
         self._check(lib().tsdf_set_frame_aos(self._h, pp, nn, C.byref(lay), shape[1], shape[0]))
         self._frame_shape = tuple(shape)
+
+    def queue_frame(self, xyz, normals=None, rgb=None):
+        """tsdf_queue_frame: stage the NEXT frame while the current one is tracked / integrated.  The arrays are borrowed
+        until next_frame() returns (they are kept alive here); they must already be C-contiguous float32 / uint8."""
+        for a, dt in ((xyz, np.float32), (normals, np.float32), (rgb, np.uint8)):
+            if a is not None and not (a.flags["C_CONTIGUOUS"] and a.dtype == dt):
+                raise ValueError("queue_frame borrows the buffers: C-contiguous float32 / uint8 arrays are needed")
+        h, w = xyz.shape[:2]
+        self._queued_keep = (xyz, normals, rgb)
+        self._check(lib().tsdf_queue_frame(self._h, _fptr(xyz), _fptr(normals) if normals is not None else None,
+                                           rgb.ctypes.data_as(C.POINTER(C.c_uint8)) if rgb is not None else None, w, h))
+
+    def queue_frame_aos(self, points, normals=None):
+        """tsdf_queue_frame_aos: as queue_frame, for arrays of point structs (see set_frame_aos)."""
+        lay = AosLayout(0, 0, -1, -1, -1, 0, 0)
+        f = points.dtype.fields
+        lay.point_stride, lay.xyz_offset = points.dtype.itemsize, f["x"][1]
+        if all(k in f for k in "rgb"):
+            lay.r_offset, lay.g_offset, lay.b_offset = f["r"][1], f["g"][1], f["b"][1]
+        nn = None
+        if normals is not None:
+            g = normals.dtype.fields
+            lay.normal_stride, lay.normal_offset = normals.dtype.itemsize, g["normal_x"][1]
+            nn = C.c_void_p(normals.ctypes.data)
+        if not (points.flags["C_CONTIGUOUS"] and (normals is None or normals.flags["C_CONTIGUOUS"])):
+            raise ValueError("queue_frame_aos borrows the buffers: C-contiguous arrays are needed")
+        self._queued_keep = (points, normals)
+        self._check(lib().tsdf_queue_frame_aos(self._h, C.c_void_p(points.ctypes.data), nn, C.byref(lay), points.shape[1], points.shape[0]))
+
+    def next_frame(self):
+        """tsdf_next_frame: the queued frame becomes the current one; its buffers are the caller's again."""
+        self._check(lib().tsdf_next_frame(self._h))
+        self._queued_keep = None
 
     def set_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
         """Borrow device pointers (ints, e.g. torch.Tensor.data_ptr()) of images already in HBM."""

@@ -117,6 +117,20 @@ struct tsdf_handle {
     unsigned long long* wg_counts = nullptr;      // device: {owned, halo} voxels updated, cumulative, per integrate workgroup
     unsigned long long* wg_counts_host = nullptr; // pinned mirror
     int64_t frame_serial = 0;      // frames made current so far (tsdf_frame_serial)
+    // two-deep frame queue (tsdf_queue_frame / tsdf_next_frame): the NEXT frame is uploaded and packed into the pixel
+    // buffer the current frame does not use while the current one is tracked and integrated
+    struct Queued {
+        bool active = false, direct = false, has_nrm = false, has_rgb = false;
+        int nb = 0;
+        int32_t su = 1, sv = 0;
+        hipError_t err = hipSuccess;       // what the staging thread's HIP calls returned
+    } queued;
+    hipEvent_t ev_queued = nullptr;        // the queued frame's records are packed
+    std::thread qthread;                   // runs the pageable path's staging so that the caller can go on tracking
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::function<void()> qjob;
+    bool qbusy = false, qstop = false;
     void* worklist = nullptr;      // integrate work items (32-byte descriptors: row << 6 | chunk, the row's share of rot_inv * g)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
     unsigned* rowinfo = nullptr;      // per voxel row: first chunk, chunk count, image band
@@ -357,12 +371,27 @@ int timed_end(tsdf_handle* h, EventPair* ep, hipStream_t st) {
 // d(u,v)/dk ~ (K row 0 . c, K row 1 . c) with c = third column of rot_inv (evaluated on the optical
 // axis).  If it moves mostly down the image, store the records column-major so that the gather of 64
 // consecutive k reads neighbouring records; otherwise row-major.  Results do not depend on it.
-void choose_pixel_layout(tsdf_handle* h) {
+void pick_pixel_layout(const tsdf_handle* h, int32_t* su, int32_t* sv) {
     const double* Ri = h->pose.rot_inv;
     const double du = h->have_K ? h->K[0] * Ri[2] + h->K[1] * Ri[5] : Ri[2];
     const double dv = h->have_K ? h->K[3] * Ri[2] + h->K[4] * Ri[5] : Ri[5];
-    if (std::fabs(dv) >= std::fabs(du)) { h->pix_su = h->fh; h->pix_sv = 1; }
-    else { h->pix_su = 1; h->pix_sv = h->fw; }
+    if (std::fabs(dv) >= std::fabs(du)) { *su = h->fh; *sv = 1; }
+    else { *su = 1; *sv = h->fw; }
+}
+void choose_pixel_layout(tsdf_handle* h) { pick_pixel_layout(h, &h->pix_su, &h->pix_sv); }
+
+// make stream `st` wait until the integration that last read pixel buffer nb is done
+int wait_buffer_free(tsdf_handle* h, int nb, hipStream_t st) {
+    if (h->used_valid[nb]) {
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
+    } else if (h->used_untracked[nb]) {
+        // the buffer was last read by an integration that recorded no event (device-resident frames do not pay
+        // for one): order behind everything queued on the main stream, once
+        HIP_TRY(h, hipEventRecord(h->ev_buf_used[nb], h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
+    }
+    h->used_untracked[nb] = false;
+    return TSDF_OK;
 }
 
 // st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
@@ -372,17 +401,8 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
     const bool side = st != h->stream;
-    if (side) {
-        if (h->used_valid[nb]) {
-            HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
-        } else if (h->used_untracked[nb]) {
-            // the buffer was last read by an integration that recorded no event (device-resident frames do not pay
-            // for one): order behind everything queued on the main stream, once
-            HIP_TRY(h, hipEventRecord(h->ev_buf_used[nb], h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
-        }
-        h->used_untracked[nb] = false;
-    }
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first");
+    if (side) { const int rcw = wait_buffer_free(h, nb, st); if (rcw) return rcw; }
     h->frame_side = side;
     EventPair* ep;
     int rc = timed_begin(h, 1, &ep, st);
@@ -736,6 +756,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_queued, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
@@ -788,6 +809,15 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
 void tsdf_destroy(tsdf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->qthread.joinable()) {                           // the staging thread of the frame queue
+        {
+            std::unique_lock<std::mutex> g(h->qmu);
+            h->qcv.wait(g, [&] { return !h->qbusy; });
+            h->qstop = true;
+        }
+        h->qcv.notify_all();
+        h->qthread.join();
+    }
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->comm.destroy();
@@ -801,6 +831,7 @@ void tsdf_destroy(tsdf_handle* h) {
     }
     if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
+    if (h->ev_queued) (void)hipEventDestroy(h->ev_queued);
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
@@ -987,6 +1018,144 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
     if (rc) return rc;
     HIP_TRY(h, hipEventSynchronize(h->ev_copied));      // the caller's buffers have been read
+    return TSDF_OK;
+}
+
+// ---- two-deep frame queue ----------------------------------------------------------------------------------------
+namespace {
+void queue_thread_main(tsdf_handle* h) {
+    (void)hipSetDevice(h->device);
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::unique_lock<std::mutex> g(h->qmu);
+            h->qcv.wait(g, [&] { return h->qstop || h->qjob; });
+            if (h->qstop) return;
+            job.swap(h->qjob);
+        }
+        job();
+        { std::lock_guard<std::mutex> g(h->qmu); h->qbusy = false; }
+        h->qcv.notify_all();
+    }
+}
+
+// what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
+int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
+                       bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
+    if (h->have_frame && (h->fw != width || h->fh != height))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    tsdf_handle::Queued& q = h->queued;
+    q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.err = hipSuccess;
+    pick_pixel_layout(h, &q.su, &q.sv);      // from the pose of this moment: only the order of the records depends on it
+    rc = wait_buffer_free(h, q.nb, h->fstream);
+    if (rc) return rc;
+    float4* const pn = h->pn_buf[q.nb];
+    float4* const smp = h->samples_buf[q.nb];
+    const int32_t stride = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows, with_color = h->cfg.with_color ? 1 : 0;
+    const int32_t su = q.su, sv = q.sv;
+    if (q.direct) {
+        HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+        HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
+        HIP_TRY(h, launch_pack(h->fstream, h->in_xyz, has_nrm ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, width, height, stride,
+                               su, sv, pn, smp, ncols, nrows, with_color));
+        HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
+        q.active = true;
+        return TSDF_OK;
+    }
+    // pageable buffers: the pinned staging planes must be free (they may still feed the previous frame's copies), then a
+    // library thread fills them (with the staging pool) and issues copies and pack while the caller goes on
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    if (!h->qthread.joinable()) {
+        try { h->qthread = std::thread(queue_thread_main, h); }
+        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_frame: cannot start the staging thread"); }
+    }
+    {
+        std::lock_guard<std::mutex> g(h->qmu);
+        h->qbusy = true;
+        h->qjob = [h, npix, has_nrm, has_rgb, fill, width, height, stride, su, sv, pn, smp, ncols, nrows, with_color] {
+            hipError_t e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill);
+            if (e == hipSuccess) e = launch_pack(h->fstream, h->in_xyz, has_nrm ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, width, height,
+                                                 stride, su, sv, pn, smp, ncols, nrows, with_color);
+            if (e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
+            h->queued.err = e;
+        };
+    }
+    h->qcv.notify_all();
+    q.active = true;
+    return TSDF_OK;
+}
+}  // namespace
+
+int tsdf_queue_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
+    if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_queue_frame: bad argument") : TSDF_E_BADARG;
+    const size_t npix = (size_t)width * height;
+    const bool direct = is_pinned_host(xyz, npix * 12) && (!nrm || is_pinned_host(nrm, npix * 12)) && (!rgb || is_pinned_host(rgb, npix * 3));
+    std::function<void(size_t, size_t)> fill;
+    if (!direct) fill = [h, xyz, nrm, rgb](size_t i0, size_t i1) {
+        std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+        if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+        if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
+    };
+    return queue_frame_common(h, xyz, nrm, rgb, width, height, nrm != nullptr, rgb != nullptr, fill);
+}
+
+int tsdf_queue_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height) {
+    if (!h || !L || !points || width <= 0 || height <= 0)
+        return h ? fail(h, TSDF_E_BADARG, "tsdf_queue_frame_aos: bad argument (the points are required)") : TSDF_E_BADARG;
+    const bool color = L->r_offset >= 0 && L->g_offset >= 0 && L->b_offset >= 0;
+    if (L->point_stride < 12 || L->xyz_offset < 0 || L->xyz_offset + 12 > L->point_stride ||
+        (color && (L->r_offset >= L->point_stride || L->g_offset >= L->point_stride || L->b_offset >= L->point_stride)))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame_aos: point layout (stride %d, xyz at %d) does not hold three floats and the colour bytes",
+                    L->point_stride, L->xyz_offset);
+    if (normals && (L->normal_stride < 12 || L->normal_offset < 0 || L->normal_offset + 12 > L->normal_stride))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame_aos: normal layout (stride %d, normal at %d) does not hold three floats",
+                    L->normal_stride, L->normal_offset);
+    const tsdf_aos_layout lay = *L;
+    std::function<void(size_t, size_t)> fill = [h, points, normals, lay, color](size_t i0, size_t i1) {
+        const char* p = (const char*)points + i0 * (size_t)lay.point_stride;
+        for (size_t i = i0; i < i1; ++i, p += lay.point_stride) {
+            std::memcpy(h->pin_xyz + 3 * i, p + lay.xyz_offset, 12);
+            if (color) { h->pin_rgb[3 * i] = (uint8_t)p[lay.r_offset]; h->pin_rgb[3 * i + 1] = (uint8_t)p[lay.g_offset]; h->pin_rgb[3 * i + 2] = (uint8_t)p[lay.b_offset]; }
+        }
+        if (normals) {
+            const char* q = (const char*)normals + i0 * (size_t)lay.normal_stride + lay.normal_offset;
+            for (size_t i = i0; i < i1; ++i, q += lay.normal_stride) std::memcpy(h->pin_nrm + 3 * i, q, 12);
+        }
+    };
+    return queue_frame_common(h, nullptr, nullptr, nullptr, width, height, normals != nullptr, color, fill);
+}
+
+int tsdf_next_frame(tsdf_handle* h) {
+    if (!h) return TSDF_E_BADARG;
+    tsdf_handle::Queued& q = h->queued;
+    if (!q.active) return fail(h, TSDF_E_NO_FRAME, "tsdf_next_frame: no frame is queued");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    q.active = false;
+    if (q.direct) {
+        HIP_TRY(h, hipEventSynchronize(h->ev_copied));       // the caller's buffers have been read
+    } else {
+        std::unique_lock<std::mutex> g(h->qmu);
+        h->qcv.wait(g, [&] { return !h->qbusy; });           // the staging thread is done with the caller's buffers
+        if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
+    }
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
+    h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
+    h->pix_su = q.su; h->pix_sv = q.sv;
+    h->frame_side = true;
+    h->have_frame = true;
+    h->staged_xyz = true;
+    h->frame_serial++;
+    h->frame_has_nrm = q.has_nrm;
+    h->frame_has_rgb = q.has_rgb;
     return TSDF_OK;
 }
 
