@@ -105,7 +105,7 @@ hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const 
 // integrate_blocks_per_cu()).
 size_t integrate_worklist_entries(const Grid& g);
 size_t integrate_worklist_bytes(const Grid& g);      // 32-byte item descriptors (+ slack)
-constexpr size_t kPixelRecordBytes = 32 + 8;         // per pixel: two float4 records + the f64 cosine plane behind them
+constexpr size_t kPixelRecordBytes = 32;             // per pixel: two float4 records (24 of them used when the volume has no colour)
 size_t integrate_row_entries(const Grid& g);
 size_t integrate_bookkeeping_words();
 int integrate_blocks_per_cu();

@@ -67,7 +67,7 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 
 // ------------------------------------------------------------------------------------------------
 // frame packing.  Per pixel one record {Px,Py,Pz, rgb bits} {Nx,Ny,Nz, (float)cosine} (32 bytes; 24 bytes {P,N} for a
-// volume without colour) + the f64 cosine in a plane behind the records (kPixelRecordBytes per pixel in all).  One record
+// volume without colour; kPixelRecordBytes per pixel allocated).  One record
 // per projected voxel instead of scattered plane reads.  Records are stored row-major
 // or column-major (pix_su / pix_sv), whichever makes the pixels hit by 64 consecutive k of one voxel
 // row neighbours in memory: a k-row projects to a near-vertical image line for an upright camera,
@@ -99,11 +99,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
         // with colour: 32-byte records {Px,Py,Pz, rgb bits} {Nx,Ny,Nz, (float)cosine}.  sdf.cpp:294: cosine =
         // |cam_vect . n| / |n| depends on the pixel only; its f32 rounding rides in the record: for the common weight
         // w_new == 1 the colour weight (float)(w_new * cosine) is exactly that ...
+        // (the voxels of the exp() band, whose weight is not 1, recompute the f64 cosine from the normal)
         const double cosine = pixel_cosine(nx, ny, nz);
         pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
         pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)cosine);
-        // ... and its f64 value in a plane behind the records, for the voxels whose weight is not 1 (the exp() band)
-        reinterpret_cast<double*>(pn + 2 * (long long)width * height)[rec] = cosine;
     } else {
         // without colour: 24-byte records {Px,Py,Pz, Nx,Ny,Nz} (a quarter fewer cache lines per gathered pixel run)
         float* const r6 = reinterpret_cast<float*>(pn) + rec * 6;
@@ -432,9 +431,9 @@ constexpr unsigned kDroppedOffset = 0x7fffffffu;     // beyond every buffer: the
 constexpr int kRsrcWord3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
 
 // Per-pixel data of a frame, written by pack_kernel into ONE buffer of kPixelRecordBytes per pixel (record index
-// rec = col*pix_su + row*pix_sv):  with colour  [0, 32 npix) records {Px,Py,Pz,rgb}{Nx,Ny,Nz,(float)cosine},
-// [32 npix, 40 npix) the cosine in f64;  without colour  [0, 24 npix) records {Px,Py,Pz,Nx,Ny,Nz}.
-static_assert(kPixelRecordBytes == 40, "pixel planes");
+// rec = col*pix_su + row*pix_sv):  with colour  [0, 32 npix) records {Px,Py,Pz,rgb}{Nx,Ny,Nz,(float)cosine};
+// without colour  [0, 24 npix) records {Px,Py,Pz,Nx,Ny,Nz}.
+static_assert(kPixelRecordBytes == 32, "pixel records");
 
 // v_cvt_i32_f64 as the hardware does it (saturating, NaN -> 0); a C cast of an out-of-range value is undefined
 __device__ __forceinline__ int cvt_i32_f64_sat(double x) {
@@ -599,18 +598,15 @@ struct GatherState {        // stage 1 done: pixel record requested
     unsigned long long live;   // lane mask (wave-uniform)
     unsigned code;          // the item (wave-uniform)
     double pcx, pcy, pcz;   // camera-frame voxel centre
-    unsigned pix8;          // 8 * biased record index of the lane's pixel (colour: offset into the f64 cosine plane)
     u32x4 A, B;             // halves of the pixel records of lanes 0..31 (A) and 32..63 (B): lane l holds half l&1 of the
                             // record of lane l>>1 (A) / 32 + (l>>1) (B)                 (in flight until stage 2)
 };
 struct UpdateState {        // stage 2 done: volume reads requested
     unsigned long long live;   // lane mask (wave-uniform)
-    unsigned long long band;   // lanes whose weight went through exp() (wave-uniform)
     unsigned code;          // the item (wave-uniform)
     float d_new, w_new;
     unsigned rgb;           // colour: the pixel's packed rgb
-    float wc1;              // colour: (float)cosine, the colour weight for w_new == 1
-    u32x2 C;                // colour: f64 cosine of the pixel, band lanes only  (in flight until stage 3)
+    float wc;               // colour: (float)(w_new * cosine), the colour weight
     unsigned off8;          // byte offset of the lane's {D,W} in the item's segment, kDroppedOffset when dead
     u32x2 old;              // {D, W}            (in flight until stage 3)
     u32x4 col;              // {Color_W, R, G, B} (fused colour; in flight until stage 3)
@@ -662,8 +658,6 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     const long long bias = (long long)pc.su + pc.sv;
     const __amdgpu_buffer_rsrc_t pn_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(pn - bias * kRec), 0, (int)((npix + bias) * kRec), kRsrcWord3);
-    const __amdgpu_buffer_rsrc_t cos_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(pn + npix * 32 - bias * 8), 0, COLOR ? (int)((npix + bias) * 8) : 0, kRsrcWord3);
     const unsigned lane8 = (unsigned)lane * 8u;
     const unsigned half_off = (unsigned)(lane & 1) * (unsigned)kHalf;
     __shared__ u32x4 s_pieces[kIntegrateBlock / 64][128];      // wave-private un-shuffle buffer of the paired gather
@@ -694,7 +688,6 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         if (COLOR) {
             g.A = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)ra, 0, 0);      // piece for LDS slot lane
             g.B = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)rb, 0, 0);      // piece for LDS slot 64 + lane
-            g.pix8 = roff >> 2;                                                      // (a dropped offset stays beyond the plane)
         } else {
             const u32x3 a3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)ra, 0, 0);
             const u32x3 b3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)rb, 0, 0);
@@ -737,18 +730,19 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 #if TSDF_INTEGRATE_DEBUG
         if (p.debug & 2) okm = 0ull;                                        // timing experiment only: no volume RMW
 #endif
-        if (COLOR) {
-            // sdf.cpp:294-299: wc = (float)(w_new * cosine).  For w_new == 1 that is the pre-rounded cosine of the
-            // record; the lanes of the exp() band also fetch the pixel's f64 cosine and stage 3 forms the product.
-            u.C = __builtin_amdgcn_raw_buffer_load_b64(cos_rsrc, (int)select_by_mask(bandm, gin.pix8, dropped), 0, 0);
-            u.rgb = P.w; u.wc1 = __uint_as_float(N.w);
-        }
-        float wn = 1.0f;
-        if (bandm != 0ull)
+        // sdf.cpp:294-299: wc = (float)(w_new * cosine).  For w_new == 1 that is the pre-rounded cosine of the record;
+        // a wavefront with lanes in the exp() band recomputes the f64 cosine from the normal for those lanes.
+        float wn = 1.0f, wc = COLOR ? __uint_as_float(N.w) : 0.f;
+        if (bandm != 0ull) {
             wn = __uint_as_float(select_by_mask(bandm, __float_as_uint(band_weight<EXPPOLY>(d, eps)), 0x3f800000u));
+            if (COLOR)
+                wc = __uint_as_float(select_by_mask(bandm, __float_as_uint((float)((double)wn * pixel_cosine(Nx, Ny, Nz))),
+                                                    __float_as_uint(wc)));
+        }
+        if (COLOR) { u.rgb = P.w; u.wc = wc; }
         d = d < neg_delta ? neg_delta : d;                                  // sdf.cpp:285-287
         u.d_new = d; u.w_new = wn;
-        u.live = okm; u.band = bandm;
+        u.live = okm;
         const unsigned code2 = gin.code;
         u.code = code2;
         long long base2 = (long long)(code2 >> 6) * m + (long long)(code2 & 63u) * 64;
@@ -778,14 +772,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
         const float W = __uint_as_float(uin.old.y), D = __uint_as_float(uin.old.x);
         const float cx = __uint_as_float(uin.col.x);
-        float wc = 0.f;
-        if (COLOR) {
-            wc = uin.wc1;
-            if (uin.band != 0ull) {
-                const double cosd = __hiloint2double((int)uin.C.y, (int)uin.C.x);
-                wc = __uint_as_float(select_by_mask(uin.band, __float_as_uint((float)((double)uin.w_new * cosd)), __float_as_uint(wc)));
-            }
-        }
+        const float wc = COLOR ? uin.wc : 0.f;
         v2f sum1, num1, num2 = v2f{0.f, 0.f};
         sum1.x = W + uin.w_new;
         num1.x = W * D + uin.w_new * uin.d_new;
@@ -835,11 +822,11 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     for (int q = 0; q < NG; ++q) {
         G[q].live = 0ull; G[q].code = 0u;
         G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
-        G[q].A = u32x4{0u, 0u, 0u, 0u}; G[q].B = G[q].A; G[q].pix8 = kDroppedOffset;
+        G[q].A = u32x4{0u, 0u, 0u, 0u}; G[q].B = G[q].A;
     }
 #pragma unroll
     for (int q = 0; q < NU; ++q) {
-        U[q].live = 0ull; U[q].band = 0ull; U[q].code = 0u; U[q].C = u32x2{0u, 0u}; U[q].rgb = 0u; U[q].wc1 = 0.f;
+        U[q].live = 0ull; U[q].code = 0u; U[q].rgb = 0u; U[q].wc = 0.f;
         U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].off8 = kDroppedOffset;
         U[q].old = u32x2{0u, 0x3f800000u}; U[q].col = u32x4{0x3f800000u, 0u, 0u, 0u};
     }
