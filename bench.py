@@ -71,9 +71,11 @@ def parse(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes")
     ap.add_argument("--no-full-sequence", action="store_true")
     ap.add_argument("--no-weak-leg", action="store_true")
-    ap.add_argument("--allreduce", choices=["rccl", "auto", "shm", "torch"], default="rccl",
+    ap.add_argument("--allreduce", choices=["rccl", "auto", "shm", "peer", "torch"], default="rccl",
                     help="exchange step of a Gauss-Newton pass: rccl = in-library RCCL all-reduce (falls back to the "
-                         "shared-memory fan-in only if RCCL fails its self-test); auto = self-test and time both, keep the faster")
+                         "shared-memory fan-in only if RCCL fails its self-test); shm = host-side fan-in through a POSIX "
+                         "shared segment; peer = device-side exchange through HIP-IPC-mapped buffers (tsdf_comm_init_peer); "
+                         "auto = self-test and time all three, keep the fastest")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--timing-period", type=int, default=4, help="HIP events around every n-th integrate/pack launch")
@@ -471,17 +473,22 @@ def run(args):
 
     shm_serial = [0]
 
-    def init_shm(s):
+    def init_shm(s, peer=False):
         shm_serial[0] += 1
         names = [f"/tsdf_{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}_{shm_serial[0]}"]
         dist.broadcast_object_list(names, 0)
         try:
-            s.comm_init_shm(world, rank, names[0])
+            (s.comm_init_peer if peer else s.comm_init_shm)(world, rank, names[0])
             good = True
         except Exception as e:      # noqa: BLE001
-            print(f"[bench] rank {rank}: shared-memory fan-in failed ({e})", file=sys.stderr)
+            print(f"[bench] rank {rank}: {'device-side peer exchange' if peer else 'shared-memory fan-in'} failed ({e})", file=sys.stderr)
             good = False
         return all_agree(good)
+
+    KIND = {"rccl": "rccl-in-library", "shm": "shared-memory fan-in", "peer": "device-side peer exchange"}
+
+    def init_mode(s, mode):
+        return init_rccl(s) if mode == "rccl" else init_shm(s, peer=(mode == "peer"))
 
     def torch_hook(s):
         scratch = torch.zeros(30, dtype=torch.float64, device=cpu_or_dev)
@@ -497,26 +504,25 @@ def run(args):
         rccl -> shm -> torch, except when it was asked for by name on the command line)."""
         s.comm_finalize()
         s.set_allreduce_hook(None)
-        order = {"rccl": ["rccl", "shm"], "shm": ["shm"], "torch": []}[want]
+        order = {"rccl": ["rccl", "shm"], "shm": ["shm"], "peer": ["peer"], "torch": []}[want]
         if args.dist_backend != "nccl" and "rccl" in order and not args.rccl_under_gloo:
             order.remove("rccl")               # ranks may share a GPU under gloo: RCCL refuses that
         for mode in order:
-            ok = init_rccl(s) if mode == "rccl" else init_shm(s)
-            if ok:
+            if init_mode(s, mode):
                 good, _ = probe(s, 4)
                 if all_agree(good):
-                    return {"rccl": "rccl-in-library", "shm": "shared-memory fan-in"}[mode]
+                    return KIND[mode]
             s.comm_finalize()
             dist.barrier()
         torch_hook(s)
         return "torch.distributed-hook"
 
     if world > 1:
-        # time both in-library exchange steps on this machine (reported either way)
-        for mode in ("rccl", "shm"):
+        # time the in-library exchange steps on this machine (reported either way)
+        for mode in ("rccl", "shm", "peer"):
             if mode == "rccl" and args.dist_backend != "nccl" and not args.rccl_under_gloo:
                 continue
-            if (init_rccl(sdf) if mode == "rccl" else init_shm(sdf)):
+            if init_mode(sdf, mode):
                 good, us = probe(sdf)
                 if all_agree(good):
                     exchange_us[mode] = us
@@ -528,8 +534,8 @@ def run(args):
             dist.broadcast_object_list(choice, 0)           # every rank must take the same decision: rank 0's timings
             want = choice[0]
         allreduce_kind = setup_exchange(sdf, want)
-        if args.allreduce == "shm" and not allreduce_kind.startswith("shared"):
-            raise SystemExit("--allreduce shm requested but it failed its self-test")
+        if args.allreduce in ("shm", "peer") and allreduce_kind != KIND[args.allreduce]:
+            raise SystemExit(f"--allreduce {args.allreduce} requested but it failed its self-test")
         if args.allreduce == "rccl" and args.dist_backend == "nccl" and not allreduce_kind.startswith("rccl") and rank == 0:
             print(f"[bench] in-library RCCL failed its self-test; exchange step = {allreduce_kind}", file=sys.stderr)
         comm_state["kind"] = allreduce_kind
@@ -628,15 +634,15 @@ def run(args):
     # ---- N > 1: the same timed region with the other exchange step, for comparison
     def leg_other_exchange():
         lg = state["leg"]
-        kind2 = setup_exchange(lg.sdf, "shm")
-        if kind2.startswith("shared"):
-            lg.restart()
-            e4, _, _ = lg.timed_region(d_frames, events=False)
-            extras["value_with_shared_memory_fan_in"] = args.steps / e4
+        for mode, key in (("shm", "value_with_shared_memory_fan_in"), ("peer", "value_with_device_side_peer_exchange")):
+            if mode in exchange_us and setup_exchange(lg.sdf, mode) == KIND[mode]:
+                lg.restart()
+                e4, _, _ = lg.timed_region(d_frames, events=False)
+                extras[key] = args.steps / e4
         state["kind"] = setup_exchange(lg.sdf, "rccl")
         dist.barrier()
     if world > 1 and not args.no_extras and args.dist_backend == "nccl" and allreduce_kind == "rccl-in-library" \
-            and "shm" in exchange_us:
+            and ("shm" in exchange_us or "peer" in exchange_us):
         guarded("other_exchange", leg_other_exchange)
 
     # ---- full fr1/plant sequence (1246 frames): ATE-RMSE and tracking failures at 256^3 and at the benchmark m
@@ -695,7 +701,7 @@ def run(args):
             leg5 = Leg(m5, w5, h5, seq5.K)
             if world > 1:
                 k = state["kind"]
-                setup_exchange(leg5.sdf, "rccl" if k.startswith("rccl") else ("shm" if k.startswith("shared") else "torch"))
+                setup_exchange(leg5.sdf, {v: k2 for k2, v in KIND.items()}.get(k, "torch"))
             e5, tm5, cn5 = leg5.timed_region(fr5)
             l5 = max(1, cn5["integrate_calls"])
             t5 = max(1, tm5["integrate_launches"])

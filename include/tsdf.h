@@ -279,7 +279,16 @@ int tsdf_comm_init(tsdf_handle *h, int32_t nranks, int32_t rank, const void *id1
  * have joined rank 0 unlinks the name, so nothing is left behind in /dev/shm even if the job dies later.  `name`
  * must be unique among jobs that initialise at the same time (e.g. contain the master port). */
 int tsdf_comm_init_shm(tsdf_handle *h, int32_t nranks, int32_t rank, const char *name);
-int tsdf_comm_finalize(tsdf_handle *h);                          /* drop the RCCL communicator (hook, if any, takes over) */
+/* Device-side alternative for ranks on ONE node (at most 64): no host in the exchange step.  Every rank owns a small
+ * buffer in uncached device memory that every other rank maps through a HIP IPC handle (hipIpcGetMemHandle /
+ * hipIpcOpenMemHandle; over xGMI between GPUs, and two ranks may also share one GPU).  The tracker workgroup that
+ * finishes a rank's 34-double row stores it into its slot of EVERY rank's buffer, releases {generation, pass number}
+ * behind it at system scope, waits for the words of the other ranks in its own buffer and adds the rows in rank
+ * order: the same bits on every rank and as the shared-memory fan-in.  A rank that waits longer than 5 s gives up and
+ * the call that launched the pass returns TSDF_E_COMM.  Rendezvous, `name` and time limit as tsdf_comm_init_shm (the
+ * segment carries the IPC handles); TSDF_E_COMM when the runtime refuses IPC, and nothing is left configured then. */
+int tsdf_comm_init_peer(tsdf_handle *h, int32_t nranks, int32_t rank, const char *name);
+int tsdf_comm_finalize(tsdf_handle *h);                          /* drop the RCCL communicator / the shared segment / the peer mappings (hook, if any, takes over) */
 /* Alternative: let the host do the 28-double sum (e.g. torch.distributed); fn = NULL removes it. */
 int tsdf_set_allreduce_hook(tsdf_handle *h, tsdf_allreduce_fn fn, void *ctx);
 /* Sum-all-reduce n doubles through whichever of the two is configured (identity if neither). */

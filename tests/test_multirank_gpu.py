@@ -31,12 +31,16 @@ def run_bench(extra, nproc, traj, port, env=None):
     return json.loads(line), np.loadtxt(traj)
 
 
-@pytest.mark.parametrize("mode,nproc", [("shm", 2), ("torch", 2), ("shm", 3), ("auto", 2)])
+@pytest.mark.parametrize("mode,nproc", [("shm", 2), ("torch", 2), ("shm", 3), ("auto", 2), ("peer", 2), ("peer", 3)])
 def test_sharded_bench_reproduces_single_rank_trajectory(tmp_path, mode, nproc):
     j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
-    jn, tn = run_bench(["--allreduce", mode], nproc, str(tmp_path / "tn.txt"), 29600 + nproc + {"shm": 7, "torch": 0, "auto": 13}[mode])
+    jn, tn = run_bench(["--allreduce", mode], nproc, str(tmp_path / "tn.txt"), 29600 + nproc + {"shm": 7, "torch": 0, "auto": 13, "peer": 23}[mode])
     assert jn["n_gpus"] == nproc and jn["config"]["halo"] > 0
-    assert ("shared-memory" in jn["config"]["allreduce"]) == (mode in ("shm", "auto"))   # gloo plumbing: RCCL not a candidate
+    kind = jn["config"]["allreduce"]
+    assert {"shm": "shared-memory" in kind, "torch": "torch" in kind, "peer": "peer exchange" in kind,
+            "auto": "shared-memory" in kind or "peer exchange" in kind}[mode]                   # gloo plumbing: RCCL not a candidate
+    if mode == "peer":            # HIP IPC between two processes on the one GPU; its exchange step was timed as well
+        assert jn["config"]["exchange_step_us_measured"]["peer"] > 0
     assert t1.shape == tn.shape and np.array_equal(t1, tn)          # 4-decimal TUM lines, identical
     assert abs(jn["ate_rmse_m"] - j1["ate_rmse_m"]) < 1e-9
     assert jn["gn_iterations_per_frame"] == j1["gn_iterations_per_frame"]

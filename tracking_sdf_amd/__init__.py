@@ -107,7 +107,7 @@ ABI_SYMBOLS = (
     "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
-    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
+    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
 
@@ -186,6 +186,7 @@ def lib():
         "tsdf_comm_unique_id": (C.c_int, [C.c_void_p]),
         "tsdf_comm_init": (C.c_int, [H, C.c_int32, C.c_int32, C.c_void_p]),
         "tsdf_comm_init_shm": (C.c_int, [H, C.c_int32, C.c_int32, C.c_char_p]),
+        "tsdf_comm_init_peer": (C.c_int, [H, C.c_int32, C.c_int32, C.c_char_p]),
         "tsdf_comm_finalize": (C.c_int, [H]),
         "tsdf_set_allreduce_hook": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
         "tsdf_allreduce": (C.c_int, [H, dp, C.c_int32]),
@@ -545,6 +546,9 @@ class SDF:
 
     def comm_init_shm(self, nranks, rank, name: str):
         self._check(lib().tsdf_comm_init_shm(self._h, nranks, rank, name.encode()))
+
+    def comm_init_peer(self, nranks, rank, name: str):
+        self._check(lib().tsdf_comm_init_peer(self._h, nranks, rank, name.encode()))
 
     def comm_finalize(self):
         self._check(lib().tsdf_comm_finalize(self._h))

@@ -195,6 +195,16 @@ struct tsdf_handle {
         bool active() const { return base != nullptr; }
     } shm;
 
+    // device-side exchange between the ranks of one node (tsdf_comm_init_peer); the shared segment above stays open
+    // next to it: it carried the IPC handles
+    struct Peer {
+        int nranks = 0, rank = 0;
+        char* own = nullptr;            // this rank's buffer: nranks x 2 slots of kPeerSlotBytes, uncached device memory
+        std::vector<char*> mapped;      // rank r's buffer as mapped here (mapped[rank] == own)
+        char** bases_dev = nullptr;     // the same pointers on the device
+        bool active() const { return own != nullptr; }
+    } peer;
+
     // tsdf_sample scratch (grown on demand, kept between calls)
     double* sample_vox = nullptr; float* sample_val = nullptr; int32_t* sample_ok = nullptr; size_t sample_cap = 0;
 
@@ -443,8 +453,14 @@ constexpr size_t kShmSlot = 512;   // bytes per (rank, parity) slot: 34 doubles 
 // Segment = header, then nranks x 2 slots.  Header words (8 bytes each): magic, generation, nranks, go, joined[nranks].
 constexpr unsigned long long kShmMagic = 0x5453444653484d31ull;   // "TSDFSHM1"
 enum { kShmHdrMagic = 0, kShmHdrGen = 1, kShmHdrRanks = 2, kShmHdrGo = 3, kShmHdrJoined = 4 };
+// Behind joined[]: one 128-byte entry per rank for tsdf_comm_init_peer (64-byte HIP IPC handle, then a word that
+// turns into the generation once the handle is there, then one that does so once the rank has mapped everybody).
+constexpr size_t kShmPeerEntry = 128;
+inline size_t shm_peer_entries_offset(int nranks) {
+    return (((size_t)kShmHdrJoined + (size_t)nranks) * 8 + kShmPeerEntry - 1) / kShmPeerEntry * kShmPeerEntry;
+}
 inline size_t shm_header_bytes(int nranks) {
-    return (((size_t)kShmHdrJoined + (size_t)nranks) * 8 + kShmSlot - 1) / kShmSlot * kShmSlot;
+    return (shm_peer_entries_offset(nranks) + (size_t)nranks * kShmPeerEntry + kShmSlot - 1) / kShmSlot * kShmSlot;
 }
 inline volatile unsigned long long* shm_hdr(char* base, int word) {
     return reinterpret_cast<volatile unsigned long long*>(base) + word;
@@ -456,6 +472,15 @@ inline size_t shm_slot_offset(const tsdf_handle* h, int rank, unsigned long long
 // run (or another initialisation) can never be taken for this pass
 inline unsigned long long shm_word(const tsdf_handle* h, unsigned long long seq) {
     return (h->shm.gen << 32) | (seq & 0xFFFFFFFFull);
+}
+
+void peer_close(tsdf_handle* h) {
+    for (int r = 0; r < (int)h->peer.mapped.size(); ++r)
+        if (h->peer.mapped[r] && r != h->peer.rank) (void)hipIpcCloseMemHandle(h->peer.mapped[r]);
+    h->peer.mapped.clear();
+    if (h->peer.bases_dev) (void)hipFree(h->peer.bases_dev);
+    if (h->peer.own) (void)hipFree(h->peer.own);
+    h->peer.bases_dev = nullptr; h->peer.own = nullptr; h->peer.nranks = 0;
 }
 
 void shm_close(tsdf_handle* h) {
@@ -495,13 +520,25 @@ int shm_fan_in(tsdf_handle* h, unsigned long long seq, int n) {
     return TSDF_OK;
 }
 
+constexpr int kPeerTimeoutMs = 5000;
+PeerExchange peer_exchange_for(const tsdf_handle* h, unsigned long long seq) {
+    PeerExchange px;
+    px.bases = h->peer.bases_dev;
+    px.n = h->peer.nranks; px.rank = h->peer.rank;
+    px.parity = (unsigned)(seq & 1ull);
+    px.word = shm_word(h, seq);                       // generation of the rendezvous + pass number
+    px.timeout_ticks = (long long)kPeerTimeoutMs * 100000ll;   // wall_clock64(): 100 MHz
+    return px;
+}
+
 // Launch one accumulation pass and wait for its kRedWidth-double result row in h->red_host.
 // reduce_ranks: sum the leading kRedAllreduce entries over ranks (RCCL on the device buffer, or hook).
 int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     TrackParams p;
     fill_track_params(h, p);
     const bool use_rccl = reduce_ranks && h->comm.active();
-    const bool use_shm = reduce_ranks && !use_rccl && h->shm.active();
+    const bool use_peer = reduce_ranks && !use_rccl && h->peer.active();
+    const bool use_shm = reduce_ranks && !use_rccl && !use_peer && h->shm.active();
     const unsigned long long seq = ++h->pass_seq;
     // Where the last workgroup of track_kernel publishes this rank's finished row: pinned host memory (the host then
     // also publishes it into the shared segment with a host store), or -- TSDF_HOST_FOLD=0 -- straight into this rank's
@@ -515,9 +552,13 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.a, h->stream));
     // the row ends up on this host anyway (no in-stream all-reduce, no device-published slot): let the device stop
     // after the shard level and add the <= 8 shard rows here
-    const bool host_fanin = h->host_fanin && h->poll && !use_rccl && !dev_publish_shm && !h->timing_track;
+    const bool host_fanin = h->host_fanin && h->poll && !use_rccl && !use_peer && !dev_publish_shm && !h->timing_track;
+    // device-side exchange: the workgroup that finishes the row swaps it with the other ranks before handing it out
+    PeerExchange px;
+    if (use_peer) px = peer_exchange_for(h, seq);
     HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
-                                   use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq));
+                                   use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq,
+                                   use_peer ? &px : nullptr));
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
     if (use_rccl) {
         std::string cerr;
@@ -562,7 +603,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         // it saves the runtime's completion-signal path.  Bounded: fall back to a real synchronisation.
         volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(h->red_host + kRedWidth);
         const auto t0 = std::chrono::steady_clock::now();
-        const auto limit = std::chrono::milliseconds(use_rccl ? 2000 : 5);
+        const auto limit = std::chrono::milliseconds(use_peer ? kPeerTimeoutMs + 1000 : use_rccl ? 2000 : 5);
         for (unsigned spins = 0;; ++spins) {
             if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > limit) break;
@@ -577,8 +618,14 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         int rc2 = shm_fan_in(h, seq, kRedAllreduce);
         if (rc2) return rc2;
     }
-    if (h->red_host[27] != h->red_host[27])
-        return fail(h, TSDF_E_HIP, "tracker fan-in: a partial row stayed stale through two cache invalidations (hand-off protocol violated)");
+    if (h->red_host[27] != h->red_host[27]) {
+        unsigned long long bits;
+        std::memcpy(&bits, &h->red_host[27], sizeof bits);
+        if (use_peer && bits == kRowPoisonPeerTimeout)
+            return fail(h, TSDF_E_COMM, "peer exchange: not every rank delivered its row of pass %llu within %d ms", seq, kPeerTimeoutMs);
+        return fail(h, TSDF_E_HIP, "tracker fan-in: a partial row stayed stale through two cache invalidations (hand-off protocol violated)%s",
+                    use_peer ? " on one of the ranks" : "");
+    }
     if (h->timing_track) {
         float ms = 0.f;
         hipError_t te = hipEventElapsedTime(&ms, h->ev_track.a, h->ev_track.b);
@@ -821,6 +868,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->comm.destroy();
+    peer_close(h);
     shm_close(h);
     free_frame(h);
     free_preproc(h);
@@ -1831,6 +1879,7 @@ int tsdf_comm_init_shm(tsdf_handle* h, int32_t nranks, int32_t rank, const char*
     int rc = check_ready(h, false);
     if (rc) return rc;
     if (!name || nranks <= 0 || nranks > 4096 || rank < 0 || rank >= nranks) return fail(h, TSDF_E_BADARG, "tsdf_comm_init_shm: bad argument");
+    peer_close(h);
     shm_close(h);
     const size_t header = shm_header_bytes(nranks);
     const size_t bytes = header + (size_t)nranks * 2 * kShmSlot;
@@ -1931,11 +1980,79 @@ int tsdf_comm_init_shm(tsdf_handle* h, int32_t nranks, int32_t rank, const char*
     return TSDF_OK;
 }
 
+// Device-side exchange for the ranks of one node.  Rendezvous = tsdf_comm_init_shm (the segment carries the HIP IPC
+// handles in its header and stays open); then every rank allocates its buffer (uncached device memory, zeroed),
+// publishes the handle, maps everybody else's and waits until everybody has mapped everybody.
+int tsdf_comm_init_peer(tsdf_handle* h, int32_t nranks, int32_t rank, const char* name) {
+    if (!h) return TSDF_E_BADARG;
+    if (nranks > kPeerMaxRanks) return fail(h, TSDF_E_BADARG, "tsdf_comm_init_peer: at most %d ranks (one node)", kPeerMaxRanks);
+    int rc = tsdf_comm_init_shm(h, nranks, rank, name);
+    if (rc) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the header keeps 64 bytes per handle");
+    auto give_up = [&](int code, const char* what, hipError_t e) {
+        std::string msg = std::string("tsdf_comm_init_peer: ") + what + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
+        (void)hipGetLastError();
+        peer_close(h);
+        shm_close(h);
+        return fail(h, code, "%s", msg.c_str());
+    };
+    const size_t bytes = (size_t)nranks * 2 * kPeerSlotBytes;
+    void* own = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&own, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&own, bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) return give_up(TSDF_E_HIP, "no uncached / fine-grained device memory for the exchange buffer", e);
+    h->peer.own = static_cast<char*>(own);
+    h->peer.nranks = nranks; h->peer.rank = rank;
+    h->peer.mapped.assign((size_t)nranks, nullptr);
+    h->peer.mapped[(size_t)rank] = h->peer.own;
+    if ((e = hipMemsetAsync(own, 0, bytes, h->stream)) != hipSuccess || (e = hipStreamSynchronize(h->stream)) != hipSuccess)
+        return give_up(TSDF_E_HIP, "zeroing the exchange buffer", e);
+    hipIpcMemHandle_t mine;
+    if ((e = hipIpcGetMemHandle(&mine, own)) != hipSuccess) return give_up(TSDF_E_COMM, "hipIpcGetMemHandle", e);
+    char* entries = h->shm.base + shm_peer_entries_offset(nranks);
+    auto entry_word = [&](int r, int w) { return reinterpret_cast<volatile unsigned long long*>(entries + (size_t)r * kShmPeerEntry + 64) + w; };
+    const unsigned long long gen = h->shm.gen;
+    std::memcpy(entries + (size_t)rank * kShmPeerEntry, &mine, sizeof mine);
+    *entry_word(rank, 2) = (unsigned long long)getpid();
+    *entry_word(rank, 3) = (unsigned long long)(uintptr_t)own;
+    __atomic_store_n(entry_word(rank, 0), gen, __ATOMIC_RELEASE);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto wait_for = [&](int r, int w) {
+        for (unsigned spins = 0; __atomic_load_n(entry_word(r, w), __ATOMIC_ACQUIRE) != gen; ++spins) {
+            if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return false;
+            struct timespec ts = {0, 100000}; nanosleep(&ts, nullptr);
+        }
+        return true;
+    };
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) continue;
+        if (!wait_for(r, 0)) return give_up(TSDF_E_COMM, "a rank did not publish its buffer within 20 s", hipSuccess);
+        if (*entry_word(r, 2) == (unsigned long long)getpid()) {        // another handle of this very process: no IPC needed (or possible)
+            h->peer.mapped[(size_t)r] = reinterpret_cast<char*>((uintptr_t)*entry_word(r, 3));
+            continue;
+        }
+        hipIpcMemHandle_t theirs;
+        std::memcpy(&theirs, entries + (size_t)r * kShmPeerEntry, sizeof theirs);
+        void* ptr = nullptr;
+        if ((e = hipIpcOpenMemHandle(&ptr, theirs, hipIpcMemLazyEnablePeerAccess)) != hipSuccess)
+            return give_up(TSDF_E_COMM, "hipIpcOpenMemHandle", e);
+        h->peer.mapped[(size_t)r] = static_cast<char*>(ptr);
+    }
+    if ((e = hipMalloc((void**)&h->peer.bases_dev, (size_t)nranks * sizeof(char*))) != hipSuccess ||
+        (e = hipMemcpy(h->peer.bases_dev, h->peer.mapped.data(), (size_t)nranks * sizeof(char*), hipMemcpyHostToDevice)) != hipSuccess)
+        return give_up(TSDF_E_HIP, "pointer table", e);
+    __atomic_store_n(entry_word(rank, 1), gen, __ATOMIC_RELEASE);
+    for (int r = 0; r < nranks; ++r)
+        if (!wait_for(r, 1)) return give_up(TSDF_E_COMM, "a rank did not map the buffers within 20 s", hipSuccess);
+    return TSDF_OK;
+}
+
 int tsdf_comm_finalize(tsdf_handle* h) {
     int rc = check_ready(h, false);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->comm.destroy();
+    peer_close(h);
     shm_close(h);
     return TSDF_OK;
 }
@@ -1957,6 +2074,19 @@ int tsdf_allreduce(tsdf_handle* h, double* buf, int32_t n) {
         if (!h->comm.allreduce_sum_f64(h->red_dev, n, h->stream, &err)) return fail(h, TSDF_E_COMM, "RCCL all-reduce failed: %s", err.c_str());
         HIP_TRY(h, hipMemcpyAsync(buf, h->red_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return TSDF_OK;
+    }
+    if (h->peer.active()) {
+        // through the device, as a tracker pass does it: the row goes to every rank's buffer, the sum comes back
+        const unsigned long long seq = ++h->pass_seq;
+        double row[kRedWidth];
+        for (int e = 0; e < kRedWidth; ++e) row[e] = e < n ? buf[e] : 0.0;
+        HIP_TRY(h, hipMemcpyAsync(h->red_dev, row, sizeof row, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, launch_peer_exchange(h->stream, peer_exchange_for(h, seq), h->red_dev, n, h->red_host, seq));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->red_host[27] != h->red_host[27] && !(n > 27 && buf[27] != buf[27]))
+            return fail(h, TSDF_E_COMM, "peer exchange: not every rank delivered its row within %d ms", kPeerTimeoutMs);
+        std::memcpy(buf, h->red_host, (size_t)n * sizeof(double));
         return TSDF_OK;
     }
     if (h->shm.active()) {

@@ -118,9 +118,29 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit
 // word that receives `word` after the row is complete; host_shards (pinned, may be null): when given, the shard rows go
 // to the host instead (kShardSlotDoubles per shard, word at [kPartWidth]) and the host adds them; `pass` tags the rows.
+// Device-side exchange of the result rows between the ranks of one node (tsdf_comm_init_peer): every rank owns a
+// buffer of n x 2 slots of kPeerSlotBytes (writer rank, pass parity) in uncached device memory, mapped into every other
+// rank through a HIP IPC handle.  The workgroup that finishes a rank's row stores it into its slot of EVERY rank's
+// buffer (its own included), releases the pass word behind it at system scope, waits for the n words of its own buffer
+// and adds the leading kRedAllreduce entries in rank order -- the same order and bits on every rank.
+constexpr size_t kPeerSlotBytes = 512;            // 34 doubles + the word, padded
+constexpr int kPeerMaxRanks = 64;
+struct PeerExchange {
+    char* const* bases = nullptr;   // device array of n pointers: rank r's buffer as mapped into this process
+    int n = 0, rank = 0;            // n == 0: no exchange
+    unsigned parity = 0;            // which slot of the pair this pass uses
+    unsigned long long word = 0;    // what is released behind a row, and waited for
+    long long timeout_ticks = 0;    // wall_clock64() ticks (100 MHz) a rank waits for the others before it gives up
+};
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
-                               unsigned long long word, unsigned long long pass);
+                               unsigned long long word, unsigned long long pass, const PeerExchange* peers = nullptr);
+// the same exchange for a row that is already in red_dev (tsdf_allreduce): one wavefront; n_sum leading entries are added
+hipError_t launch_peer_exchange(hipStream_t s, const PeerExchange& px, double* red_dev, int n_sum, double* host_row,
+                                unsigned long long host_word);
+// NaN bit patterns a row's term count (entry 27) carries when the hand-off failed
+constexpr unsigned long long kRowPoisonStale = 0x7ff8000000000000ull;
+constexpr unsigned long long kRowPoisonPeerTimeout = 0x7ff8000000000001ull;
 int track_num_shards(int32_t n_samples);
 size_t track_fold_counter_words();
 hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* red_host, unsigned long long seq);

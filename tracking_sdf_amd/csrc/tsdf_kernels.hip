@@ -1150,6 +1150,7 @@ struct TrackFold {               // in-launch fan-in of the per-workgroup rows
                                  // (each behind its own word) and the second fan-in level runs there
     unsigned long long word;     // what is released behind host_row once it is complete
     double tag;                  // pass number carried by every row (last column): a stale row cannot pass for a fresh one
+    PeerExchange peers;          // n > 0: the finished row is exchanged with the other ranks before it is handed out
 };
 
 // sc1 (device-scope, L1-bypassing, write-through) accesses for data handed from one workgroup to another inside a
@@ -1160,6 +1161,74 @@ __device__ __forceinline__ void store_sc1(double* p, double v) {
 }
 __device__ __forceinline__ double load_sc1(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wavefront exchanges this rank's row (res, kRedWidth doubles in LDS) with the other ranks of the node and leaves
+// the sum of the leading n_sum entries over ranks, in rank order, in res.  False: a rank did not show up in time.
+// System-scope (sc0 sc1) stores and loads on uncached memory: neither this device's L2s nor a peer's hold a copy.
+__device__ __forceinline__ bool peer_exchange_row(const PeerExchange& px, double* res, int n_sum, int lane) {
+    const size_t mine = ((size_t)px.rank * 2 + px.parity) * kPeerSlotBytes;
+    for (int r = 0; r < px.n; ++r) {
+        double* slot = reinterpret_cast<double*>(px.bases[r] + mine);
+        if (lane < kRedWidth) __hip_atomic_store(&slot[lane], res[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int r = lane; r < px.n; r += 64)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(px.bases[r] + mine + kRedWidth * sizeof(double)), px.word,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // everybody's row of this pass in this rank's own buffer
+    const char* own = px.bases[px.rank];
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    for (int r = lane; r < px.n; r += 64) {
+        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(
+            own + ((size_t)r * 2 + px.parity) * kPeerSlotBytes + kRedWidth * sizeof(double));
+        unsigned spins = 0;                     // second bound, should the clock not be what it is expected to be
+        while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != px.word) {
+            if (wall_clock64() - t0 > px.timeout_ticks || ++spins > (1u << 25)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    ok = __all(ok ? 1 : 0) != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (ok && lane < n_sum) {
+        double v = 0.0;
+        for (int r = 0; r < px.n; ++r)
+            v += __hip_atomic_load(reinterpret_cast<const double*>(own + ((size_t)r * 2 + px.parity) * kPeerSlotBytes) + lane,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        res[lane] = v;
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(64) void peer_exchange_kernel(PeerExchange px, double* __restrict__ red_dev, int n_sum,
+                                                           double* __restrict__ host_row, unsigned long long host_word) {
+    __shared__ double s_row[kRedWidth];
+    const int lane = threadIdx.x;
+    if (lane < kRedWidth) s_row[lane] = red_dev[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const bool ok = peer_exchange_row(px, s_row, n_sum, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < kRedWidth) {
+        double v = s_row[lane];
+        if (!ok && lane == 27) v = __longlong_as_double((long long)kRowPoisonPeerTimeout);
+        red_dev[lane] = v;
+        if (host_row) host_row[lane] = v;
+    }
+    if (host_row) {
+        __threadfence_system();
+        if (lane == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_row + kRedWidth), host_word, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_peer_exchange(hipStream_t s, const PeerExchange& px, double* red_dev, int n_sum, double* host_row,
+                                unsigned long long host_word) {
+    if (px.n <= 0 || px.n > kPeerMaxRanks || n_sum < 0 || n_sum > kRedWidth) return hipErrorInvalidValue;
+    peer_exchange_kernel<<<dim3(1), dim3(64), 0, s>>>(px, red_dev, n_sum, host_row, host_word);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const float2* __restrict__ dw,
@@ -1502,13 +1571,20 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         else if (tid == 33) v = s_tot[kPartSamples];
         // a row that stayed stale through two L1 invalidations: the hand-off protocol is broken; poison the term
         // count so that the host refuses the pass instead of solving with an old row
-        if (stale && tid == 27) v = __longlong_as_double(0x7ff8000000000000ll);
-        if (fold.red_dev) fold.red_dev[tid] = v;
+        if (stale && tid == 27) v = __longlong_as_double((long long)kRowPoisonStale);
+        if (fold.red_dev && fold.peers.n == 0) fold.red_dev[tid] = v;
         s_res[tid] = v;
     }
     // the counters go back to zero for the next pass (launches of one stream are ordered; nobody else is left in this one)
     if (tid <= kTrackShards) __hip_atomic_store(&fold.ctr[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    // several ranks with a device-side exchange: this rank's row goes to every rank, the sum over ranks comes back
+    if (fold.peers.n > 0 && tid < 64) {
+        const bool poisoned = s_res[27] != s_res[27];      // a stale fan-in: the NaN travels through every rank's sum
+        const bool ok = peer_exchange_row(fold.peers, s_res, kRedAllreduce, tid);
+        if (!ok && !poisoned && tid == 27) s_res[27] = __longlong_as_double((long long)kRowPoisonPeerTimeout);
+        if (fold.red_dev && tid < kRedWidth) fold.red_dev[tid] = s_res[tid];
+    }
     // host hand-off without a stream synchronisation: one wave writes the row to pinned host memory, fences at system
     // scope, then releases the word the host spins on
     if (fold.host_row && tid < 64) {
@@ -1545,9 +1621,10 @@ size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blo
 // before the first pass (the kernel re-zeroes them); shard rows live behind the per-workgroup rows in `partials`.
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
-                               unsigned long long word, unsigned long long pass) {
+                               unsigned long long word, unsigned long long pass, const PeerExchange* peers) {
     const int nb = track_num_blocks(p.n_samples);
     if (nb <= 0) return hipErrorInvalidValue;
+    if (peers && (peers->n < 0 || peers->n > kPeerMaxRanks || host_shards)) return hipErrorInvalidValue;
     TrackFold f;
     f.ctr = ctr;
     f.shard_rows = partials + (size_t)nb * kPartWidth;
@@ -1556,6 +1633,7 @@ hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2
     f.host_shards = host_shards;
     f.word = word;
     f.tag = (double)(pass & 0xFFFFFFFFFFFFull);
+    if (peers) f.peers = *peers;
     track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, f);
     return hipGetLastError();
 }
