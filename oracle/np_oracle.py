@@ -107,7 +107,9 @@ class Volume:
             for jo in (0, 1):
                 for ko in (0, 1):
                     ci, cj, ck = bi + io, bj + jo, bk + ko
-                    # fabs(int - float): the int is converted to float, the difference and the sums are float
+                    # sdf.cpp:146 fabs(int - float): the int is converted to float, the difference and the sums are float.
+                    # Float, not C's double fabs, because `using namespace std;` (camera_tracking.h:11, included by
+                    # sdf.h:29 ahead of sdf.cpp) makes the call resolve to the std::fabs(float) overload.
                     vol = (np.abs(ci.astype(f32) - fi) + np.abs(cj.astype(f32) - fj)) + np.abs(ck.astype(f32) - fk)
                     inside = (ci >= 0) & (cj >= 0) & (ck >= 0) & (ci < m) & (cj < m) & (ck < m)       # sdf.h:113-119
                     idx = np.where(inside, (m * m) * ci + m * cj + ck, 0)

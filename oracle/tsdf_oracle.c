@@ -231,7 +231,10 @@ float orc_interpolate_distance(const orc_sdf *s, const double vox[3], int32_t *i
                 cv[0] = trunc_f32(i) + io;
                 cv[1] = trunc_f32(j) + jo;
                 cv[2] = trunc_f32(k) + ko;
-                /* std::fabs(float) overloads: float arithmetic, sdf.cpp:146 */
+                /* sdf.cpp:146 writes fabs(int - float).  That is FLOAT arithmetic, not C's double fabs: sdf.cpp sees
+                 * sdf.h:29 -> camera_tracking.h:11 `using namespace std;` before this line, so the call resolves to
+                 * the std::fabs(float) overload (the int operand is converted to float first, the difference, the
+                 * absolute value and both additions are float).  Do not "fix" this to fabs(): it changes bits. */
                 volume = fabsf(cv[0] - i) + fabsf(cv[1] - j) + fabsf(cv[2] - k);
                 a_idx = orc_get_array_index(s, cv);
                 if (a_idx != -1) {
