@@ -3,7 +3,9 @@
 // records of a run of pixels 1..2 apart in an L2-resident 9.8 MB table), an 8-byte {D,W} load and a 16-byte colour
 // load of a contiguous run of ~34 of the 64 voxels of a random 64-voxel segment of 1 GiB / 2 GiB arrays, and the two
 // stores.  198.8k items over 1280 workgroups x 4 wavefronts, like the kernel.  Modes: 0 = everything, 1 = no gathers,
-// 2 = no volume traffic, 3 = gathers + loads (no stores).  PIPE = 1 prefetches the next item's gathers.
+// 2 = no volume traffic, 3 = gathers + loads (no stores).  PIPE = 1 prefetches the next item's gathers; PIPE = 2 pulls the
+// NEXT item's volume lines (4 x 128 B of {D,W}, 8 of colour) into L2 with scalar loads one item ahead: does a vector
+// load that hits L2 instead of HBM free the CU's vector-memory pipeline sooner?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -24,16 +26,33 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
     };
     unsigned base = rnd(seed) % nrec;
     u4 ga = u4{0, 0, 0, 0}, gb = ga;
-    if (MODE != 1 && PIPE) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
+    if (MODE != 1 && PIPE == 1) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
+    unsigned seg_next = __builtin_amdgcn_readfirstlane(rnd(seed) % nseg);
+    unsigned sink = 0;
     for (int it = 0; it < items_per_wave; ++it) {
-        if (MODE != 1 && !PIPE) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
-        const unsigned seg = __builtin_amdgcn_readfirstlane(rnd(seed) % nseg);
+        if (MODE != 1 && PIPE != 1) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
+        const unsigned seg = seg_next;
+        seg_next = __builtin_amdgcn_readfirstlane(rnd(seed) % nseg);
+        if (PIPE == 2 && MODE != 2) {
+            // one dword of each 128-byte line of the next item's segments, through the scalar cache
+            const char* pd = reinterpret_cast<const char*>(dw) + (size_t)seg_next * 512;
+            const char* pc = reinterpret_cast<const char*>(col) + (size_t)seg_next * 1024;
+            unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                         "s_load_dword %0, %12, 0x0\n\ts_load_dword %1, %12, 0x80\n\ts_load_dword %2, %12, 0x100\n\ts_load_dword %3, %12, 0x180\n\t"
+                         "s_load_dword %4, %13, 0x0\n\ts_load_dword %5, %13, 0x80\n\ts_load_dword %6, %13, 0x100\n\ts_load_dword %7, %13, 0x180\n\t"
+                         "s_load_dword %8, %13, 0x200\n\ts_load_dword %9, %13, 0x280\n\ts_load_dword %10, %13, 0x300\n\ts_load_dword %11, %13, 0x380\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10), "=&s"(t11)
+                         : "s"(pd), "s"(pc) : "memory");
+            sink ^= t0 ^ t1 ^ t2 ^ t3 ^ t4 ^ t5 ^ t6 ^ t7 ^ t8 ^ t9 ^ t10 ^ t11;
+        }
         const unsigned first = __builtin_amdgcn_readfirstlane(rnd(seed) % 30u);
         const bool live = lane >= first && lane < first + 34u;
         acc ^= ga.x + gb.w;                                        // consume the gathers
         const unsigned nbase = rnd(seed) % nrec;
         u4 na = u4{0, 0, 0, 0}, nb = na;
-        if (MODE != 1 && PIPE && it + 1 < items_per_wave) { na = rec[gather_addr(nbase, 0)]; nb = rec[gather_addr(nbase, 1)]; }
+        if (MODE != 1 && PIPE == 1 && it + 1 < items_per_wave) { na = rec[gather_addr(nbase, 0)]; nb = rec[gather_addr(nbase, 1)]; }
         if (MODE != 2) {
             u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
             if (live) { d = dw[(size_t)seg * 64 + lane]; c = __builtin_nontemporal_load(&col[(size_t)seg * 64 + lane]); }
@@ -43,7 +62,7 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
         }
         base = nbase; ga = na; gb = nb;
     }
-    if (acc == 0x12345678u) out[wave] = acc;
+    if ((acc ^ sink) == 0x12345678u) out[wave] = acc;
 }
 
 int main() {
@@ -56,17 +75,18 @@ int main() {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     const char* names[4] = {"all", "no_gathers", "no_volume", "no_stores"};
     for (int rep = 0; rep < 3; ++rep)
-        for (int pipe = 0; pipe < 2; ++pipe)
+        for (int pipe = 0; pipe < 3; ++pipe)
             for (int mode = 0; mode < 4; ++mode) {
                 CHECK(hipEventRecord(a));
                 for (int k = 0; k < 10; ++k) {
 #define L(M, P) mix<M, P><<<blocks, 256>>>(rec, nrec, dw, col, nseg, ipw, out)
                     if (pipe == 0) { if (mode == 0) L(0, 0); if (mode == 1) L(1, 0); if (mode == 2) L(2, 0); if (mode == 3) L(3, 0); }
-                    else { if (mode == 0) L(0, 1); if (mode == 1) L(1, 1); if (mode == 2) L(2, 1); if (mode == 3) L(3, 1); }
+                    else if (pipe == 1) { if (mode == 0) L(0, 1); if (mode == 1) L(1, 1); if (mode == 2) L(2, 1); if (mode == 3) L(3, 1); }
+                    else { if (mode == 0) L(0, 2); if (mode == 1) L(1, 2); if (mode == 2) L(2, 2); if (mode == 3) L(3, 2); }
                 }
                 CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
                 float ms; CHECK(hipEventElapsedTime(&ms, a, b));
-                if (rep == 2) printf("{\"mode\": \"%s\", \"prefetch_next_gather\": %d, \"us_per_launch\": %.1f}\n", names[mode], pipe, ms * 100.0);
+                if (rep == 2) printf("{\"mode\": \"%s\", \"pipe\": %d, \"us_per_launch\": %.1f}\n", names[mode], pipe, ms * 100.0);
             }
     return 0;
 }

@@ -179,6 +179,10 @@ struct tsdf_handle {
     bool host_fanin = true;        // the second level of the tracker fan-in runs on the host (TSDF_HOST_FANIN=0: on the device)
     unsigned integrate_launches = 0;
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
+    // TSDF_TRACK_PROFILE=1: host-side clock of a pass, printed by tsdf_destroy (ns sums: parameters, launch call, wait
+    // for the row, fold + solve + pose)
+    bool track_profile = false;
+    double tp_fill = 0, tp_launch = 0, tp_wait = 0, tp_post = 0; long long tp_passes = 0;
 
     // comm
     rccl::Comm comm;
@@ -534,6 +538,7 @@ PeerExchange peer_exchange_for(const tsdf_handle* h, unsigned long long seq) {
 // Launch one accumulation pass and wait for its kRedWidth-double result row in h->red_host.
 // reduce_ranks: sum the leading kRedAllreduce entries over ranks (RCCL on the device buffer, or hook).
 int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
+    const auto tp0 = h->track_profile ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     TrackParams p;
     fill_track_params(h, p);
     const bool use_rccl = reduce_ranks && h->comm.active();
@@ -556,9 +561,16 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     // device-side exchange: the workgroup that finishes the row swaps it with the other ranks before handing it out
     PeerExchange px;
     if (use_peer) px = peer_exchange_for(h, seq);
+    const auto tp1 = h->track_profile ? std::chrono::steady_clock::now() : tp0;
     HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
                                    use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq,
                                    use_peer ? &px : nullptr));
+    const auto tp2 = h->track_profile ? std::chrono::steady_clock::now() : tp0;
+    if (h->track_profile) {
+        h->tp_fill += std::chrono::duration<double, std::nano>(tp1 - tp0).count();
+        h->tp_launch += std::chrono::duration<double, std::nano>(tp2 - tp1).count();
+        h->tp_passes++;
+    }
     if (h->timing_track) HIP_TRY(h, hipEventRecord(h->ev_track.b, h->stream));
     if (use_rccl) {
         std::string cerr;
@@ -582,6 +594,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
             }
         }
         if (!all) HIP_TRY(h, hipStreamSynchronize(h->stream));      // a shard row did not show up in time: synchronise for real
+        if (h->track_profile) h->tp_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tp2).count();
         // shard order, as the device's last workgroup adds them: the same bits in every exchange mode
         double tot[kPartWidth];
         bool stale = false;
@@ -656,8 +669,23 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
 int fetch_counters(tsdf_handle* h) {
     const size_t nw = 2 * (size_t)h->integrate_blocks;
     HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->wg_counts_host, h->wg_counts, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->wg_counts_host, h->wg_counts, 13 * nw * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->integrate_debug & 256) {       // stage profile of debug builds: shader-clock cycles per pipeline step, first wavefront of every workgroup
+        if (h->integrate_debug & 2048) {     // per workgroup: steps and loop time (10 ns ticks) of its first wavefront, cumulative
+            for (size_t b = 0; b < (size_t)h->integrate_blocks; ++b)
+                std::fprintf(stderr, "WGLOOP %zu %llu %llu\n", b, h->wg_counts_host[nw + 6 * (4 * b) + 3], h->wg_counts_host[nw + 6 * (4 * b) + 5]);
+        }
+        for (int wv = 0; wv < 4; ++wv) {
+            unsigned long long t[6] = {0, 0, 0, 0, 0, 0};
+            for (size_t b = 0; b < (size_t)h->integrate_blocks; ++b)
+                for (int q = 0; q < 6; ++q) t[q] += h->wg_counts_host[nw + 6 * (4 * b + wv) + q];
+            if (t[3])
+                std::fprintf(stderr, "STAGES wave %d steps %llu cycles_per_step S1 %.1f S2 %.1f S3 %.1f loop %.1f (%.3f us per step, %.0f MHz)\n", wv, t[3],
+                             (double)t[0] / t[3], (double)t[1] / t[3], (double)t[2] / t[3], (double)t[4] / t[3], 0.01 * (double)t[5] / t[3],
+                             t[5] ? (double)t[4] / (0.01 * (double)t[5]) : 0.0);
+        }
+    }
     unsigned long long own = 0, halo = 0;
     for (size_t b = 0; b < nw; b += 2) { own += h->wg_counts_host[b]; halo += h->wg_counts_host[b + 1]; }
     if (h->integrate_debug & 4096) {      // load-balance experiment of debug builds: per workgroup {updated voxels, 10 ns ticks}, cumulative
@@ -831,9 +859,10 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
         const int per_cu = env ? std::atoi(env) : integrate_blocks_per_cu();
         h->integrate_blocks = (prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4) + 7) / 8 * 8;   // whole XCD groups
     }
-    CREATE_TRY(hipMalloc((void**)&h->wg_counts, 2 * (size_t)h->integrate_blocks * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemsetAsync(h->wg_counts, 0, 2 * (size_t)h->integrate_blocks * sizeof(unsigned long long), h->stream));
-    CREATE_TRY(hipHostMalloc((void**)&h->wg_counts_host, 2 * (size_t)h->integrate_blocks * sizeof(unsigned long long), hipHostMallocDefault));
+    // 2 words per workgroup (updated voxels: owned, halo) + 4 x 6 more behind them for the stage profile of debug builds
+    CREATE_TRY(hipMalloc((void**)&h->wg_counts, 26 * (size_t)h->integrate_blocks * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(h->wg_counts, 0, 26 * (size_t)h->integrate_blocks * sizeof(unsigned long long), h->stream));
+    CREATE_TRY(hipHostMalloc((void**)&h->wg_counts_host, 26 * (size_t)h->integrate_blocks * sizeof(unsigned long long), hipHostMallocDefault));
     CREATE_TRY(hipMalloc((void**)&h->red_dev, kRedWidth * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->red_host, (kRedWidth + 2) * sizeof(double), hipHostMallocDefault));
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
@@ -842,6 +871,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipHostMalloc((void**)&h->shard_host, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double), hipHostMallocDefault));
     std::memset(h->shard_host, 0, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double));
     { const char* ev = std::getenv("TSDF_HOST_FANIN"); h->host_fanin = !(ev && std::atoi(ev) == 0); }
+    { const char* ev = std::getenv("TSDF_TRACK_PROFILE"); h->track_profile = ev && std::atoi(ev) != 0; }
     CREATE_TRY(hipMalloc((void**)&h->fold_ctr, track_fold_counter_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, track_fold_counter_words() * sizeof(unsigned), h->stream));
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
@@ -856,6 +886,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
 void tsdf_destroy(tsdf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->track_profile && h->tp_passes)
+        std::fprintf(stderr, "TRACKPROFILE passes %lld  ns per pass: parameters %.0f  launch call %.0f  wait for the row %.0f  fold+solve+pose %.0f\n",
+                     h->tp_passes, h->tp_fill / h->tp_passes, h->tp_launch / h->tp_passes, h->tp_wait / h->tp_passes, h->tp_post / h->tp_passes);
     if (h->qthread.joinable()) {                           // the staging thread of the frame queue
         {
             std::unique_lock<std::mutex> g(h->qmu);
@@ -1461,6 +1494,8 @@ int tsdf_track(tsdf_handle* h, tsdf_track_stats* stats) {
     // TSDF_E_NO_SAMPLES / TSDF_E_HALO / TSDF_E_COMM / TSDF_E_HIP "pose left unchanged").
     const hm::Pose entry = h->pose;
     for (g = 0; g < h->cfg.gn_max_iter && !stop; ++g) {            // camera_tracking.cpp:79
+        const auto tq0 = h->track_profile ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        const double waited = h->tp_wait, before = h->tp_fill + h->tp_launch;
         rc = accumulate_pass(h, true);
         if (rc) { h->pose = entry; return rc; }
         n_terms = (int64_t)h->red_host[27];
@@ -1473,6 +1508,9 @@ int tsdf_track(tsdf_handle* h, tsdf_track_stats* stats) {
             h->pose = entry;
             return fail(h, TSDF_E_SINGULAR, "normal equations singular at iteration %d; pose left unchanged", g);
         }
+        if (h->track_profile)      // everything of this pass that was neither parameters, launch nor waiting
+            h->tp_post += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tq0).count() -
+                          (h->tp_wait - waited) - (h->tp_fill + h->tp_launch - before);
     }
     if (stats) {
         stats->iterations = g;

@@ -186,15 +186,59 @@ constexpr int kBins = TSDF_BANDS;
 static_assert(kBins >= 8 && kBins <= 4096 && (kBins & (kBins - 1)) == 0, "bands: a power of two that fits the row word");
 constexpr int kBinSetWords = 2 * kBins + 2;
 
+// Shares of the eight XCDs in the band-sorted work list, adjusted from launch to launch.  Items differ in cost (live
+// lanes, lines touched) and an XCD's band keeps its character from frame to frame; with equal item counts the slowest
+// XCD finished 10-15 % after the fastest.  Feedback block behind the two bookkeeping sets: words [0..8] = share
+// boundaries as fractions of the list in 2^-24 units (0 .. 2^24), then (8-byte aligned) eight 64-bit sums of what the
+// first wavefronts of the XCD's workgroups measured for their item loops in the LAST launch (s_memrealtime ticks).
+// clip_rows_kernel (block 0) turns them into the next boundaries: share ~ items per tick, half-way damped, each
+// share kept within [1/16, 1/4].  Only the schedule depends on it -- every voxel belongs to exactly one item.
+constexpr int kFbWords = 32;
+constexpr int kFbTicksWord = 16;
+constexpr unsigned kFbOne = 1u << 24;
+#ifndef TSDF_XCD_FEEDBACK
+#define TSDF_XCD_FEEDBACK 1
+#endif
+__device__ __forceinline__ void update_xcd_shares(unsigned* fb) {
+    unsigned long long* ticks = reinterpret_cast<unsigned long long*>(fb + kFbTicksWord);
+    if (fb[8] != kFbOne) {                                   // first launch: equal shares
+        for (int x = 0; x <= 8; ++x) fb[x] = (unsigned)x * (kFbOne / 8u);
+    } else if (TSDF_XCD_FEEDBACK) {
+        double rate[8], sum = 0.0;
+        bool ok = true;
+        for (int x = 0; x < 8; ++x) {
+            const double share = (double)(fb[x + 1] - fb[x]);
+            ok &= ticks[x] != 0ull;
+            rate[x] = ok ? share / (double)ticks[x] : 0.0;
+            sum += rate[x];
+        }
+        if (ok && sum > 0.0) {
+            double sh[8], tot = 0.0;
+            for (int x = 0; x < 8; ++x) {
+                const double target = rate[x] / sum, old = (double)(fb[x + 1] - fb[x]) / (double)kFbOne;
+                double v = 0.5 * old + 0.5 * target;
+                v = v < 1.0 / 16.0 ? 1.0 / 16.0 : (v > 0.25 ? 0.25 : v);
+                sh[x] = v; tot += v;
+            }
+            double run = 0.0;
+            for (int x = 0; x < 8; ++x) { fb[x] = (unsigned)(run / tot * (double)kFbOne); run += sh[x]; }
+            fb[0] = 0u; fb[8] = kFbOne;
+        }
+    }
+    for (int x = 0; x < 8; ++x) ticks[x] = 0ull;
+}
+
 // rowinfo word: bit 31 = the row has items, bits 16..27 = band, bits 8..15 = number of chunks, bits 0..7 = first chunk
 __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
                                                                 unsigned* __restrict__ rowinfo,
                                                                 unsigned* __restrict__ set,
-                                                                unsigned* __restrict__ next_set) {
+                                                                unsigned* __restrict__ next_set,
+                                                                unsigned* __restrict__ xcd_fb) {
     const int m = p.g.m;
     const int tid = threadIdx.x;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
     if (blockIdx.x == 0) for (int t = tid; t < kBinSetWords; t += kClipBlock) next_set[t] = 0u;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) update_xcd_shares(xcd_fb);   // (the last launch's integrate kernel is done: same stream)
     __shared__ unsigned s_hist[kBins];
     for (int t = tid; t < kBins; t += kClipBlock) s_hist[t] = 0u;
     __syncthreads();
@@ -631,7 +675,8 @@ template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ count,
     float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
-    unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */) {
+    unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */,
+    unsigned* __restrict__ xcd_fb) {
     constexpr int kRec = COLOR ? 32 : 24, kHalf = kRec / 2;        // bytes of a pixel record / of the piece a lane fetches
     extern __shared__ double s_tab[];
     const int m = p.g.m;
@@ -645,13 +690,18 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     make_proj_const(p, tl, lane, pc);
     // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
     // list = one band of the image, so the pixel records it gathers stay in its own L2.
-    const unsigned vblock = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // The XCD's part of the list [x_lo, x_hi) follows the shares of update_xcd_shares(); its gridDim.x / 8 workgroups
+    // split it evenly.
+    const unsigned xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const unsigned x_lo = (unsigned)(((unsigned long long)n_items * xcd_fb[xcd]) >> 24);
+    const unsigned x_hi = (unsigned)(((unsigned long long)n_items * xcd_fb[xcd + 1]) >> 24);
     // The workgroup's contiguous share of the work list, dealt to its wavefronts ITEM BY ITEM: at any moment the NW
     // wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring voxel rows.
-    const unsigned wg_first = (unsigned)(((unsigned long long)n_items * vblock) / gridDim.x);
-    const unsigned wg_last = (unsigned)(((unsigned long long)n_items * (vblock + 1)) / gridDim.x);
+    const unsigned wg_first = x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * in_xcd) / per_xcd);
+    const unsigned wg_last = x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * (in_xcd + 1)) / per_xcd);
     const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
     unsigned n_own = 0, n_halo = 0;
+    const unsigned long long loop_t0 = __builtin_amdgcn_s_memrealtime();      // for the XCD shares of the next launch
 
     // planes of the frame's pixel data, their bases shifted by the bias of the record index
     const long long npix = (long long)p.width * p.height;
@@ -830,17 +880,51 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         U[q].d_new = 0.f; U[q].w_new = 1.f; U[q].off8 = kDroppedOffset;
         U[q].old = u32x2{0u, 0x3f800000u}; U[q].col = u32x4{0x3f800000u, 0u, 0u, 0u};
     }
+#if TSDF_INTEGRATE_DEBUG
+    // stage profile (bit 256): the first wavefront of every workgroup stamps the shader clock at the stage boundaries
+    // (s_memtime + s_waitcnt lgkmcnt(0), a scheduling barrier for memory operations) and adds up what each stage took
+    unsigned long long t_s1 = 0, t_s2 = 0, t_s3 = 0, n_steps = 0;
+    const bool stamp = (p.debug & 256) != 0 && ((p.debug & 512) != 0 || wv == 0);      // bit 512: every wavefront stamps
+    auto clock_now = [&]() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return t; };
+    unsigned long long rt0 = 0, ct0 = 0;
+    if (stamp) { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) : : "memory"); ct0 = clock_now(); }
+#endif
     for (int j = 0; j < cnt + 1 + TSDF_INTEGRATE_DEPTH; j += PERIOD) {
 #pragma unroll
         for (int q = 0; q < PERIOD; ++q) {
             // S1(j+q) -> G[q%2];  S2(j+q-1): G[(q+1)%2] -> U[q%NU];  S3(j+q-1-DEPTH): U[(q+1)%NU] (the oldest)
+#if TSDF_INTEGRATE_DEBUG
+            if (stamp) {
+                const unsigned long long c0 = clock_now();
+                stage1(j + q, G[q % NG]);
+                const unsigned long long c1 = clock_now();
+                stage2(G[(q + 1) % NG], U[q % NU]);
+                const unsigned long long c2 = clock_now();
+                stage3(U[(q + 1) % NU]);
+                const unsigned long long c3 = clock_now();
+                t_s1 += c1 - c0; t_s2 += c2 - c1; t_s3 += c3 - c2; ++n_steps;
+                continue;
+            }
+#endif
             stage1(j + q, G[q % NG]);
             stage2(G[(q + 1) % NG], U[q % NU]);
             stage3(U[(q + 1) % NU]);
         }
     }
+#if TSDF_INTEGRATE_DEBUG
+    if (stamp && lane == 0) {
+        unsigned long long rt1, ct1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) : : "memory");
+        ct1 = clock_now();
+        // per workgroup and wavefront: cycles in S1, S2, S3, steps, loop cycles, loop time in 10 ns ticks
+        unsigned long long* w = counters + 2 * (size_t)gridDim.x + 6 * ((size_t)blockIdx.x * NW + (size_t)wv);
+        w[0] += t_s1; w[1] += t_s2; w[2] += t_s3; w[3] += n_steps; w[4] += ct1 - ct0; w[5] += rt1 - rt0;
+    }
+#endif
     // (steps run up to j >= cnt + DEPTH, so S3 has retired item cnt-1 inside the loop: nothing to drain)
 
+    if (wv == 0 && lane == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(xcd_fb + kFbTicksWord) + xcd, __builtin_amdgcn_s_memrealtime() - loop_t0 + 1ull);
     // Update counts (wave-uniform already): LDS across the waves, then the workgroup adds to ITS OWN pair of cumulative
     // words (plain read-modify-write, nobody else touches them; the host adds the pairs up when somebody asks).
     __shared__ unsigned s_cnt[2][kIntegrateBlock / 64];
@@ -867,7 +951,8 @@ int integrate_blocks_per_cu() {
     return n;
 }
 
-size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords; }
+size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords + kFbWords; }
+static_assert((2 * kBinSetWords) % 2 == 0, "the 64-bit tick sums of the feedback block must be 8-byte aligned");
 
 static bool make_tiling(const IntegrateParams& p, IntegrateTiling& tl) {
     const int m = p.g.m;
@@ -902,10 +987,12 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     // two bookkeeping sets used alternately (see kBinSetWords)
     unsigned* const cur = work_count + (launch_parity & 1) * kBinSetWords;
     unsigned* const nxt = work_count + ((launch_parity + 1) & 1) * kBinSetWords;
+    unsigned* const xcd_fb = work_count + 2 * kBinSetWords;
+    if (n_blocks < 8 || (n_blocks & 7)) return hipErrorInvalidValue;      // eight XCDs take equal numbers of workgroups
     ItemDesc* const list = static_cast<ItemDesc*>(worklist);
     hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
-    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt);
+    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt, xcd_fb);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, list, counters);
@@ -916,7 +1003,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     const size_t lds = ktab ? (size_t)m * 24 : 0;
     const char* planes = reinterpret_cast<const char*>(pn);
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) \
-    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, dw, crgb, planes, wg_counts)
+    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, dw, crgb, planes, wg_counts, xcd_fb)
 #define TSDF_LAUNCH_INTEGRATE3(C, KS, EP) do { if (ktab) TSDF_LAUNCH_INTEGRATE(C, KS, EP, true); else TSDF_LAUNCH_INTEGRATE(C, KS, EP, false); } while (0)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE3(C, KS, true); else TSDF_LAUNCH_INTEGRATE3(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
