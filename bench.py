@@ -449,12 +449,22 @@ def run(args):
 
     def probe(s, n=40):
         """Self-test + time of one exchange step (sum of 30 doubles over the ranks), microseconds."""
-        got = s.allreduce(np.full(30, float(rank + 1)))
-        good = bool(np.all(got == world * (world + 1) / 2))
+        try:
+            got = s.allreduce(np.full(30, float(rank + 1)))
+            good = bool(np.all(got == world * (world + 1) / 2))
+        except Exception as e:      # noqa: BLE001  (an exchange step that fails here must not take the run down)
+            print(f"[bench] rank {rank}: exchange self-test failed ({e})", file=sys.stderr)
+            good = False
+        if not all_agree(good):     # every rank takes the same branch: a rank that timed the step alone would wait for the others
+            return False, float("inf")
         dist.barrier()
         t0 = perf()
-        for _ in range(n):
-            s.allreduce(np.ones(30))
+        try:
+            for _ in range(n):
+                s.allreduce(np.ones(30))
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] rank {rank}: exchange step failed while being timed ({e})", file=sys.stderr)
+            good = False
         return good, 1e6 * (perf() - t0) / n
 
     def init_rccl(s):

@@ -133,7 +133,6 @@ struct tsdf_handle {
     bool qbusy = false, qstop = false;
     void* worklist = nullptr;      // integrate work items (32-byte descriptors: row << 6 | chunk, the row's share of rot_inv * g)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
-    unsigned* rowinfo = nullptr;      // per voxel row: first chunk, chunk count, image band
     int integrate_blocks = 0;      // persistent grid of integrate_kernel
     int integrate_debug = 0;       // timing experiments; only honoured by builds with -DTSDF_INTEGRATE_DEBUG=1
 
@@ -688,6 +687,11 @@ int fetch_counters(tsdf_handle* h) {
     }
     unsigned long long own = 0, halo = 0;
     for (size_t b = 0; b < nw; b += 2) { own += h->wg_counts_host[b]; halo += h->wg_counts_host[b + 1]; }
+    {   // TSDF_LIST_STATS=1: how much of the work list missed its band's predicted region (cumulative)
+        static const bool list_stats = [] { const char* e = std::getenv("TSDF_LIST_STATS"); return e && std::atoi(e) != 0; }();
+        if (list_stats)
+            std::fprintf(stderr, "LISTSTATS items %llu in the overflow region %llu\n", h->counters_host[kCntItems], h->counters_host[kCntOverflowItems]);
+    }
     if (h->integrate_debug & 4096) {      // load-balance experiment of debug builds: per workgroup {updated voxels, 10 ns ticks}, cumulative
         for (size_t b = 0; b < nw; b += 2)
             std::fprintf(stderr, "WGT %zu %llu %llu\n", b / 2, h->wg_counts_host[b + 1], h->wg_counts_host[b]);
@@ -848,9 +852,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMemsetAsync(h->counters, 0, kNumCounters * sizeof(unsigned long long), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->counters_host, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
     CREATE_TRY(hipMalloc((void**)&h->worklist, integrate_worklist_bytes(g)));
+    CREATE_TRY(hipMemsetAsync(h->worklist, 0, integrate_worklist_bytes(g), h->stream));
     CREATE_TRY(hipMalloc((void**)&h->work_count, integrate_bookkeeping_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->work_count, 0, integrate_bookkeeping_words() * sizeof(unsigned), h->stream));
-    CREATE_TRY(hipMalloc((void**)&h->rowinfo, integrate_row_entries(g) * sizeof(unsigned)));
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
@@ -921,7 +925,6 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->counters) (void)hipFree(h->counters);
     if (h->worklist) (void)hipFree(h->worklist);
     if (h->work_count) (void)hipFree(h->work_count);
-    if (h->rowinfo) (void)hipFree(h->rowinfo);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->wg_counts) (void)hipFree(h->wg_counts);
     if (h->wg_counts_host) (void)hipHostFree(h->wg_counts_host);
@@ -1429,7 +1432,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     EventPair* ep;
     rc = timed_begin(h, 0, &ep, h->stream);
     if (rc) return rc;
-    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count, h->rowinfo,
+    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
                                 h->integrate_blocks, h->integrate_launches++, h->wg_counts));
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;

@@ -176,15 +176,24 @@ __device__ __forceinline__ void clip_affine(double a, double b, double& lo, doub
     // (b == 0 and a within rounding of 0: leave it to the exact per-voxel test)
 }
 
-// Work-list bookkeeping of one launch: [0] = number of items, [1 .. kBins] = items per image band, [kBins + 1 ..
-// 2 kBins] = scatter cursors.  Two such sets are used alternately: the clip kernel of a launch re-zeroes the set the
-// NEXT launch will use (nobody touches it during this launch), which saves a memset per frame.
+// Work-list bookkeeping of one launch (a "set", words):
+//   [kSetCur + b]     cursor of image band b: items of band b handed out so far = the band's item count at the end
+//   [kSetFirstOvf + b] smallest cursor value at which a group of band b did not fit its region any more (~0: all fitted)
+//   [kSetCap + b]     capacity of band b's region in the list          } prepared by the PREVIOUS launch's
+//   [kSetBase + b]    first list entry of band b's region (b = 0..kBins: [kBins] = end of the regions)  } integrate_kernel
+//   [kSetOvf]         items in the overflow region (list entries [ovf_base, ...), ovf_base = half of the list)
+// One pass builds the band-sorted list (list_rows_kernel): the band regions are sized from the band counts of the
+// previous frame (+25 % + 128 entries) -- consecutive frames see nearly the same image -- and whatever does not fit goes
+// to the overflow region behind them, which is integrated like any other part of the list, only without the band's
+// locality.  The first launch after creation (all capacities 0) puts everything there.  Two sets are used
+// alternately: a launch's integrate_kernel prepares the set of the NEXT launch (nobody else touches it meanwhile).
 #ifndef TSDF_BANDS
 #define TSDF_BANDS 64
 #endif
 constexpr int kBins = TSDF_BANDS;
 static_assert(kBins >= 8 && kBins <= 4096 && (kBins & (kBins - 1)) == 0, "bands: a power of two that fits the row word");
-constexpr int kBinSetWords = 2 * kBins + 2;
+enum { kSetCur = 0, kSetFirstOvf = kBins, kSetCap = 2 * kBins, kSetBase = 3 * kBins, kSetOvf = 4 * kBins + 1 };
+constexpr int kBinSetWords = 4 * kBins + 2;
 
 // Shares of the eight XCDs in the band-sorted work list, adjusted from launch to launch.  Items differ in cost (live
 // lanes, lines touched) and an XCD's band keeps its character from frame to frame; with equal item counts the slowest
@@ -228,19 +237,33 @@ __device__ __forceinline__ void update_xcd_shares(unsigned* fb) {
     for (int x = 0; x < 8; ++x) ticks[x] = 0ull;
 }
 
-// rowinfo word: bit 31 = the row has items, bits 16..27 = band, bits 8..15 = number of chunks, bits 0..7 = first chunk
-__global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p, IntegrateTiling tl,
-                                                                unsigned* __restrict__ rowinfo,
-                                                                unsigned* __restrict__ set,
-                                                                unsigned* __restrict__ next_set,
-                                                                unsigned* __restrict__ xcd_fb) {
+// One work item as integrate_kernel reads it, with ONE scalar load: the item code and the row's share of rot_inv * g
+// (its first two terms in Eigen's order ((r0*gx + r1*gy) + r2*gz), identical for every k of the row).
+struct __attribute__((aligned(32))) ItemDesc {
+    unsigned code;          // row << 6 | chunk   (row = il * m + j, chunk = k / 64)
+    unsigned pad;
+    double s0, s1, s2;
+};
+static_assert(sizeof(ItemDesc) == 32, "one s_load_dwordx8 per item");
+
+// The list of work items, sorted by image band, in ONE pass (round 3; rounds 1-2 clipped the rows in one kernel and
+// scattered their items in a second one, because the band counts had to be complete before the first item could be
+// placed: two latency-bound kernels of 7 and 10 us).  One thread per voxel row clips it against the frustum; the
+// workgroup's rows are counted per band in LDS, ONE returning atomic per band and workgroup reserves their place in the
+// band's region -- or, when the region is full, in the overflow region -- and all threads write the descriptors.
+// integrate_kernel hands each XCD one contiguous part of the list = a band of the image whose pixel records (about
+// 1.2 MB) then live in that XCD's L2: with the list in row order every XCD gathered from the whole image, and 63 % of
+// the launch's fabric reads were pixel records fetched again and again (296 MB for a 9.8 MB image).  The order inside a
+// band is whatever the atomics give -- every voxel belongs to exactly one item, so no result depends on it.
+__global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p, IntegrateTiling tl,
+                                                                unsigned* __restrict__ set, ItemDesc* __restrict__ list,
+                                                                unsigned ovf_base, unsigned* __restrict__ xcd_fb) {
     const int m = p.g.m;
     const int tid = threadIdx.x;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
-    if (blockIdx.x == 0) for (int t = tid; t < kBinSetWords; t += kClipBlock) next_set[t] = 0u;
     if (blockIdx.x == gridDim.x - 1 && tid == 0) update_xcd_shares(xcd_fb);   // (the last launch's integrate kernel is done: same stream)
-    __shared__ unsigned s_hist[kBins];
-    for (int t = tid; t < kBins; t += kClipBlock) s_hist[t] = 0u;
+    __shared__ unsigned s_wg[kBins], s_dest[kBins];
+    for (int t = tid; t < kBins; t += kClipBlock) s_wg[t] = 0u;
     __syncthreads();
     int c0 = 0, n = 0, bin = 0;
     if (row < tl.n_rows) {
@@ -291,98 +314,40 @@ __global__ __launch_bounds__(kClipBlock) void clip_rows_kernel(IntegrateParams p
             }
         }
         if (klo <= khi) { c0 = klo >> 6; n = (khi >> 6) - c0 + 1; }
-        rowinfo[row] = n ? (0x80000000u | ((unsigned)bin << 16) | ((unsigned)n << 8) | (unsigned)c0) : 0u;
     }
-    if (n) atomicAdd(&s_hist[bin], (unsigned)n);
-    __syncthreads();
-    // only the band counters are touched here (no-return adds on up to 64 different words): a total that every
-    // workgroup adds to is one hot word, and a thousand returning atomics on one word cost ~12 us by themselves;
-    // the scatter pass gets the total out of its scan of the bands
-    for (int t = tid; t < kBins; t += kClipBlock) {
-        const unsigned hcnt = s_hist[t];
-        if (hcnt) atomicAdd(&set[1 + t], hcnt);
-    }
-}
-
-// One work item as integrate_kernel reads it, with ONE scalar load: the item code and the row's share of rot_inv * g
-// (its first two terms in Eigen's order ((r0*gx + r1*gy) + r2*gz), identical for every k of the row).
-struct __attribute__((aligned(32))) ItemDesc {
-    unsigned code;          // row << 6 | chunk   (row = il * m + j, chunk = k / 64)
-    unsigned pad;
-    double s0, s1, s2;
-};
-static_assert(sizeof(ItemDesc) == 32, "one s_load_dwordx8 per item");
-
-// Second pass: the items of every row go to the part of the list that belongs to the row's image band (counting
-// sort by band; the order inside a band is whatever the atomics give -- every voxel belongs to exactly one item, so
-// no result depends on the order).  integrate_kernel hands each XCD one contiguous eighth of the list = a band of
-// the image whose pixel records (about 1.2 MB) then live in that XCD's L2: with the list in row order every XCD
-// gathered from the whole image, and 63 % of the launch's fabric reads were pixel records fetched again and again
-// (296 MB for a 9.8 MB image).
-__global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(IntegrateParams p, IntegrateTiling tl,
-                                                                   const unsigned* __restrict__ rowinfo,
-                                                                   unsigned* __restrict__ set, ItemDesc* __restrict__ list,
-                                                                   unsigned long long* __restrict__ counters) {
-    __shared__ unsigned s_start[kBins], s_wg[kBins], s_base[kBins];
-    __shared__ unsigned s_wave[kClipBlock / 64];
-    const int tid = threadIdx.x;
-    const long long row = (long long)blockIdx.x * kClipBlock + tid;
-    {
-        // exclusive scan of the band counts: every thread takes BPT consecutive bands, the workgroup scans the thread sums
-        constexpr int BPT = (kBins + kClipBlock - 1) / kClipBlock;
-        unsigned cntb[BPT], tsum = 0u;
-#pragma unroll
-        for (int q = 0; q < BPT; ++q) {
-            const int bq = tid * BPT + q;
-            cntb[q] = bq < kBins ? set[1 + bq] : 0u;
-            tsum += cntb[q];
-        }
-        unsigned incl = tsum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off);
-            if ((tid & 63) >= off) incl += t;
-        }
-        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
-        __syncthreads();
-        unsigned before = 0u, total = 0u;
-#pragma unroll
-        for (int w = 0; w < kClipBlock / 64; ++w) { if (w < (tid >> 6)) before += s_wave[w]; total += s_wave[w]; }
-        unsigned run = before + incl - tsum;
-#pragma unroll
-        for (int q = 0; q < BPT; ++q) {
-            const int bq = tid * BPT + q;
-            if (bq < kBins) { s_start[bq] = run; s_wg[bq] = 0u; }
-            run += cntb[q];
-        }
-        if (blockIdx.x == 0 && tid == 0) {                  // the launch's item count, for integrate_kernel and the statistics
-            set[0] = total;
-            if (total) atomicAdd(&counters[kCntItems], (unsigned long long)total);
-        }
-    }
-    __syncthreads();
-    const unsigned info = row < tl.n_rows ? rowinfo[row] : 0u;
-    const unsigned n = (info >> 8) & 0xFFu, c0 = info & 0xFFu, bin = (info >> 16) & 0xFFFu;
     unsigned rank = 0u;
-    if (info) rank = atomicAdd(&s_wg[bin], n);
+    if (n) rank = atomicAdd(&s_wg[bin], (unsigned)n);
     __syncthreads();
-    for (int t = tid; t < kBins; t += kClipBlock) s_base[t] = s_wg[t] ? atomicAdd(&set[1 + kBins + t], s_wg[t]) : 0u;
+    // one returning atomic per band with items: the group's place in the band's region, or in the overflow region
+    for (int t = tid; t < kBins; t += kClipBlock) {
+        const unsigned cnt = s_wg[t];
+        if (cnt) {
+            const unsigned at = atomicAdd(&set[kSetCur + t], cnt);
+            unsigned dest;
+            if (at + cnt <= set[kSetCap + t]) dest = set[kSetBase + t] + at;
+            else {
+                atomicMin(&set[kSetFirstOvf + t], at);       // the band's region ends being valid here
+                dest = ovf_base + atomicAdd(&set[kSetOvf], cnt);
+            }
+            s_dest[t] = dest;
+        }
+    }
     __syncthreads();
     // The items are written by ALL threads of the workgroup, one 32-byte descriptor each per round: most rows of a
     // workgroup have no item and a few have up to m/64, so a loop over the own row's chunks left one lane of a
     // wavefront writing while the others waited (11.4 us per launch at 512^3; 6-7 us spread out).
     __shared__ unsigned s_at[kClipBlock], s_n[kClipBlock], s_c0[kClipBlock], s_pre[kClipBlock + 1];
-    s_at[tid] = info ? s_start[bin] + s_base[bin] + rank : 0u;
-    s_n[tid] = info ? n : 0u;
-    s_c0[tid] = c0;
+    __shared__ unsigned s_wave[kClipBlock / 64];
+    s_at[tid] = n ? s_dest[bin] + rank : 0u;
+    s_n[tid] = (unsigned)n;
+    s_c0[tid] = (unsigned)c0;
     {
-        unsigned incl = info ? n : 0u;                      // exclusive scan of the rows' item counts over the workgroup
+        unsigned incl = (unsigned)n;                        // exclusive scan of the rows' item counts over the workgroup
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned t = __shfl_up(incl, off);
             if ((tid & 63) >= off) incl += t;
         }
-        __syncthreads();                                    // (s_wave was read above)
         if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
         __syncthreads();
         unsigned before = 0u;
@@ -393,7 +358,6 @@ __global__ __launch_bounds__(kClipBlock) void scatter_rows_kernel(IntegrateParam
     }
     __syncthreads();
     const unsigned total = s_pre[kClipBlock];
-    const int m = p.g.m;
     for (unsigned e = tid; e < total; e += kClipBlock) {
         // the row of item e: the last r with s_pre[r] <= e
         unsigned lo = 0u, hi = kClipBlock;
@@ -673,7 +637,8 @@ __device__ __forceinline__ float band_weight(float d, float eps) {
 
 template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
-    IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ count,
+    IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ set,
+    unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
     float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
     unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */,
     unsigned* __restrict__ xcd_fb) {
@@ -683,9 +648,56 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
-    const unsigned n_items = *count;
     constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
+    // The list as list_rows_kernel left it: band b's items in [base[b], base[b] + fill[b]), then the overflow region.
+    // Segment table (kBins + 1 segments): first VIRTUAL index of each segment (the list without its holes) and what to
+    // add to a virtual index to get the list entry.
+    static_assert(kBins <= 64, "one lane per band in the segment scan");
+    __shared__ unsigned s_vstart[kBins + 2], s_delta[kBins + 1];
+    if (tid < 64) {
+        const bool is_band = tid < kBins;
+        const unsigned cur = is_band ? set[kSetCur + tid] : 0u, fo = is_band ? set[kSetFirstOvf + tid] : 0u;
+        const unsigned fill = cur < fo ? cur : fo;            // what fitted the band's region
+        unsigned incl = fill;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off);
+            if (tid >= off) incl += t;
+        }
+        if (is_band) { s_vstart[tid] = incl - fill; s_delta[tid] = set[kSetBase + tid] - (incl - fill); }
+        if (tid == kBins - 1) {
+            const unsigned ovf = set[kSetOvf];
+            s_vstart[kBins] = incl; s_delta[kBins] = ovf_base - incl;
+            s_vstart[kBins + 1] = incl + ovf;
+        }
+        if (blockIdx.x == 0) {
+            // the set of the NEXT launch: capacities from this launch's band counts (+25 % + 128), regions packed from
+            // entry 0 and clipped at the overflow region, cursors back to zero
+            const unsigned want = is_band ? cur + (cur >> 2) + 128u : 0u;
+            unsigned wincl = want;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(wincl, off);
+                if (tid >= off) wincl += t;
+            }
+            const unsigned wexcl = wincl - want;
+            const unsigned base = wexcl < ovf_base ? wexcl : ovf_base;
+            const unsigned cap = wexcl < ovf_base ? (want < ovf_base - wexcl ? want : ovf_base - wexcl) : 0u;
+            if (is_band) {
+                next_set[kSetCur + tid] = 0u; next_set[kSetFirstOvf + tid] = ~0u;
+                next_set[kSetCap + tid] = cap; next_set[kSetBase + tid] = base;
+            }
+            if (tid == kBins - 1) { next_set[kSetBase + kBins] = base + cap; next_set[kSetOvf] = 0u; }
+            unsigned long long tot = cur;                    // the launch's item count, for the statistics
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+            if (tid == 0 && tot) atomicAdd(&totals[kCntItems], tot);
+            if (tid == 0 && set[kSetOvf]) atomicAdd(&totals[kCntOverflowItems], (unsigned long long)set[kSetOvf]);
+        }
+    }
     if (KTAB) build_k_table(p, s_tab, tid, kIntegrateBlock);
+    else __syncthreads();
+    const unsigned n_items = __builtin_amdgcn_readfirstlane(s_vstart[kBins + 1]);   // (an LDS load is a per-lane value to the compiler)
     ProjConst pc;
     make_proj_const(p, tl, lane, pc);
     // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
@@ -693,12 +705,14 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     // The XCD's part of the list [x_lo, x_hi) follows the shares of update_xcd_shares(); its gridDim.x / 8 workgroups
     // split it evenly.
     const unsigned xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const unsigned x_lo = (unsigned)(((unsigned long long)n_items * xcd_fb[xcd]) >> 24);
-    const unsigned x_hi = (unsigned)(((unsigned long long)n_items * xcd_fb[xcd + 1]) >> 24);
+    // (readfirstlane: xcd_fb is written at the end of this kernel, so the compiler may fetch the shares with a vector
+    // load and then takes everything derived from them for per-lane values)
+    const unsigned x_lo = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd])) >> 24);
+    const unsigned x_hi = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd + 1])) >> 24);
     // The workgroup's contiguous share of the work list, dealt to its wavefronts ITEM BY ITEM: at any moment the NW
     // wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring voxel rows.
-    const unsigned wg_first = x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * in_xcd) / per_xcd);
-    const unsigned wg_last = x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * (in_xcd + 1)) / per_xcd);
+    const unsigned wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * in_xcd) / per_xcd)));
+    const unsigned wg_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * (in_xcd + 1)) / per_xcd)));
     const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
     unsigned n_own = 0, n_halo = 0;
     const unsigned long long loop_t0 = __builtin_amdgcn_s_memrealtime();      // for the XCD shares of the next launch
@@ -717,9 +731,26 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     // One pipeline step = S1(j) | S2(j-1) | S3(j-1-DEPTH): three independent instruction streams.
     // S1 requests the pixel record of item j, S2 consumes the record requested a step earlier and requests the volume data,
     // S3 consumes the volume data requested DEPTH steps earlier -- every request has (at least) a whole step to complete.
+    // virtual index -> list entry: the wavefront walks its items in increasing order and keeps the segment it is in.
+    // (seg_end is wave-uniform in an SGPR; seg_delta stays in a VGPR as the LDS load leaves it -- the kernel has no
+    // scalar registers to spare -- and goes through v_readfirstlane once per item.)
+    unsigned seg_end = 0u, seg_delta = 0u;
+    auto locate = [&](unsigned v) {
+        // segment of v = number of segment ends <= v (lane l looks at the end of segment l; the overflow segment is the last)
+        const unsigned e = s_vstart[(lane < kBins ? lane : kBins - 1) + 1];
+        const unsigned sg = (unsigned)__popcll(__ballot(lane < kBins && v >= e));
+        seg_end = __builtin_amdgcn_readfirstlane(s_vstart[sg + 1]);
+        seg_delta = s_delta[sg];
+    };
     auto stage1 = [&](int j, GatherState& g /*out: item j*/) {
         const bool have = j < cnt;
-        const ItemDesc ds = list[wg_first + (unsigned)wv + NW * (unsigned)(have ? j : 0)];
+        unsigned entry = 0u;                                    // (no item left: entry 0, masked below)
+        if (have) {
+            const unsigned v = wg_first + (unsigned)wv + NW * (unsigned)j;
+            if (__builtin_expect(v >= seg_end, 0)) locate(v);
+            entry = v + seg_delta;
+        }
+        const ItemDesc ds = list[__builtin_amdgcn_readfirstlane(entry)];    // wave-uniform: one scalar 32-byte load
         unsigned long long okm;
         unsigned pixb;
         project_item<KSTD, KTAB>(pc, ds, s_tab, lane, g.pcx, g.pcy, g.pcz, okm, pixb);
@@ -941,8 +972,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 size_t integrate_worklist_entries(const Grid& g) {
     return (size_t)(g.xe - g.xs) * g.m * ((g.m + 63) / 64);
 }
-size_t integrate_worklist_bytes(const Grid& g) { return (integrate_worklist_entries(g) + 8) * sizeof(ItemDesc); }   // + slack: idle wavefronts read one descriptor past their share
-size_t integrate_row_entries(const Grid& g) { return (size_t)(g.xe - g.xs) * g.m; }
+// band regions (at most `entries` in all) + an overflow region that can hold every item; zero-filled once at creation
+// (a wavefront without items reads entry 0)
+size_t integrate_worklist_bytes(const Grid& g) { return (2 * integrate_worklist_entries(g) + 8) * sizeof(ItemDesc); }
 
 int integrate_blocks_per_cu() {
     int n = 0;
@@ -977,7 +1009,7 @@ static bool use_exp_poly(const IntegrateParams& p) {
 
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
-                            void* worklist, unsigned* work_count, unsigned* rowinfo, int n_blocks,
+                            void* worklist, unsigned* work_count, int n_blocks,
                             unsigned launch_parity, unsigned long long* wg_counts) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
@@ -992,10 +1024,8 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     ItemDesc* const list = static_cast<ItemDesc*>(worklist);
     hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
-    clip_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, nxt, xcd_fb);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    scatter_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, rowinfo, cur, list, counters);
+    const unsigned ovf_base = (unsigned)integrate_worklist_entries(p.g);       // band regions in the first half of the list
+    list_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, cur, list, ovf_base, xcd_fb);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     const bool exp_poly = use_exp_poly(p);
@@ -1003,7 +1033,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     const size_t lds = ktab ? (size_t)m * 24 : 0;
     const char* planes = reinterpret_cast<const char*>(pn);
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) \
-    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, dw, crgb, planes, wg_counts, xcd_fb)
+    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb)
 #define TSDF_LAUNCH_INTEGRATE3(C, KS, EP) do { if (ktab) TSDF_LAUNCH_INTEGRATE(C, KS, EP, true); else TSDF_LAUNCH_INTEGRATE(C, KS, EP, false); } while (0)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE3(C, KS, true); else TSDF_LAUNCH_INTEGRATE3(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
