@@ -227,7 +227,7 @@ PMC_CORRECTION_NOTE = ("bytes from the L2's memory-side request counters by requ
 
 
 def pmc_traffic(args, wl_args):
-    """HBM bytes of one integrate launch (clip_rows_kernel + scatter_rows_kernel + integrate_kernel) of THIS workload, measured now:
+    """HBM bytes of one integrate launch (list_rows_kernel + integrate_kernel) of THIS workload, measured now:
     two child runs of this script under rocprofv3 --pmc, one counter group each (read requests by size, write
     requests by size; never combined with a trace domain), program directly after `--`.  Returns a dict or a reason."""
     import csv
@@ -241,7 +241,7 @@ def pmc_traffic(args, wl_args):
     try:
         for gi, group in enumerate(PMC_GROUPS):
             d = os.path.join(work, "g%d" % gi)
-            cmd = ["rocprofv3", "--pmc"] + list(group) + ["--kernel-include-regex", "tsdf::(integrate|clip_rows|scatter_rows)", "--output-format", "csv", "-d", d, "--", sys.executable,
+            cmd = ["rocprofv3", "--pmc"] + list(group) + ["--kernel-include-regex", "tsdf::(integrate|list_rows)", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-child", "--steps", "12", "--warmup", "2"] + wl_args
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -767,7 +767,7 @@ def run(args):
             "gn_iterations_per_frame": cn["track_iterations"] / max(1, cn["track_calls"]),
             "stage_ms_per_frame": {"track_wall": 1e3 * track_wall_main / args.steps,
                                    "integrate_launch": avg_ms, "pack_kernel": pack_ms},
-            "roofline": {"kernel": "integrate (clip_rows_kernel + scatter_rows_kernel + integrate_kernel, one launch of the three per frame; integrate_kernel is 85 % of the interval)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "integrate (list_rows_kernel + integrate_kernel, one launch of the two per frame; integrate_kernel is 90 % of the interval)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_updated_voxel": bpv,
                          "updated_voxels_per_launch": upd_per_launch, "avg_launch_ms": avg_ms,
@@ -797,7 +797,7 @@ def run(args):
             out["roofline"]["measured_rmw_ceiling_GBs"] = ceil_gbs
             out["roofline"]["frac_of_measured_ceiling"] = achieved / ceil_gbs
             out["roofline"]["ceiling_source"] = "profiles/r01_rmw_probe.json (build/rmw_probe on MI355X)"
-        # HBM traffic of the integrate launch (its three kernels), measured now by two rocprofv3 --pmc child passes of this workload
+        # HBM traffic of the integrate launch (its two kernels), measured now by two rocprofv3 --pmc child passes of this workload
         if n1_extras and not args.no_pmc:
             wl = ["--config", str(args.config), "--voxels", str(m), "--width", str(width), "--height", str(height),
                   "--frame-step", str(args.frame_step), "--timing-period", str(args.timing_period)]
@@ -807,14 +807,14 @@ def run(args):
             if isinstance(got, dict):
                 def tot(prefix, field):
                     return sum(v[field] for k, v in got.items() if k.startswith(prefix))
-                kernels3 = ("tsdf::integrate_kernel", "tsdf::clip_rows_kernel", "tsdf::scatter_rows_kernel")
+                kernels3 = ("tsdf::integrate_kernel", "tsdf::list_rows_kernel")
                 fetch = sum(tot(k, "read_bytes") for k in kernels3)
                 write = sum(tot(k, "write_bytes") for k in kernels3)
                 out["roofline"]["traffic"] = fetch + write
                 out["roofline"]["traffic_detail"] = {
                     "read_bytes": fetch, "write_bytes": write,
                     "source": "two rocprofv3 --pmc child passes of this command's workload run by bench.py itself "
-                              "(one counter group per pass, 12 timed steps), bytes per launch of the three kernels",
+                              "(one counter group per pass, 12 timed steps), bytes per launch of the two kernels",
                     "correction": PMC_CORRECTION_NOTE, "ratio_to_algorithmic": (fetch + write) / alg_bytes,
                     "requests_integrate_kernel": {k: v["requests"] for k, v in got.items() if k.startswith("tsdf::integrate_kernel")}}
             else:

@@ -147,3 +147,13 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     rc, rc2, msg = r.stdout.strip().split(" ", 2)
     assert int(rc) == ts.E_COMM and int(rc2) == ts.E_COMM
     assert "cannot load librccl" in msg and "nonexistent" in msg
+
+
+def test_graft_entry_build_passes():
+    """The driver's "does it build" check: __graft_entry__.build() (make all + ABI version + every declared symbol)."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    importlib.import_module("__graft_entry__").build()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing experiments on integrate_kernel in ONE process: for every value of TSDF_DEBUG_INTEGRATE given on the command
 line a fresh handle integrates the same frames at the ground-truth poses (fusion-only mode) and the average launch time
-(clip_rows + scatter_rows + integrate_kernel between HIP events) is printed.  Needs a library built with
+(list_rows_kernel + integrate_kernel between HIP events) is printed.  Needs a library built with
 -DTSDF_INTEGRATE_DEBUG=1 for the bits to do anything (TSDF_HIP_LIB=build/variants/libtsdf_hip_dbg.so); the results of
 most bits are garbage, only the time means something.  Prints one JSON line per (scene, debug value).
 """

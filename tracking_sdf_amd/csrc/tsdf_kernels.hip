@@ -1,6 +1,6 @@
 // tsdf_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the tracking_sdf hot path.
 //
-//   clip_rows_kernel   per k-row frustum interval -> compact list of 64-voxel work items
+//   list_rows_kernel   per k-row frustum interval -> list of 64-voxel work items, sorted by image band
 //   integrate_kernel   SDF::update over that list          (reference src/sdf.cpp:224-315)
 //   track_kernel       one Gauss-Newton accumulation pass    (reference src/camera_tracking.cpp:146-189,
 //                      + get_partial_derivative :246-363, SDF::interpolate_distance sdf.cpp:127-163)
@@ -133,18 +133,18 @@ hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const 
 // that own in-frustum voxels run long serial chains (pixel gather -> {D,W} read -> write) while the
 // rest of the chip has nothing to do.  So the work is first compacted, then spread evenly:
 //
-//   clip_rows_kernel   one thread per k-row (fixed i,j; k = 0..m-1).  A row is a straight segment in
+//   list_rows_kernel   one thread per k-row (fixed i,j; k = 0..m-1).  A row is a straight segment in
 //                      camera space, pc(k) = Q0 + k Q1, and every frustum test (z >= 0, u > -1, u < W,
 //                      v > -1, v < H) is affine in k, so the k that can pass form ONE interval, found
-//                      with five divisions per row.  The interval is widened by a voxel per side and
-//                      its 64-voxel chunks are appended to a work list (block scan + one atomic per
-//                      workgroup).  Every listed voxel still runs the reference's exact tests, so the
+//                      with five reciprocals per row.  The interval is widened by a voxel per side and
+//                      its 64-voxel chunks go to the work list, into the region of the image band the row
+//                      projects to.  Every listed voxel still runs the reference's exact tests, so the
 //                      cull never changes a result.
-//   integrate_kernel   persistent workgroups stride over the list; one item = 64 consecutive k of one
-//                      row = one 512-byte {D,W} segment (+1 KiB colour): perfectly coalesced RMW.
-//                      The row's share of rot_inv * g (its first two terms, identical for all k) is computed
-//                      by the lane that fetches the item code, once per item, and broadcast with v_readlane, so
-//                      the per-voxel f64 work is 1 multiply + 2 adds per camera coordinate.
+//   integrate_kernel   persistent workgroups take contiguous shares of the list; one item = 64 consecutive k of
+//                      one row = one 512-byte {D,W} segment (+1 KiB colour): perfectly coalesced RMW.
+//                      The row's share of rot_inv * g (its first two terms, identical for all k) travels in the
+//                      item descriptor (one scalar 32-byte load per item), the third term comes from a table of
+//                      the m values of k in LDS: two f64 adds per camera coordinate and voxel.
 //
 // Algorithmic traffic: 16 B (48 B with colour) per *updated* voxel + the 32-byte pixel records.
 
@@ -200,7 +200,7 @@ constexpr int kBinSetWords = 4 * kBins + 2;
 // XCD finished 10-15 % after the fastest.  Feedback block behind the two bookkeeping sets: words [0..8] = share
 // boundaries as fractions of the list in 2^-24 units (0 .. 2^24), then (8-byte aligned) eight 64-bit sums of what the
 // first wavefronts of the XCD's workgroups measured for their item loops in the LAST launch (s_memrealtime ticks).
-// clip_rows_kernel (block 0) turns them into the next boundaries: share ~ items per tick, half-way damped, each
+// list_rows_kernel (its last block) turns them into the next boundaries: share ~ items per tick, half-way damped, each
 // share kept within [1/16, 1/4].  Only the schedule depends on it -- every voxel belongs to exactly one item.
 constexpr int kFbWords = 32;
 constexpr int kFbTicksWord = 16;
