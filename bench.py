@@ -633,6 +633,12 @@ def run(args):
         extras["value_h2d_inclusive_queued"] = args.steps / best_of_two("host_q", [tuple(np.ascontiguousarray(a) for a in f) for f in host_frames])
         extras["value_h2d_inclusive_pinned_buffers_queued"] = args.steps / best_of_two("host_q", pinned_frames)
         extras["value_pcl_clouds_inclusive_queued"] = args.steps / best_of_two("aos_q", aos)
+        # SURVEY 8(d)'s end-to-end definition in one place: the reference's own input format (PCL clouds in pageable memory)
+        # and the best a host can do (page-locked planes), both through the queue.  `value` stays the device-resident rate
+        # the bench contract prescribes ("inputs already resident in HBM when the timed region starts").
+        extras["value_host_inclusive"] = {"pcl_clouds_pageable": extras["value_pcl_clouds_inclusive_queued"],
+                                          "planes_page_locked": extras["value_h2d_inclusive_pinned_buffers_queued"],
+                                          "planes_pageable": extras["value_h2d_inclusive_queued"], "unit": "frames/s"}
         extras["queued_note"] = ("frame k+1 handed to tsdf_queue_frame(_aos) before frame k is tracked and integrated, taken with tsdf_next_frame: "
                                  "the upload (and the host-side repack of pageable buffers, on library threads) overlaps the whole of frame k")
         pin16 = [torch.from_numpy(d.view(np.int16)).pin_memory() for d in depth16]
@@ -750,8 +756,8 @@ def run(args):
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": f"frames/sec (track + integrate per frame), synthetic fr1/plant stream, {m}^3 TSDF",
-            "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "value": args.steps / elapsed, "value_device_resident": args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32/f64",
             "dtype_note": "f32 voxel state and SDF samples, f64 geometry and normal equations (the reference's own mix)",
             "data": "synthetic (frames resident in HBM before the timed region)",
