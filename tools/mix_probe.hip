@@ -71,22 +71,26 @@ int main() {
     CHECK(hipMalloc(&rec, (size_t)nrec * 32)); CHECK(hipMalloc(&dw, (size_t)nseg * 512)); CHECK(hipMalloc(&col, (size_t)nseg * 1024));
     CHECK(hipMalloc(&out, 1 << 20));
     CHECK(hipMemset(rec, 1, (size_t)nrec * 32)); CHECK(hipMemset(dw, 0, (size_t)nseg * 512)); CHECK(hipMemset(col, 0, (size_t)nseg * 1024));
-    const int blocks = 1280, ipw = 39;                             // 1280 x 4 x 39 = 199.7k items
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     const char* names[4] = {"all", "no_gathers", "no_volume", "no_stores"};
-    for (int rep = 0; rep < 3; ++rep)
-        for (int pipe = 0; pipe < 3; ++pipe)
-            for (int mode = 0; mode < 4; ++mode) {
-                CHECK(hipEventRecord(a));
-                for (int k = 0; k < 10; ++k) {
+    // grid sweep (199.7k items in all): wavefronts per CU = blocks * 4 / 256
+    const int grids[6] = {1280, 256, 512, 768, 1024, 2048};
+    for (int gi = 0; gi < 6; ++gi) {
+        const int blocks = grids[gi], ipw = (199680 + blocks * 4 - 1) / (blocks * 4);
+        for (int rep = 0; rep < 3; ++rep)
+            for (int pipe = 0; pipe < (gi == 0 ? 3 : 1); ++pipe)
+                for (int mode = 0; mode < (gi == 0 ? 4 : 2); ++mode) {
+                    CHECK(hipEventRecord(a));
+                    for (int k = 0; k < 10; ++k) {
 #define L(M, P) mix<M, P><<<blocks, 256>>>(rec, nrec, dw, col, nseg, ipw, out)
-                    if (pipe == 0) { if (mode == 0) L(0, 0); if (mode == 1) L(1, 0); if (mode == 2) L(2, 0); if (mode == 3) L(3, 0); }
-                    else if (pipe == 1) { if (mode == 0) L(0, 1); if (mode == 1) L(1, 1); if (mode == 2) L(2, 1); if (mode == 3) L(3, 1); }
-                    else { if (mode == 0) L(0, 2); if (mode == 1) L(1, 2); if (mode == 2) L(2, 2); if (mode == 3) L(3, 2); }
+                        if (pipe == 0) { if (mode == 0) L(0, 0); if (mode == 1) L(1, 0); if (mode == 2) L(2, 0); if (mode == 3) L(3, 0); }
+                        else if (pipe == 1) { if (mode == 0) L(0, 1); if (mode == 1) L(1, 1); if (mode == 2) L(2, 1); if (mode == 3) L(3, 1); }
+                        else { if (mode == 0) L(0, 2); if (mode == 1) L(1, 2); if (mode == 2) L(2, 2); if (mode == 3) L(3, 2); }
+                    }
+                    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+                    if (rep == 2) printf("{\"workgroups\": %d, \"items_per_wavefront\": %d, \"mode\": \"%s\", \"pipe\": %d, \"us_per_launch\": %.1f}\n", blocks, ipw, names[mode], pipe, ms * 100.0);
                 }
-                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
-                float ms; CHECK(hipEventElapsedTime(&ms, a, b));
-                if (rep == 2) printf("{\"mode\": \"%s\", \"pipe\": %d, \"us_per_launch\": %.1f}\n", names[mode], pipe, ms * 100.0);
-            }
+    }
     return 0;
 }
