@@ -631,3 +631,30 @@ def test_track_and_integrate_equals_the_two_calls():
         s.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_work_list_regions_follow_the_previous_frame_and_overflow_when_it_lies():
+    """The integrate work list is placed in per-band regions sized from the PREVIOUS launch's band counts, with an
+    overflow region for whatever does not fit (list_rows_kernel).  Drive the prediction wrong on purpose: a camera that
+    alternates between looking along the path, rolled by 90 degrees (other record layout, other bands) and standing
+    50 m away (the whole volume projects into a few pixels of ONE band, nothing is updated), 8 launches on one handle.  Every
+    launch must update exactly the oracle's voxels and the volume must come out bit-identical."""
+    m = 96
+    seq, fr = frames(8, noise=True, holes=0.02, step=9)
+    oo, ot = make_oracle(m, seq.K)
+    go, gt = make_gpu(m, seq.K)
+    a = np.deg2rad(90.0)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    counts = []
+    for k in range(8):
+        R = seq.R[k] @ (Rz if k % 4 == 1 else np.eye(3))
+        t = seq.t[k] - (50.0 * R[:, 2] if k % 4 == 2 else 0.0)                # backwards along the optical axis
+        xyz, nrm, rgb = synth.render_frame(R, t, seq.K, W_, H_, noise=True, holes=0.02, rng=np.random.default_rng(40 + k))
+        ot.set_camera_transformation(R, t)
+        gt.set_camera_transformation(R, t)
+        n_or = oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+        st = go.update(gt, xyz, nrm, rgb)
+        assert st["n_updated"] == n_or, (k, st["n_updated"], n_or)
+        counts.append(n_or)
+    assert max(counts) > 20 * (min(counts) + 1), counts          # the launches really differ
+    assert_volume_equal(go, oo, m)
