@@ -148,7 +148,10 @@ hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const 
 //
 // Algorithmic traffic: 16 B (48 B with colour) per *updated* voxel + the 32-byte pixel records.
 
-constexpr int kClipBlock = 256;
+#ifndef TSDF_CLIP_BLOCK
+#define TSDF_CLIP_BLOCK 256
+#endif
+constexpr int kClipBlock = TSDF_CLIP_BLOCK;      // rows (threads) per workgroup of list_rows_kernel
 #ifndef TSDF_INTEGRATE_MIN_WAVES
 #define TSDF_INTEGRATE_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
