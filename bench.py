@@ -76,6 +76,10 @@ def parse(argv=None):
                          "shared-memory fan-in only if RCCL fails its self-test); shm = host-side fan-in through a POSIX "
                          "shared segment; peer = device-side exchange through HIP-IPC-mapped buffers (tsdf_comm_init_peer); "
                          "auto = self-test and time all three, keep the fastest")
+    ap.add_argument("--frame-queue", action="store_true",
+                    help="queue the HBM-resident frame k+1 (tsdf_queue_frame_device) while frame k is processed instead of setting "
+                         "every frame in front of its own tracker passes (measured: no gain, the packing kernel slows the tracker "
+                         "passes it runs next to by what it saves)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--timing-period", type=int, default=4, help="HIP events around every n-th integrate/pack launch")
@@ -343,6 +347,8 @@ def run(args):
     import ctypes as C
     L = ts.lib()
     f_set, f_step, f_pose = L.tsdf_set_frame_device, L.tsdf_track_and_integrate, L.tsdf_get_pose
+    f_queue, f_next = L.tsdf_queue_frame_device, L.tsdf_next_frame
+    MAIN_MODE = "device_q" if args.frame_queue else "device"
     perf = time.perf_counter
 
     class Leg:
@@ -360,8 +366,9 @@ def run(args):
             self.pose_ptr = self.pose_t.ctypes.data_as(C.POINTER(C.c_double))
             self.track_wall = 0.0
             self.est = []
+            self.sdf_has_queued = False
 
-        def first_frame(self, fr, mode="device", host=None, depth16=None):
+        def first_frame(self, fr, mode=MAIN_MODE, host=None, depth16=None):
             """frame 1: integrate only at the reference's initial pose (sdf_reconstruction.cpp:69)"""
             self.est = []
             self.feed(0, fr, mode, host, depth16)
@@ -373,6 +380,19 @@ def run(args):
                 dx, dn, dc = fr[k]
                 self.sdf._check(f_set(self.sdf._h, C.c_void_p(dx.data_ptr()), C.c_void_p(dn.data_ptr()),
                                       C.c_void_p(dc.data_ptr()), self.w, self.h))
+            elif mode == "device_q":
+                # the two-deep queue with frames that are resident in HBM: frame k was queued during step k-1, frame k+1 is
+                # queued now, so its packing kernel runs next to frame k's tracker passes instead of in front of frame k+1's
+                def q(i):
+                    dx, dn, dc = fr[i]
+                    self.sdf._check(f_queue(self.sdf._h, C.c_void_p(dx.data_ptr()), C.c_void_p(dn.data_ptr()),
+                                            C.c_void_p(dc.data_ptr()), self.w, self.h))
+                if not self.sdf_has_queued:
+                    q(k)
+                self.sdf._check(f_next(self.sdf._h))
+                self.sdf_has_queued = k + 1 < len(fr)
+                if self.sdf_has_queued:
+                    q(k + 1)
             elif mode == "host":
                 self.sdf.set_frame(*host[k])
             elif mode == "aos":
@@ -389,7 +409,7 @@ def run(args):
             else:
                 self.sdf.set_depth_frame(depth16[k], host[k][2])
 
-        def step(self, k, fr, mode="device", host=None, depth16=None, timed=False):
+        def step(self, k, fr, mode=MAIN_MODE, host=None, depth16=None, timed=False):
             self.feed(k, fr, mode, host, depth16)
             tq = perf()
             rc = f_step(self.sdf._h, 1, None, None)        # estimate_new_position + update, sdf_reconstruction.cpp:70,74
@@ -399,7 +419,7 @@ def run(args):
             f_pose(self.sdf._h, None, self.pose_ptr, None, None)      # host-side pose read while the integration runs
             self.est.append(self.pose_t.copy())
 
-        def timed_region(self, fr, mode="device", host=None, depth16=None, events=True):
+        def timed_region(self, fr, mode=MAIN_MODE, host=None, depth16=None, events=True):
             """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
             self.first_frame(fr, mode, host, depth16)
             for k in range(1, 1 + args.warmup):
@@ -601,6 +621,10 @@ def run(args):
                 e, _, _ = lg.timed_region(d_frames, mode, host, depth, events=False)
                 best = e if best is None else min(best, e)
             return best
+        if MAIN_MODE == "device":
+            extras["value_device_resident_queued"] = args.steps / best_of_two("device_q", None)
+            extras["device_queued_note"] = ("the same HBM-resident frames through tsdf_queue_frame_device / tsdf_next_frame: frame k+1's packing "
+                                            "kernel runs next to frame k's tracker passes instead of in front of frame k+1's")
         e2 = best_of_two("host", host_frames)
         extras["value_h2d_inclusive"] = args.steps / e2
         extras["h2d_inclusive_note"] = ("best of two repetitions; xyz + normals + rgb (27 B/pixel) handed over as HOST buffers every frame through "
@@ -760,7 +784,8 @@ def run(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32/f64",
             "dtype_note": "f32 voxel state and SDF samples, f64 geometry and normal equations (the reference's own mix)",
-            "data": "synthetic (frames resident in HBM before the timed region)",
+            "data": "synthetic (frames resident in HBM before the timed region" + ("" if not args.frame_queue else "; frame k+1 queued with "
+                    "tsdf_queue_frame_device while frame k is tracked and integrated") + ")",
             "config": {"workload": f"{wl_label}: fr1/plant ground-truth camera path at 30 Hz (re-based to the reference's "
                                    f"initial pose), analytic scene (plant on a pedestal at the path's focus, room with "
                                    f"pillars/domes/furniture), {width}x{height} depth with Kinect noise + 2% holes, "

@@ -156,6 +156,12 @@ int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm
  * at a time, of the same size as the current one; tsdf_set_frame* while a frame is queued is an error.
  * tsdf_queue_frame_aos needs the points (it has no 'normals only' form). */
 int tsdf_queue_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uint8_t *rgb, int32_t width, int32_t height);
+/* The same for a frame that is already in device memory (tsdf_set_frame_device's layouts and borrowing rule: the
+ * buffers must be complete when the call is made and stay valid and unchanged until the frame AFTER this one has been
+ * made current, or tsdf_synchronize).  Only the packing kernel is left to hide: it runs on the frame stream as soon as
+ * the integration of the frame before the current one has released the record buffer, i.e. next to the current
+ * frame's tracker passes instead of in front of the next frame's. */
+int tsdf_queue_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb, int32_t width, int32_t height);
 int tsdf_next_frame(tsdf_handle *h);
 /* Number of frames made current so far (every successful tsdf_set_frame* / tsdf_set_depth_frame adds one; -1 for a
  * NULL handle): lets a caller that uploads a cloud for estimate_new_position check, at SDF::update time

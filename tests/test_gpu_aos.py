@@ -146,6 +146,9 @@ def run_queued(kind, n=5):
             frames.append(tuple(t.numpy() for t in hold) + (hold,))
         elif kind == "aos":
             frames.append(clouds(xyz, nrm, rgb))
+        elif kind == "device":
+            hold = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (xyz, nrm, rgb)]
+            frames.append(hold)
         else:
             frames.append((np.ascontiguousarray(xyz), np.ascontiguousarray(nrm), np.ascontiguousarray(rgb)))
     s = ts.SDF(M, with_color=True)
@@ -155,6 +158,8 @@ def run_queued(kind, n=5):
     def queue(k):
         if kind == "aos":
             s.queue_frame_aos(*frames[k])
+        elif kind == "device":
+            s.queue_frame_device(frames[k][0].data_ptr(), frames[k][1].data_ptr(), frames[k][2].data_ptr(), W, H, keep=frames[k])
         else:
             s.queue_frame(*frames[k][:3])
     poses = []
@@ -177,7 +182,7 @@ def run_queued(kind, n=5):
     return poses, D, Wt, col
 
 
-@pytest.mark.parametrize("kind", ["pageable", "pinned", "aos"])
+@pytest.mark.parametrize("kind", ["pageable", "pinned", "aos", "device"])
 def test_queued_frames_give_the_same_trajectory_and_volume(kind):
     """tsdf_queue_frame / tsdf_next_frame: the next frame is uploaded under the current frame's tracker passes and
     integration; poses and volume must equal the plain set_frame loop bit for bit."""

@@ -103,7 +103,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p
 ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_set_tracker_params", "tsdf_get_pose", "tsdf_set_frame",
-    "tsdf_frame_serial", "tsdf_queue_frame", "tsdf_queue_frame_aos", "tsdf_next_frame",
+    "tsdf_frame_serial", "tsdf_queue_frame", "tsdf_queue_frame_device", "tsdf_queue_frame_aos", "tsdf_next_frame",
     "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
@@ -159,6 +159,7 @@ def lib():
         "tsdf_get_pose": (C.c_int, [H, dp, dp, dp, dp]),
         "tsdf_set_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
         "tsdf_set_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+        "tsdf_queue_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
         "tsdf_set_frame_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32]),
         "tsdf_default_preproc": (None, [C.POINTER(PreprocParams)]),
         "tsdf_set_depth_frame": (C.c_int, [H, C.POINTER(C.c_uint16), fp, u8p, C.c_int32, C.c_int32, C.POINTER(PreprocParams)]),
@@ -451,6 +452,14 @@ class SDF:
         self._keep = [keep]
         self._check(lib().tsdf_set_frame_device(self._h, C.c_void_p(d_xyz), C.c_void_p(d_normals or 0),
                                                 C.c_void_p(d_rgb or 0), int(width), int(height)))
+
+    def queue_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
+        """tsdf_queue_frame_device: queue a frame that is already in HBM (device pointers as ints); its packing kernel
+        runs next to the current frame's tracker passes.  The buffers must stay valid until the frame after this one
+        has been made current (`keep` holds references that long)."""
+        self._queued_keep_dev = getattr(self, "_queued_keep_dev", [])[-1:] + [keep]
+        self._check(lib().tsdf_queue_frame_device(self._h, C.c_void_p(d_xyz), C.c_void_p(d_normals or 0),
+                                                  C.c_void_p(d_rgb or 0), int(width), int(height)))
 
     # -- SDF::update(camera_tracking, cloud_filtered, normals), sdf.h:161-163
     def update(self, camera_tracking=None, cloud_filtered=None, normals=None, rgb=None, want_stats=True):

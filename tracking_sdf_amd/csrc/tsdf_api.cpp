@@ -120,7 +120,7 @@ struct tsdf_handle {
     // two-deep frame queue (tsdf_queue_frame / tsdf_next_frame): the NEXT frame is uploaded and packed into the pixel
     // buffer the current frame does not use while the current one is tracked and integrated
     struct Queued {
-        bool active = false, direct = false, has_nrm = false, has_rgb = false;
+        bool active = false, direct = false, device = false, has_nrm = false, has_rgb = false;
         int nb = 0;
         int32_t su = 1, sv = 0;
         hipError_t err = hipSuccess;       // what the staging thread's HIP calls returned
@@ -1135,7 +1135,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
     tsdf_handle::Queued& q = h->queued;
-    q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.err = hipSuccess;
+    q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess;
     pick_pixel_layout(h, &q.su, &q.sv);      // from the pose of this moment: only the order of the records depends on it
     rc = wait_buffer_free(h, q.nb, h->fstream);
     if (rc) return rc;
@@ -1217,6 +1217,29 @@ int tsdf_queue_frame_aos(tsdf_handle* h, const void* points, const void* normals
     return queue_frame_common(h, nullptr, nullptr, nullptr, width, height, normals != nullptr, color, fill);
 }
 
+int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
+    if (!h || !d_xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_queue_frame_device: bad argument") : TSDF_E_BADARG;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
+    if (h->have_frame && (h->fw != width || h->fh != height))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    rc = ensure_frame_buffers(h, width, height, false);
+    if (rc) return rc;
+    tsdf_handle::Queued& q = h->queued;
+    q.nb = h->fidx ^ 1; q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true; q.err = hipSuccess;
+    pick_pixel_layout(h, &q.su, &q.sv);
+    // the record buffer of the frame before the current one: free once that frame's integration is done -- from then
+    // on the pack runs on the frame stream, next to the current frame's tracker passes
+    rc = wait_buffer_free(h, q.nb, h->fstream);
+    if (rc) return rc;
+    HIP_TRY(h, launch_pack(h->fstream, d_xyz, d_nrm, d_rgb, width, height, h->cfg.pixel_stride, q.su, q.sv, h->pn_buf[q.nb],
+                           h->samples_buf[q.nb], h->ncols, h->nrows, h->cfg.with_color ? 1 : 0));
+    HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
+    q.active = true;
+    return TSDF_OK;
+}
+
 int tsdf_next_frame(tsdf_handle* h) {
     if (!h) return TSDF_E_BADARG;
     tsdf_handle::Queued& q = h->queued;
@@ -1224,7 +1247,11 @@ int tsdf_next_frame(tsdf_handle* h) {
     int rc = bind_device(h);
     if (rc) return rc;
     q.active = false;
-    if (q.direct) {
+    const bool from_device = q.device;
+    q.device = false;
+    if (from_device) {
+        // nothing to wait for on the host: device buffers stay borrowed as tsdf_set_frame_device's do
+    } else if (q.direct) {
         HIP_TRY(h, hipEventSynchronize(h->ev_copied));       // the caller's buffers have been read
     } else {
         std::unique_lock<std::mutex> g(h->qmu);
@@ -1236,7 +1263,7 @@ int tsdf_next_frame(tsdf_handle* h) {
     h->pix_su = q.su; h->pix_sv = q.sv;
     h->frame_side = true;
     h->have_frame = true;
-    h->staged_xyz = true;
+    h->staged_xyz = !from_device;
     h->frame_serial++;
     h->frame_has_nrm = q.has_nrm;
     h->frame_has_rgb = q.has_rgb;
