@@ -9,6 +9,7 @@
                                                                             -> <tag>_bench.json
   3. tools/pmc_memside.py (separate --pmc passes: SQ, TCP, TCC request sizes) -> <tag>_pmc_memside.json
   4. tools/pmc_calibrate.py (known-byte kernels; needs `make pmc_calibrate`)  -> <tag>_fetch_calibration.json
+  6. tools/pmc_ta.py (TA / L1 stall counters of integrate_kernel, one counter per pass) -> <tag>_pmc_ta_integrate.json
   5. rocprofv3 --kernel-trace --stats -- python3 tools/preproc_workload.py  -> <tag>_preproc_kernel_stats.csv
 rocprofv3 always gets the program itself after `--`; --pmc is never combined with a trace domain.
 """
@@ -84,6 +85,7 @@ def main():
     # 3. / 4.
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_memside.py"), out, tag, "--passes=9,10,0,1,2,4,5,6,7"],
                    cwd=ROOT, env=env)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_ta.py"), os.path.join(out, tag + "_pmc_ta_integrate.json")], cwd=ROOT, env=env)
     if os.path.exists(os.path.join(ROOT, "build", "pmc_calibrate")):
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_calibrate.py"), out], cwd=ROOT, env=env)
     print(json.dumps({"value": line["value"], "traffic": line["roofline"]["traffic"], "frac": line["roofline"]["frac"]}))
