@@ -29,8 +29,9 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
     if (MODE != 1 && PIPE == 1) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
     unsigned seg_next = __builtin_amdgcn_readfirstlane(rnd(seed) % nseg);
     unsigned sink = 0;
+    u2 pd = u2{0, 0}; u4 pc = u4{0, 0, 0, 0}; unsigned pseg = 0, pfirst = 99u;       // PIPE 3: the item whose volume data is in flight
     for (int it = 0; it < items_per_wave; ++it) {
-        if (MODE != 1 && PIPE != 1) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
+        if (MODE != 1 && MODE != 4 && PIPE != 1) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
         const unsigned seg = seg_next;
         seg_next = __builtin_amdgcn_readfirstlane(rnd(seed) % nseg);
         if (PIPE == 2 && MODE != 2) {
@@ -53,12 +54,27 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
         const unsigned nbase = rnd(seed) % nrec;
         u4 na = u4{0, 0, 0, 0}, nb = na;
         if (MODE != 1 && PIPE == 1 && it + 1 < items_per_wave) { na = rec[gather_addr(nbase, 0)]; nb = rec[gather_addr(nbase, 1)]; }
-        if (MODE != 2) {
+        if (MODE != 2 && PIPE != 3) {
             u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
             if (live) { d = dw[(size_t)seg * 64 + lane]; c = __builtin_nontemporal_load(&col[(size_t)seg * 64 + lane]); }
             d.x += acc; c.y ^= d.y;
-            if (MODE != 3 && live) { dw[(size_t)seg * 64 + lane] = d; __builtin_nontemporal_store(c, &col[(size_t)seg * 64 + lane]); }
+            // MODE 4 (no gathers): the stores go to ANOTHER random segment (copy-like)
+            const unsigned wseg = MODE == 4 ? __builtin_amdgcn_readfirstlane((seg * 2654435761u) % nseg) : seg;
+            if (MODE != 3 && live) { dw[(size_t)wseg * 64 + lane] = d; __builtin_nontemporal_store(c, &col[(size_t)wseg * 64 + lane]); }
             if (MODE == 3) acc ^= d.x + c.y;
+        }
+        if (MODE != 2 && PIPE == 3) {
+            // volume loads one item ahead: the loads of item it + 1 are in flight while item it is stored
+            const unsigned nfirst = (seg_next * 40503u >> 7) % 30u;
+            const bool nlive = lane >= nfirst && lane < nfirst + 34u;
+            u2 nd = u2{0, 0}; u4 nc = u4{0, 0, 0, 0};
+            if (it + 1 < items_per_wave && nlive) { nd = dw[(size_t)seg_next * 64 + lane]; nc = __builtin_nontemporal_load(&col[(size_t)seg_next * 64 + lane]); }
+            const bool plive = pfirst != 99u && lane >= pfirst && lane < pfirst + 34u;
+            u2 d = pd; u4 c = pc;
+            d.x += acc; c.y ^= d.y;
+            if (MODE != 3 && plive) { dw[(size_t)pseg * 64 + lane] = d; __builtin_nontemporal_store(c, &col[(size_t)pseg * 64 + lane]); }
+            if (MODE == 3) acc ^= d.x + c.y;
+            pd = nd; pc = nc; pseg = seg_next; pfirst = it + 1 < items_per_wave ? nfirst : 99u;
         }
         base = nbase; ga = na; gb = nb;
     }
@@ -72,20 +88,21 @@ int main() {
     CHECK(hipMalloc(&out, 1 << 20));
     CHECK(hipMemset(rec, 1, (size_t)nrec * 32)); CHECK(hipMemset(dw, 0, (size_t)nseg * 512)); CHECK(hipMemset(col, 0, (size_t)nseg * 1024));
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-    const char* names[4] = {"all", "no_gathers", "no_volume", "no_stores"};
+    const char* names[5] = {"all", "no_gathers", "no_volume", "no_stores", "no_gathers_stores_elsewhere"};
     // grid sweep (199.7k items in all): wavefronts per CU = blocks * 4 / 256
     const int grids[6] = {1280, 256, 512, 768, 1024, 2048};
     for (int gi = 0; gi < 6; ++gi) {
         const int blocks = grids[gi], ipw = (199680 + blocks * 4 - 1) / (blocks * 4);
         for (int rep = 0; rep < 3; ++rep)
-            for (int pipe = 0; pipe < (gi == 0 ? 3 : 1); ++pipe)
-                for (int mode = 0; mode < (gi == 0 ? 4 : 2); ++mode) {
+            for (int pipe = 0; pipe < (gi == 0 ? 4 : 1); ++pipe)
+                for (int mode = 0; mode < (gi == 0 ? (pipe == 0 ? 5 : 4) : 2); ++mode) {
                     CHECK(hipEventRecord(a));
                     for (int k = 0; k < 10; ++k) {
 #define L(M, P) mix<M, P><<<blocks, 256>>>(rec, nrec, dw, col, nseg, ipw, out)
-                        if (pipe == 0) { if (mode == 0) L(0, 0); if (mode == 1) L(1, 0); if (mode == 2) L(2, 0); if (mode == 3) L(3, 0); }
+                        if (pipe == 0) { if (mode == 0) L(0, 0); if (mode == 1) L(1, 0); if (mode == 2) L(2, 0); if (mode == 3) L(3, 0); if (mode == 4) L(4, 0); }
                         else if (pipe == 1) { if (mode == 0) L(0, 1); if (mode == 1) L(1, 1); if (mode == 2) L(2, 1); if (mode == 3) L(3, 1); }
-                        else { if (mode == 0) L(0, 2); if (mode == 1) L(1, 2); if (mode == 2) L(2, 2); if (mode == 3) L(3, 2); }
+                        else if (pipe == 2) { if (mode == 0) L(0, 2); if (mode == 1) L(1, 2); if (mode == 2) L(2, 2); if (mode == 3) L(3, 2); }
+                        else { if (mode == 0) L(0, 3); if (mode == 1) L(1, 3); if (mode == 2) L(2, 3); if (mode == 3) L(3, 3); }
                     }
                     CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
                     float ms; CHECK(hipEventElapsedTime(&ms, a, b));
