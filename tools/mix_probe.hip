@@ -17,14 +17,23 @@ __device__ __forceinline__ unsigned rnd(unsigned& s) { s = s * 1664525u + 101390
 
 template <int MODE, int PIPE>
 __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned nrec, u2* __restrict__ dw, u4* __restrict__ col,
-                                           unsigned nseg, int items_per_wave, unsigned* __restrict__ out) {
+                                           unsigned nseg, int items_per_wave, unsigned* __restrict__ out, unsigned window = 0, unsigned share = 1) {
     const unsigned lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     unsigned seed = wave * 2654435761u + 12345u, acc = 0;
     auto gather_addr = [&](unsigned base, unsigned half_of) {      // record of lane pair, 1..2 records apart
         const unsigned pair = half_of * 32 + (lane >> 1);
         return (size_t)((base + pair + (pair >> 1)) % nrec) * 2 + (lane & 1);
     };
-    unsigned base = rnd(seed) % nrec;
+    // window > 0: the gathers of `share` consecutive workgroups (share = 1: the four wavefronts of one workgroup) fall into a
+    // window of `window` records (480 = one image column) that moves every 8 items -- do concurrent wavefronts that
+    // share pixels get them from the L1?
+    unsigned wseed = (blockIdx.x / share) * 747796405u + 2891336453u;
+    auto pick = [&](int it) -> unsigned {
+        if (window == 0) return rnd(seed) % nrec;
+        if ((it & 7) == 0) wseed = wseed * 1664525u + 1013904223u;
+        return ((wseed >> 8) % (nrec - window) + rnd(seed) % window) % nrec;
+    };
+    unsigned base = pick(0);
     u4 ga = u4{0, 0, 0, 0}, gb = ga;
     if (MODE != 1 && PIPE == 1) { ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
     unsigned seg_next = __builtin_amdgcn_readfirstlane(rnd(seed) % nseg);
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
         const unsigned first = __builtin_amdgcn_readfirstlane(rnd(seed) % 30u);
         const bool live = lane >= first && lane < first + 34u;
         acc ^= ga.x + gb.w;                                        // consume the gathers
-        const unsigned nbase = rnd(seed) % nrec;
+        const unsigned nbase = pick(it + 1);
         u4 na = u4{0, 0, 0, 0}, nb = na;
         if (MODE != 1 && PIPE == 1 && it + 1 < items_per_wave) { na = rec[gather_addr(nbase, 0)]; nb = rec[gather_addr(nbase, 1)]; }
         if (MODE != 2 && PIPE != 3) {
@@ -108,6 +117,16 @@ int main() {
                     float ms; CHECK(hipEventElapsedTime(&ms, a, b));
                     if (rep == 2) printf("{\"workgroups\": %d, \"items_per_wavefront\": %d, \"mode\": \"%s\", \"pipe\": %d, \"us_per_launch\": %.1f}\n", blocks, ipw, names[mode], pipe, ms * 100.0);
                 }
+    }
+    for (int wi = 0; wi < 5; ++wi) {
+        const unsigned windows[5] = {0, 480, 960, 480, 480}, shares[5] = {1, 1, 1, 8, 256};
+        for (int rep = 0; rep < 3; ++rep) {
+            CHECK(hipEventRecord(a));
+            for (int k = 0; k < 10; ++k) mix<0, 0><<<1280, 256>>>(rec, nrec, dw, col, nseg, 39, out, windows[wi], shares[wi]);
+            CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+            float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+            if (rep == 2) printf("{\"gather_window_records\": %u, \"workgroups_sharing_a_window\": %u, \"mode\": \"all\", \"us_per_launch\": %.1f}\n", windows[wi], shares[wi], ms * 100.0);
+        }
     }
     return 0;
 }
