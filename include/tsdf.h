@@ -292,7 +292,10 @@ int tsdf_comm_init_shm(tsdf_handle *h, int32_t nranks, int32_t rank, const char 
  * behind it at system scope, waits for the words of the other ranks in its own buffer and adds the rows in rank
  * order: the same bits on every rank and as the shared-memory fan-in.  A rank that waits longer than 5 s gives up and
  * the call that launched the pass returns TSDF_E_COMM.  Rendezvous, `name` and time limit as tsdf_comm_init_shm (the
- * segment carries the IPC handles); TSDF_E_COMM when the runtime refuses IPC, and nothing is left configured then. */
+ * segment carries the IPC handles); TSDF_E_COMM when the runtime refuses IPC, and nothing is left configured then.
+ * Two handles of ONE process (same pid and process token) lend each other their raw buffer pointers instead of IPC
+ * mappings: such sibling handles must leave the exchange (tsdf_comm_finalize / tsdf_destroy) before any of them is
+ * destroyed. */
 int tsdf_comm_init_peer(tsdf_handle *h, int32_t nranks, int32_t rank, const char *name);
 int tsdf_comm_finalize(tsdf_handle *h);                          /* drop the RCCL communicator / the shared segment / the peer mappings (hook, if any, takes over) */
 /* Alternative: let the host do the 28-double sum (e.g. torch.distributed); fn = NULL removes it. */

@@ -170,6 +170,16 @@ def run_queued(kind, n=5):
             queue(k + 1)                          # ... and frame k+1 is staged while k is tracked and integrated
             with pytest.raises(ts.TsdfError):     # the queue is two deep
                 queue(k + 1)
+            if k == 1:
+                # tsdf_set_frame* while a frame is queued: refused BEFORE any side effect (round 3 re-allocated the frame
+                # buffers for the other size and wrote into the planes the staging thread was filling, then refused)
+                big = np.zeros((2 * H, 2 * W, 3), np.float32)
+                with pytest.raises(ts.TsdfError):
+                    s.set_frame(big, big, np.zeros((2 * H, 2 * W, 3), np.uint8))
+                with pytest.raises(ts.TsdfError):
+                    s.set_frame_aos(*clouds(big, big, np.zeros((2 * H, 2 * W, 3), np.uint8)))
+                with pytest.raises(ts.TsdfError):
+                    s.set_depth_frame(np.ones((2 * H, 2 * W), np.float32), np.zeros((2 * H, 2 * W, 3), np.uint8))
         if k > 0:
             t.estimate_new_position()
         s.update()

@@ -163,6 +163,40 @@ def test_accumulate_stale_carry_with_out_of_grid_samples():
     assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
 
 
+def test_tracker_constants_set_after_creation_reach_the_kernel():
+    """camera_tracking.cpp:3-17: the reference's constructor accepts any v_h / w_h and forms its finite-difference
+    denominators from them.  A volume created with the defaults whose CameraTracking is then constructed with other steps
+    (tsdf_set_tracker_params) must perturb by AND divide by the new steps: same A, b as a handle created with those
+    steps, and as the oracle (round 3 divided by the old denominators)."""
+    import tracking_sdf_amd as ts
+    m = 64
+    gn = (20, 0.001, 0.5, 0.02)
+    seq, fr, oo, _, go_ref, gt_ref = _fused_pair(m, gn=gn)
+    ot = orc.CameraTracking(oo, *gn)
+    ot.set_K(seq.K)
+    go = ts.SDF(m, VOL["width"], VOL["height"], VOL["depth"], VOL["origin"], VOL["delta"], VOL["epsilon"])   # default steps
+    gt = ts.CameraTracking(*gn, go)                         # ... replaced here
+    gt.set_K(seq.K)
+    go.upload(oo.D, oo.W)
+    k = 3
+    xyz = fr[k][0]
+    for t_ in (ot, gt, gt_ref):
+        t_.set_camera_transformation(seq.R[k - 1], seq.t[k - 1])
+    A_o, b_o, st_o = ot.accumulate(oo, orc.Cloud(xyz), threads=1, stale_carry=True)
+    go.set_frame(xyz); go_ref.set_frame(xyz)
+    A_g, b_g, st_g = gt.accumulate()
+    A_r, b_r, st_r = gt_ref.accumulate()
+    assert st_g["n_terms"] == st_o["n_terms"] == st_r["n_terms"] and st_o["n_ok"] > 500
+    assert np.array_equal(A_g, A_r) and np.array_equal(b_g, b_r)
+    assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
+    # and the default steps give something else: the test would notice a kernel that ignored the new ones
+    _, _, _, _, go_d, gt_d = _fused_pair(m)
+    gt_d.set_camera_transformation(seq.R[k - 1], seq.t[k - 1])
+    go_d.set_frame(xyz)
+    A_d, _, _ = gt_d.accumulate()
+    assert sym_rel_err(A_d, A_o) > 1e-3
+
+
 CARRY_THREADS = [1, 2, 3, 8, 16]
 
 

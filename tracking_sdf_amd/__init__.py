@@ -421,9 +421,10 @@ class SDF:
             if a is not None and not (a.flags["C_CONTIGUOUS"] and a.dtype == dt):
                 raise ValueError("queue_frame borrows the buffers: C-contiguous float32 / uint8 arrays are needed")
         h, w = xyz.shape[:2]
-        self._queued_keep = (xyz, normals, rgb)
+        keep = (xyz, normals, rgb)
         self._check(lib().tsdf_queue_frame(self._h, _fptr(xyz), _fptr(normals) if normals is not None else None,
                                            rgb.ctypes.data_as(C.POINTER(C.c_uint8)) if rgb is not None else None, w, h))
+        self._queued_keep = keep       # only now: a refused call must not drop the references of the frame that IS queued
 
     def queue_frame_aos(self, points, normals=None):
         """tsdf_queue_frame_aos: as queue_frame, for arrays of point structs (see set_frame_aos)."""
@@ -439,8 +440,9 @@ class SDF:
             nn = C.c_void_p(normals.ctypes.data)
         if not (points.flags["C_CONTIGUOUS"] and (normals is None or normals.flags["C_CONTIGUOUS"])):
             raise ValueError("queue_frame_aos borrows the buffers: C-contiguous arrays are needed")
-        self._queued_keep = (points, normals)
+        keep = (points, normals)
         self._check(lib().tsdf_queue_frame_aos(self._h, C.c_void_p(points.ctypes.data), nn, C.byref(lay), points.shape[1], points.shape[0]))
+        self._queued_keep = keep
 
     def next_frame(self):
         """tsdf_next_frame: the queued frame becomes the current one; its buffers are the caller's again."""
@@ -457,9 +459,9 @@ class SDF:
         """tsdf_queue_frame_device: queue a frame that is already in HBM (device pointers as ints); its packing kernel
         runs next to the current frame's tracker passes.  The buffers must stay valid until the frame after this one
         has been made current (`keep` holds references that long)."""
-        self._queued_keep_dev = getattr(self, "_queued_keep_dev", [])[-1:] + [keep]
         self._check(lib().tsdf_queue_frame_device(self._h, C.c_void_p(d_xyz), C.c_void_p(d_normals or 0),
                                                   C.c_void_p(d_rgb or 0), int(width), int(height)))
+        self._queued_keep_dev = getattr(self, "_queued_keep_dev", [])[-1:] + [keep]
 
     # -- SDF::update(camera_tracking, cloud_filtered, normals), sdf.h:161-163
     def update(self, camera_tracking=None, cloud_filtered=None, normals=None, rgb=None, want_stats=True):

@@ -204,6 +204,8 @@ struct tsdf_handle {
         int nranks = 0, rank = 0;
         char* own = nullptr;            // this rank's buffer: nranks x 2 slots of kPeerSlotBytes, uncached device memory
         std::vector<char*> mapped;      // rank r's buffer as mapped here (mapped[rank] == own)
+        std::vector<char> via_ipc;      // mapped[r] came from hipIpcOpenMemHandle (and is closed again); a sibling handle of
+                                        // this process lends its raw pointer instead and must outlive this handle's exchange
         char** bases_dev = nullptr;     // the same pointers on the device
         bool active() const { return own != nullptr; }
     } peer;
@@ -477,10 +479,23 @@ inline unsigned long long shm_word(const tsdf_handle* h, unsigned long long seq)
     return (h->shm.gen << 32) | (seq & 0xFFFFFFFFull);
 }
 
+// 64 random bits drawn once per process: tells "another handle of this process" from "a process with the same pid in
+// another PID namespace" when peers compare notes in the shared segment
+unsigned long long process_token() {
+    static const unsigned long long tok = [] {
+        unsigned long long t = 0;
+        if (FILE* f = std::fopen("/dev/urandom", "rb")) { if (std::fread(&t, sizeof t, 1, f) != 1) t = 0; std::fclose(f); }
+        if (!t) t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)getpid() << 32) ^ (unsigned long long)(uintptr_t)&t;
+        return t | 1ull;
+    }();
+    return tok;
+}
+
 void peer_close(tsdf_handle* h) {
     for (int r = 0; r < (int)h->peer.mapped.size(); ++r)
-        if (h->peer.mapped[r] && r != h->peer.rank) (void)hipIpcCloseMemHandle(h->peer.mapped[r]);
+        if (h->peer.mapped[r] && h->peer.via_ipc[r]) (void)hipIpcCloseMemHandle(h->peer.mapped[r]);
     h->peer.mapped.clear();
+    h->peer.via_ipc.clear();
     if (h->peer.bases_dev) (void)hipFree(h->peer.bases_dev);
     if (h->peer.own) (void)hipFree(h->peer.own);
     h->peer.bases_dev = nullptr; h->peer.own = nullptr; h->peer.nranks = 0;
@@ -773,6 +788,18 @@ int32_t tsdf_halo_for(const tsdf_config* c, float max_range) {
     return (int32_t)std::ceil((double)c->w_h * (double)max_range * per_m) + (int32_t)std::ceil((double)c->v_h) + 2;
 }
 
+// camera_tracking.cpp:11-17: the finite-difference denominators are float quotients formed once from v_h / w_h; they
+// must follow the steps whenever those change (tsdf_create, tsdf_set_tracker_params), or the kernel perturbs by the new
+// step and divides by the old one.
+static void set_step_denominators(tsdf_handle* h, float v_h, float w_h) {
+    const Grid& g = h->grid;
+    const float v_h2 = 2 * v_h;
+    h->v_h2_w = v_h2 / g.m_div_w;
+    h->v_h2_h = v_h2 / g.m_div_h;
+    h->v_h2_d = v_h2 / g.m_div_d;
+    h->wh2 = 2 * w_h;
+}
+
 int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     if (!cfg || !out) return fail(nullptr, TSDF_E_BADARG, "tsdf_create: null argument");
     *out = nullptr;
@@ -815,11 +842,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     const double rot0[9] = {1, 0, 0, 0, 0, -1, 0, -1, 0};
     const double trans0[3] = {0, 0, 1};
     hm::set_pose(h->pose, rot0, trans0);
-    const float v_h2 = 2 * cfg->v_h;
-    h->v_h2_w = v_h2 / g.m_div_w;
-    h->v_h2_h = v_h2 / g.m_div_h;
-    h->v_h2_d = v_h2 / g.m_div_d;
-    h->wh2 = 2 * cfg->w_h;
+    set_step_denominators(h, cfg->v_h, cfg->w_h);
 
     auto bail = [&](int code) { std::string msg = h->err; tsdf_destroy(h); fail(nullptr, code, "%s", msg.c_str()); return code; };
 #define CREATE_TRY(expr)                                                                              \
@@ -986,6 +1009,7 @@ int tsdf_set_tracker_params(tsdf_handle* h, int32_t gn_max_iter, float max_twist
     if (gn_max_iter < 0 || !(v_h > 0.0f) || !(w_h > 0.0f) || !(max_twist_diff == max_twist_diff))
         return fail(h, TSDF_E_BADARG, "tsdf_set_tracker_params: bad argument (iterations %d, v_h %g, w_h %g)", gn_max_iter, (double)v_h, (double)w_h);
     h->cfg.gn_max_iter = gn_max_iter; h->cfg.max_twist_diff = max_twist_diff; h->cfg.v_h = v_h; h->cfg.w_h = w_h;
+    set_step_denominators(h, v_h, w_h);
     return TSDF_OK;
 }
 
@@ -1072,6 +1096,7 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
 
 int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
     if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame: bad argument") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame");
     int rc = bind_device(h);
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, true);
@@ -1136,6 +1161,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     const size_t npix = (size_t)width * height;
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess;
+    h->staged_xyz = false;                   // in_xyz / in_nrm / in_rgb are about to hold the QUEUED frame, not the current one
     pick_pixel_layout(h, &q.su, &q.sv);      // from the pose of this moment: only the order of the records depends on it
     rc = wait_buffer_free(h, q.nb, h->fstream);
     if (rc) return rc;
@@ -1272,6 +1298,7 @@ int tsdf_next_frame(tsdf_handle* h) {
 
 int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
     if (!h || !d_xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_device: bad argument") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_device");
     int rc = bind_device(h);
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, false);
@@ -1284,6 +1311,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
                        int32_t width, int32_t height) {
     if (!h || !L || (!points && !normals) || width <= 0 || height <= 0)
         return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: bad argument") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_aos");
     const bool color = points && L->r_offset >= 0 && L->g_offset >= 0 && L->b_offset >= 0;
     if (points && (L->point_stride < 12 || L->xyz_offset < 0 || L->xyz_offset + 12 > L->point_stride ||
                    (color && (L->r_offset >= L->point_stride || L->g_offset >= L->point_stride || L->b_offset >= L->point_stride))))
@@ -1349,6 +1377,7 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
         return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: the bilateral grid takes sigma_s in [1, 30] pixels, not %g", (double)pp.sigma_s);
     if (depth16 && !(pp.depth_scale > 0))
         return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: depth_scale must be positive");
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_depth_frame");
     int rc = bind_device(h);
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, true);
@@ -2072,6 +2101,7 @@ int tsdf_comm_init_peer(tsdf_handle* h, int32_t nranks, int32_t rank, const char
     h->peer.own = static_cast<char*>(own);
     h->peer.nranks = nranks; h->peer.rank = rank;
     h->peer.mapped.assign((size_t)nranks, nullptr);
+    h->peer.via_ipc.assign((size_t)nranks, 0);
     h->peer.mapped[(size_t)rank] = h->peer.own;
     if ((e = hipMemsetAsync(own, 0, bytes, h->stream)) != hipSuccess || (e = hipStreamSynchronize(h->stream)) != hipSuccess)
         return give_up(TSDF_E_HIP, "zeroing the exchange buffer", e);
@@ -2082,6 +2112,7 @@ int tsdf_comm_init_peer(tsdf_handle* h, int32_t nranks, int32_t rank, const char
     const unsigned long long gen = h->shm.gen;
     std::memcpy(entries + (size_t)rank * kShmPeerEntry, &mine, sizeof mine);
     *entry_word(rank, 2) = (unsigned long long)getpid();
+    *entry_word(rank, 4) = process_token();          // pids repeat across PID namespaces that share /dev/shm; this does not
     *entry_word(rank, 3) = (unsigned long long)(uintptr_t)own;
     __atomic_store_n(entry_word(rank, 0), gen, __ATOMIC_RELEASE);
     const auto t0 = std::chrono::steady_clock::now();
@@ -2095,7 +2126,9 @@ int tsdf_comm_init_peer(tsdf_handle* h, int32_t nranks, int32_t rank, const char
     for (int r = 0; r < nranks; ++r) {
         if (r == rank) continue;
         if (!wait_for(r, 0)) return give_up(TSDF_E_COMM, "a rank did not publish its buffer within 20 s", hipSuccess);
-        if (*entry_word(r, 2) == (unsigned long long)getpid()) {        // another handle of this very process: no IPC needed (or possible)
+        if (*entry_word(r, 2) == (unsigned long long)getpid() && *entry_word(r, 4) == process_token()) {
+            // another handle of this very process: no IPC needed (or possible).  Its raw pointer is borrowed: that handle
+            // must stay alive until this one has left the exchange (tsdf_comm_finalize / tsdf_destroy), see include/tsdf.h.
             h->peer.mapped[(size_t)r] = reinterpret_cast<char*>((uintptr_t)*entry_word(r, 3));
             continue;
         }
@@ -2105,6 +2138,7 @@ int tsdf_comm_init_peer(tsdf_handle* h, int32_t nranks, int32_t rank, const char
         if ((e = hipIpcOpenMemHandle(&ptr, theirs, hipIpcMemLazyEnablePeerAccess)) != hipSuccess)
             return give_up(TSDF_E_COMM, "hipIpcOpenMemHandle", e);
         h->peer.mapped[(size_t)r] = static_cast<char*>(ptr);
+        h->peer.via_ipc[(size_t)r] = 1;
     }
     if ((e = hipMalloc((void**)&h->peer.bases_dev, (size_t)nranks * sizeof(char*))) != hipSuccess ||
         (e = hipMemcpy(h->peer.bases_dev, h->peer.mapped.data(), (size_t)nranks * sizeof(char*), hipMemcpyHostToDevice)) != hipSuccess)
@@ -2254,6 +2288,10 @@ int tsdf_read_counters(tsdf_handle* h, tsdf_counters* out, int32_t reset) {
 int tsdf_synchronize(tsdf_handle* h) {
     int rc = check_ready(h, false);
     if (rc) return rc;
+    {   // a queued pageable frame: its copies and pack are only on the frame stream once the staging thread has issued them
+        std::unique_lock<std::mutex> g(h->qmu);
+        h->qcv.wait(g, [&] { return !h->qbusy; });
+    }
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return TSDF_OK;
