@@ -113,6 +113,8 @@ def lib():
     L.orc_mesh_colors.argtypes = [C.POINTER(_Sdf), fp, C.c_int64, fp]
     L.orc_direct_exponential_map.argtypes = [dp, C.c_double, dp]
     L.orc_inverse3.argtypes = [dp, dp]
+    L.orc_set_eigen_order.argtypes = [C.c_int32]
+    L.orc_get_eigen_order.restype = C.c_int32
     L.orc_inverse6.restype = C.c_int32
     L.orc_inverse6.argtypes = [dp, dp]
     _lib = L
@@ -329,6 +331,15 @@ class CameraTracking:
         return {"iterations": int(st.iterations), "stopped": bool(st.stopped),
                 "nonfinite": bool(st.nonfinite), "n_terms_last": int(st.n_terms_last),
                 "last_twist": np.array(st.last_twist)}
+
+
+def set_eigen_order(version):
+    """32 (default): Eigen 3.2's sequential fixed-size products; 33: the redux order of Eigen >= 3.3 (tsdf_oracle.c)."""
+    lib().orc_set_eigen_order(int(version))
+
+
+def get_eigen_order():
+    return int(lib().orc_get_eigen_order())
 
 
 def direct_exponential_map(v, delta_t=1.0):

@@ -34,16 +34,31 @@ f32 = np.float32
 f64 = np.float64
 
 
+EIGEN_ORDER = 32
+"""32: Eigen 3.2's sequential fixed-size products ((a0 b0 + a1 b1) + a2 b2) -- the default, the reference's build era.
+33: the lazy-product evaluator of Eigen >= 3.3, whose coefficient is a .sum() redux: a0 b0 + (a1 b1 + a2 b2).
+(set_eigen_order; the C oracle has the same switch, orc_set_eigen_order)"""
+
+
+def set_eigen_order(version):
+    global EIGEN_ORDER
+    EIGEN_ORDER = 33 if int(version) >= 33 else 32
+
+
+def _prod3(a0, b0, a1, b1, a2, b2):
+    return a0 * b0 + (a1 * b1 + a2 * b2) if EIGEN_ORDER >= 33 else (a0 * b0 + a1 * b1) + a2 * b2
+
+
 def _mat3_vec(M, x, y, z):
-    """Eigen 3.2 fixed-size Matrix3d * Vector3d, for arrays of vectors: row r -> ((M[r,0] x + M[r,1] y) + M[r,2] z)."""
-    return [(M[r, 0] * x + M[r, 1] * y) + M[r, 2] * z for r in range(3)]
+    """Fixed-size Matrix3d * Vector3d, for arrays of vectors, in the order of EIGEN_ORDER."""
+    return [_prod3(M[r, 0], x, M[r, 1], y, M[r, 2], z) for r in range(3)]
 
 
 def _mat3_mat3(A, B):
     out = np.empty((3, 3), dtype=f64)
     for r in range(3):
         for c in range(3):
-            out[r, c] = (A[r, 0] * B[0, c] + A[r, 1] * B[1, c]) + A[r, 2] * B[2, c]
+            out[r, c] = _prod3(A[r, 0], B[0, c], A[r, 1], B[1, c], A[r, 2], B[2, c])
     return out
 
 

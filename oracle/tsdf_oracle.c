@@ -34,15 +34,28 @@ static inline int32_t trunc_f64(double f) {
     return (int32_t)f;
 }
 
-/* Eigen 3.2 coefficient-based fixed-size products: sequential accumulation. */
+/* Fixed-size 3x3 * 3 and 3x3 * 3x3 products (camera_tracking.cpp:51-58, :92-145, :237-238, :40-47; sdf.cpp:245).
+ * Eigen 3.2 (the default here: the reference's build era) evaluates a coefficient of a small fixed-size product
+ * sequentially, ((a0*b0 + a1*b1) + a2*b2).  Eigen >= 3.3 sends the same expressions through the lazy-product
+ * evaluator, whose coefficient is (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum(), i.e. the redux unroller's
+ * a0*b0 + (a1*b1 + a2*b2).  A reference rebuilt with a modern Eigen therefore differs in last bits of every camera
+ * coordinate; orc_set_eigen_order(33) restates that build so that the difference can be quantified
+ * (tests/test_eigen_order.py).  The HIP path implements the 3.2 order only.
+ * Process-wide switch: test infrastructure, not thread-safe against concurrent oracle calls. */
+static int g_eigen_redux_products = 0;
+void orc_set_eigen_order(int32_t version) { g_eigen_redux_products = version >= 33; }
+int32_t orc_get_eigen_order(void) { return g_eigen_redux_products ? 33 : 32; }
+static inline double prod3(double a0, double b0, double a1, double b1, double a2, double b2) {
+    return g_eigen_redux_products ? a0 * b0 + (a1 * b1 + a2 * b2) : (a0 * b0 + a1 * b1) + a2 * b2;
+}
 static inline void mat3_vec(const double M[9], const double v[3], double out[3]) {
     for (int r = 0; r < 3; ++r)
-        out[r] = (M[3 * r + 0] * v[0] + M[3 * r + 1] * v[1]) + M[3 * r + 2] * v[2];
+        out[r] = prod3(M[3 * r + 0], v[0], M[3 * r + 1], v[1], M[3 * r + 2], v[2]);
 }
 static inline void mat3_mat3(const double A[9], const double B[9], double out[9]) {
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
-            out[3 * r + c] = (A[3 * r + 0] * B[0 + c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+            out[3 * r + c] = prod3(A[3 * r + 0], B[0 + c], A[3 * r + 1], B[3 + c], A[3 * r + 2], B[6 + c]);
 }
 /* Eigen redux unroller for a 3-term sum: x0 + (x1 + x2). */
 static inline double dot3_redux(const double a[3], const double b[3]) {

@@ -35,6 +35,11 @@
 extern "C" {
 #endif
 
+/* Which Eigen the restated reference is "built" with: 32 (default) = Eigen 3.2's sequential fixed-size products
+ * ((a0*b0 + a1*b1) + a2*b2); 33 = the lazy-product redux of Eigen >= 3.3, a0*b0 + (a1*b1 + a2*b2).  Process-wide. */
+void orc_set_eigen_order(int32_t version);
+int32_t orc_get_eigen_order(void);
+
 /* ---- voxel grid (class SDF, include/sdf_3d_reconstruction/sdf.h:35-186) ---- */
 typedef struct orc_sdf {
     int32_t m;                       /* sdf.h:69 */

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""How much does the Eigen version the reference is built with change its results?  (CPU only.)
+
+The oracle, host_math.hpp and the HIP kernels restate Eigen 3.2's sequential fixed-size products ((a0*b0 + a1*b1) + a2*b2);
+a reference rebuilt with Eigen >= 3.3 evaluates the same expressions (camera_tracking.cpp:40-58, :92-145, :237-238) as
+a0*b0 + (a1*b1 + a2*b2).  This script runs the C oracle both ways (orc_set_eigen_order) on the same inputs:
+  * one 64^3 integration of a noisy frame: voxels whose D / W / colour differ, voxels that took another pixel,
+  * a free run of N frames (track + integrate): pose differences frame by frame.
+Prints one JSON object."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as orc                                    # noqa: E402
+from tracking_sdf_amd import synth                      # noqa: E402
+
+VOL = dict(width=6.0, height=6.0, depth=3.5, origin=(-3.0, -3.0, -0.5), delta=0.3, epsilon=0.025)
+
+
+def make(m, K):
+    s = orc.SDF(m, VOL["width"], VOL["height"], VOL["depth"], VOL["origin"], VOL["delta"], VOL["epsilon"])
+    t = orc.CameraTracking(s, 20, 0.001, 1.0, 0.01)
+    t.set_K(K)
+    return s, t
+
+
+def ulps(a, b):
+    ia = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
+def integration(m, width, height):
+    seq = synth.Sequence(n_frames=3, width=width, height=height, noise=True, holes=0.02, step=4)
+    xyz, nrm, rgb = seq.frame(2)
+    out = {}
+    vols = {}
+    for order in (32, 33):
+        orc.set_eigen_order(order)
+        s, t = make(m, seq.K)
+        t.set_camera_transformation(seq.R[2], seq.t[2])          # a general pose (not the axis-aligned initial one)
+        n = s.update(t, orc.Cloud(xyz, nrm, rgb), with_color=True)
+        vols[order] = (n, s.D.copy(), s.W.copy(), s.Color_W.copy(), s.R.copy())
+    orc.set_eigen_order(32)
+    (n0, D0, W0, C0, R0), (n1, D1, W1, C1, R1) = vols[32], vols[33]
+    upd = (W0 > 0) | (W1 > 0)
+    dD = ulps(D0, D1)
+    out["voxels"] = int(m) ** 3
+    out["updated_eigen32"] = int(n0)
+    out["updated_eigen33"] = int(n1)
+    out["updated_in_one_order_only"] = int(((W0 > 0) != (W1 > 0)).sum())
+    out["D_differs"] = int((dD[upd] > 0).sum())
+    out["D_differs_by_more_than_4_ulp"] = int((dD[upd] > 4).sum())      # another pixel or the other side of a test, not a last bit
+    out["D_max_abs_difference_m"] = float(np.max(np.abs(D0[upd] - D1[upd])))
+    out["W_differs"] = int((ulps(W0, W1)[upd] > 0).sum())
+    out["colour_R_differs"] = int((ulps(R0, R1)[upd] > 0).sum())
+    return out
+
+
+def free_run(m, width, height, n):
+    seq = synth.Sequence(n_frames=n, width=width, height=height, noise=True, holes=0.02, step=4)
+    poses = {}
+    iters = {}
+    for order in (32, 33):
+        orc.set_eigen_order(order)
+        s, t = make(m, seq.K)
+        pp, it = [], []
+        for k in range(n):
+            xyz, nrm, rgb = seq.frame(k)
+            c = orc.Cloud(xyz, nrm, rgb)
+            if k > 0:
+                st = t.estimate_new_position(s, c)
+                it.append(st["iterations"])
+            s.update(t, c, with_color=False)
+            pp.append((t.rot.copy(), t.trans.copy()))
+        poses[order], iters[order] = pp, it
+    orc.set_eigen_order(32)
+    dt = [float(np.max(np.abs(a[1] - b[1]))) for a, b in zip(poses[32], poses[33])]
+    dr = [float(np.max(np.abs(a[0] - b[0]))) for a, b in zip(poses[32], poses[33])]
+    return {"frames": n, "translation_max_abs_difference_m_by_frame": dt, "rotation_max_abs_difference_by_frame": dr,
+            "same_iteration_counts": iters[32] == iters[33], "iterations_eigen32": iters[32], "iterations_eigen33": iters[33]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, default=64)
+    ap.add_argument("--width", type=int, default=160)
+    ap.add_argument("--height", type=int, default=120)
+    ap.add_argument("--frames", type=int, default=10)
+    a = ap.parse_args()
+    print(json.dumps({"integration_one_frame": integration(a.m, a.width, a.height),
+                      "free_run": free_run(a.m, a.width, a.height, a.frames)}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

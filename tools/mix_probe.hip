@@ -6,6 +6,12 @@
 // 2 = no volume traffic, 3 = gathers + loads (no stores).  PIPE = 1 prefetches the next item's gathers; PIPE = 2 pulls the
 // NEXT item's volume lines (4 x 128 B of {D,W}, 8 of colour) into L2 with scalar loads one item ahead: does a vector
 // load that hits L2 instead of HBM free the CU's vector-memory pipeline sooner?
+// Round 4 additions: DENSE = 1 moves the SAME volume bytes as dense 64-lane batches -- every other
+// item issues one {D,W} + colour load / store pair whose lanes 0..31 cover 32 contiguous voxels of one segment and lanes
+// 32..63 32 contiguous voxels of the segment of the item before (what a wave-private queue of live lanes pops) -- with
+// the two gathers per item unchanged.  order = 1 replaces the random segments by the kernel's real address order: the
+// band-sorted list hands a workgroup consecutive rows (consecutive 64-voxel chunks of a row, then the next row 4 KiB
+// further), dealt item by item to its four wavefronts, and the gathers of a workgroup fall into one moving image column.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -90,6 +96,59 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
     if ((acc ^ sink) == 0x12345678u) out[wave] = acc;
 }
 
+// DENSE / ordered variant (see the header comment).  live lanes per item: 34 of 64 (a run at a random start) when
+// DENSE = 0; DENSE = 1: batches of 64 = 2 x 32 contiguous voxels, one batch per two items (=> 32 per item: same bytes +-6 %).
+template <int MODE, int DENSE>
+__global__ __launch_bounds__(256) void mix2(const u4* __restrict__ rec, unsigned nrec, u2* __restrict__ dw, u4* __restrict__ col,
+                                            unsigned nseg, int items_per_wave, unsigned* __restrict__ out, int order) {
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave = blockIdx.x * 4 + wv;
+    unsigned seed = wave * 2654435761u + 12345u, acc = 0;
+    // ordered: the workgroup's share of the list starts at a row of its own; items wg_first + wv + 4 it; a row has 8 chunks
+    // of which ~5 are listed (the frustum interval), i.e. list index -> segment = (idx / 5) * 8 + 1 + idx % 5
+    const unsigned wg_first = (unsigned)(((unsigned long long)blockIdx.x * 2654435761ull) % (nseg / 8u - (unsigned)items_per_wave)) * 8u;
+    auto seg_of = [&](int it) -> unsigned {
+        if (!order) return rnd(seed) % nseg;
+        const unsigned idx = (unsigned)it * 4u + wv;
+        return (wg_first + (idx / 5u) * 8u + 1u + idx % 5u) % nseg;
+    };
+    // ordered gathers: one image column (480 records) per workgroup, moving on every 8 items; the lanes' records 1..2 apart
+    unsigned wseed = blockIdx.x * 747796405u + 2891336453u;
+    auto pick = [&](int it) -> unsigned {
+        if (!order) return rnd(seed) % nrec;
+        if ((it & 7) == 0) wseed = wseed * 1664525u + 1013904223u;
+        return ((wseed >> 8) % (nrec - 480u) + rnd(seed) % 384u) % nrec;
+    };
+    auto gather_addr = [&](unsigned base, unsigned half_of) {
+        const unsigned pair = half_of * 32 + (lane >> 1);
+        return (size_t)((base + pair + (pair >> 1)) % nrec) * 2 + (lane & 1);
+    };
+    unsigned prev_seg = 0;
+    for (int it = 0; it < items_per_wave; ++it) {
+        u4 ga = u4{0, 0, 0, 0}, gb = ga;
+        if (MODE != 1) { const unsigned base = pick(it); ga = rec[gather_addr(base, 0)]; gb = rec[gather_addr(base, 1)]; }
+        const unsigned seg = __builtin_amdgcn_readfirstlane(seg_of(it));
+        const unsigned first = __builtin_amdgcn_readfirstlane(rnd(seed) % 30u);
+        acc ^= ga.x + gb.w;
+        if (MODE != 2) {
+            size_t vox; bool live;
+            if (DENSE) {
+                live = (it & 1) != 0;                                         // a batch every other item, all 64 lanes
+                vox = lane < 32 ? (size_t)seg * 64 + first + lane : (size_t)prev_seg * 64 + (first ^ 21u) % 30u + (lane - 32);
+            } else {
+                live = lane >= first && lane < first + 34u;
+                vox = (size_t)seg * 64 + lane;
+            }
+            u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
+            if (live) { d = dw[vox]; c = __builtin_nontemporal_load(&col[vox]); }
+            d.x += acc; c.y ^= d.y;
+            if (MODE != 3 && live) { dw[vox] = d; __builtin_nontemporal_store(c, &col[vox]); }
+            if (MODE == 3) acc ^= d.x + c.y;
+        }
+        prev_seg = seg;
+    }
+    if (acc == 0x12345678u) out[wave] = acc;
+}
+
 int main() {
     const unsigned nrec = 307200, nseg = 2097152;                  // 512^3 / 64 segments
     u4 *rec, *col; u2* dw; unsigned* out;
@@ -128,5 +187,26 @@ int main() {
             if (rep == 2) printf("{\"gather_window_records\": %u, \"workgroups_sharing_a_window\": %u, \"mode\": \"all\", \"us_per_launch\": %.1f}\n", windows[wi], shares[wi], ms * 100.0);
         }
     }
+    // round 4: dense batches and the kernel's address order
+    for (int order = 0; order < 2; ++order)
+        for (int dense = 0; dense < 2; ++dense)
+            for (int mode = 0; mode < 3; ++mode)
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int blocks = gi == 0 ? 1280 : 1024, ipw = (199680 + blocks * 4 - 1) / (blocks * 4);
+                    float best = 1e9f;
+                    for (int rep = 0; rep < 3; ++rep) {
+                        CHECK(hipEventRecord(a));
+                        for (int k = 0; k < 10; ++k) {
+#define L2(M, D) mix2<M, D><<<blocks, 256>>>(rec, nrec, dw, col, nseg, ipw, out, order)
+                            if (dense == 0) { if (mode == 0) L2(0, 0); if (mode == 1) L2(1, 0); if (mode == 2) L2(2, 0); }
+                            else { if (mode == 0) L2(0, 1); if (mode == 1) L2(1, 1); if (mode == 2) L2(2, 1); }
+                        }
+                        CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                        float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+                        if (rep > 0 && ms < best) best = ms;
+                    }
+                    printf("{\"probe\": \"mix2\", \"address_order\": \"%s\", \"volume_access\": \"%s\", \"mode\": \"%s\", \"workgroups\": %d, \"us_per_launch\": %.1f}\n",
+                           order ? "kernel" : "random", dense ? "dense_batches_2x32" : "items_34_of_64", names[mode], blocks, best * 100.0);
+                }
     return 0;
 }

@@ -164,6 +164,7 @@ struct tsdf_handle {
     bool used_untracked[2] = {false, false};   // read by an integration that recorded no event
     bool frame_side = false;                   // the current frame was packed on the frame stream
     float4* pn_buf[2] = {nullptr, nullptr};
+    bool integrate_queue = true;   // integrate_queue_kernel (dense batches) rather than integrate_kernel
     float4* samples_buf[2] = {nullptr, nullptr};
     int fidx = 0;
 
@@ -305,7 +306,7 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
     if (npix > h->pn_cap) {
         for (int b = 0; b < 2; ++b) { if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]); h->pn_buf[b] = nullptr; }
         h->pn = nullptr; h->pn_cap = 0; h->have_frame = false;
-        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->pn_buf[b], npix * kPixelRecordBytes));
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->pn_buf[b], npix * kPixelBufferBytes));
         h->pn_cap = npix;
     }
     if (ns > h->samples_cap) {
@@ -882,8 +883,12 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
         { const char* dbg = std::getenv("TSDF_DEBUG_INTEGRATE"); h->integrate_debug = dbg ? std::atoi(dbg) : 0; }
+        // TSDF_INTEGRATE_KERNEL=items keeps round 3's item-at-a-time kernel (same-box comparisons); volumes of 2^32 stored
+        // voxels and more always use it
+        const char* kk = std::getenv("TSDF_INTEGRATE_KERNEL");
+        h->integrate_queue = integrate_queue_fits(g) && !(kk && std::strcmp(kk, "items") == 0);
         const char* env = std::getenv("TSDF_INTEGRATE_BLOCKS_PER_CU");
-        const int per_cu = env ? std::atoi(env) : integrate_blocks_per_cu();
+        const int per_cu = env ? std::atoi(env) : integrate_blocks_per_cu(h->integrate_queue);
         h->integrate_blocks = (prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4) + 7) / 8 * 8;   // whole XCD groups
     }
     // 2 words per workgroup (updated voxels: owned, halo) + 4 x 6 more behind them for the stage profile of debug builds
@@ -1489,7 +1494,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     rc = timed_begin(h, 0, &ep, h->stream);
     if (rc) return rc;
     HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                                h->integrate_blocks, h->integrate_launches++, h->wg_counts));
+                                h->integrate_blocks, h->integrate_launches++, h->wg_counts, h->integrate_queue));
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
     if (h->frame_side) {     // the next-but-one pack (on the frame stream) may overwrite this buffer after this launch

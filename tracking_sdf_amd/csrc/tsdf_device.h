@@ -99,19 +99,23 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
                        int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
                        float4* pn, float4* samples, int32_t ncols, int32_t nrows,
-                       int32_t color_layout /* 1: 32-byte records + f64 cosine plane (volume with colour), 0: 24-byte {P,N} records */);
+                       int32_t color_layout /* 1: 32-byte records + f64 cosine plane (volume with colour), 0: 24-byte {P,N} records */);   // pn: kPixelBufferBytes per pixel
 // worklist: integrate_worklist_bytes(g) bytes, zero before the first launch; work_count:
 // integrate_bookkeeping_words() unsigned, zero before the first launch; n_blocks: persistent grid size (CUs x
 // integrate_blocks_per_cu(), a multiple of 8).
 size_t integrate_worklist_entries(const Grid& g);
 size_t integrate_worklist_bytes(const Grid& g);      // 32-byte item descriptors: band regions + overflow region
 constexpr size_t kPixelRecordBytes = 32;             // per pixel: two float4 records (24 of them used when the volume has no colour)
+constexpr size_t kPixelBufferBytes = 40;             // what a frame's pixel buffer holds per pixel: the record + the f64 cosine (colour volumes)
 size_t integrate_bookkeeping_words();
-int integrate_blocks_per_cu();
+// queue = the round-4 kernel that updates dense batches of queued voxels (integrate_queue_kernel; needs
+// integrate_queue_fits(): fewer than 2^32 stored voxels), otherwise round 3's item-at-a-time integrate_kernel
+int integrate_blocks_per_cu(bool queue);
+bool integrate_queue_fits(const Grid& g);
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             void* worklist, unsigned* work_count, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */);
+                            unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */, bool queue);
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit

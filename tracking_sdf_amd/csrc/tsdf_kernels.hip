@@ -103,6 +103,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
         const double cosine = pixel_cosine(nx, ny, nz);
         pn[2 * rec + 0] = make_float4(px, py, pz, __uint_as_float(c));
         pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)cosine);
+        // ... and the f64 value itself goes to a plane behind the records (8 bytes per pixel, same record index): the
+        // queue kernel gathers it for DENSE batches of exp()-band voxels only (one 8-byte gather per 64 band voxels)
+        reinterpret_cast<double*>(pn + 2 * (size_t)width * height)[rec] = cosine;
     } else {
         // without colour: 24-byte records {Px,Py,Pz, Nx,Ny,Nz} (a quarter fewer cache lines per gathered pixel run)
         float* const r6 = reinterpret_cast<float*>(pn) + rec * 6;
@@ -441,10 +444,10 @@ constexpr int kMaxFastDim = 2047;                    // (dim + 1) << 20 must fit
 constexpr unsigned kDroppedOffset = 0x7fffffffu;     // beyond every buffer: the lane loads zeros / stores nothing
 constexpr int kRsrcWord3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
 
-// Per-pixel data of a frame, written by pack_kernel into ONE buffer of kPixelRecordBytes per pixel (record index
-// rec = col*pix_su + row*pix_sv):  with colour  [0, 32 npix) records {Px,Py,Pz,rgb}{Nx,Ny,Nz,(float)cosine};
-// without colour  [0, 24 npix) records {Px,Py,Pz,Nx,Ny,Nz}.
-static_assert(kPixelRecordBytes == 32, "pixel records");
+// Per-pixel data of a frame, written by pack_kernel into ONE buffer of kPixelBufferBytes per pixel (record index
+// rec = col*pix_su + row*pix_sv):  with colour  [0, 32 npix) records {Px,Py,Pz,rgb}{Nx,Ny,Nz,(float)cosine}, then
+// [32 npix, 40 npix) the f64 cosines;  without colour  [0, 24 npix) records {Px,Py,Pz,Nx,Ny,Nz}.
+static_assert(kPixelRecordBytes == 32 && kPixelBufferBytes == 40, "pixel records + f64 cosine plane");
 
 // v_cvt_i32_f64 as the hardware does it (saturating, NaN -> 0); a C cast of an out-of-range value is undefined
 __device__ __forceinline__ int cvt_i32_f64_sat(double x) {
@@ -638,25 +641,13 @@ __device__ __forceinline__ float band_weight(float d, float eps) {
     return EXPPOLY ? (float)exp_taylor8(xarg) : (float)exp(xarg);
 }
 
-template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
-__global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
-    IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ set,
-    unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
-    float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
-    unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */,
-    unsigned* __restrict__ xcd_fb) {
-    constexpr int kRec = COLOR ? 32 : 24, kHalf = kRec / 2;        // bytes of a pixel record / of the piece a lane fetches
-    extern __shared__ double s_tab[];
-    const int m = p.g.m;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
-    constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
-    // The list as list_rows_kernel left it: band b's items in [base[b], base[b] + fill[b]), then the overflow region.
-    // Segment table (kBins + 1 segments): first VIRTUAL index of each segment (the list without its holes) and what to
-    // add to a virtual index to get the list entry.
-    static_assert(kBins <= 64, "one lane per band in the segment scan");
-    __shared__ unsigned s_vstart[kBins + 2], s_delta[kBins + 1];
+// The list as list_rows_kernel left it: band b's items in [base[b], base[b] + fill[b]), then the overflow region.
+// Segment table (kBins + 1 segments): first VIRTUAL index of each segment (the list without its holes) and what to
+// add to a virtual index to get the list entry.  Workgroup 0 also prepares the bookkeeping set of the NEXT launch.
+// (first wavefront of the workgroup; the caller's barrier publishes the table)
+static_assert(kBins <= 64, "one lane per band in the segment scan");
+__device__ __forceinline__ void build_segment_table(const unsigned* __restrict__ set, unsigned* __restrict__ next_set, unsigned ovf_base,
+                                                    unsigned long long* __restrict__ totals, unsigned* s_vstart, unsigned* s_delta, int tid) {
     if (tid < 64) {
         const bool is_band = tid < kBins;
         const unsigned cur = is_band ? set[kSetCur + tid] : 0u, fo = is_band ? set[kSetFirstOvf + tid] : 0u;
@@ -698,6 +689,24 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             if (tid == 0 && set[kSetOvf]) atomicAdd(&totals[kCntOverflowItems], (unsigned long long)set[kSetOvf]);
         }
     }
+}
+
+template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
+__global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
+    IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ set,
+    unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
+    float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
+    unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */,
+    unsigned* __restrict__ xcd_fb) {
+    constexpr int kRec = COLOR ? 32 : 24, kHalf = kRec / 2;        // bytes of a pixel record / of the piece a lane fetches
+    extern __shared__ double s_tab[];
+    const int m = p.g.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
+    constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
+    __shared__ unsigned s_vstart[kBins + 2], s_delta[kBins + 1];
+    build_segment_table(set, next_set, ovf_base, totals, s_vstart, s_delta, tid);
     if (KTAB) build_k_table(p, s_tab, tid, kIntegrateBlock);
     else __syncthreads();
     const unsigned n_items = __builtin_amdgcn_readfirstlane(s_vstart[kBins + 1]);   // (an LDS load is a per-lane value to the compiler)
@@ -972,6 +981,316 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     }
 }
 
+// ---- integrate_queue_kernel (round 4) -------------------------------------------------------------------------------
+//
+// integrate_kernel pays every instruction of an item for 64 lanes of which about 33 are updated (plant scene, 512^3:
+// 199.9 k items, 12.8 M listed voxels, 10.2 M inside the frustum, 6.33 M updated; 45 % of the items have voxels in the
+// exp() band and run its f64 weight + cosine for a handful of lanes).  Its cost follows the number of items, not the
+// bytes (+36 % voxels -> +12 % time at the same item count; 6.6 vector-memory instructions per item).
+// Here the part of the work that only updated voxels need runs on DENSE wavefronts:
+//   per item (64 lanes)   S1 geometry + pixel-record gather, S2 distance and the tests of sdf.cpp:260-283; the lanes
+//                         that pass append {voxel index, d, colour weight | pixel, rgb} (16 bytes; 8 without colour) to
+//                         one of two wave-private queues in LDS (ballot + mbcnt prefix): weight-1 lanes (d < epsilon)
+//                         and lanes of the exp() band;
+//   per 64 queued lanes   a BATCH: pop 64 entries, (band queue: exp() weight, and the f64 cosine of the pixel from the
+//                         plane pack_kernel wrote -- one 8-byte gather per 64 band voxels), {D,W} + colour loads,
+//                         the running averages of sdf.cpp:289-304 and the stores, all 64 lanes live.
+// Every voxel still belongs to exactly one item, each updated voxel is queued exactly once and updated with the
+// reference's operations in the reference's order, so the volume is bit-identical to integrate_kernel's; only the
+// grouping of voxels into wavefront instructions differs.  Wave-private queues: no barrier, no atomics; LDS operations
+// of one wavefront execute in order.  A queue never holds more than 63 + 64 entries: after an item at most one queue can
+// have reached 64 unless both were nearly full, and the consume loop pops until both are below 64 again.
+// Voxel indices are 32-bit: volumes (slab + halo) of 2^32 voxels and more stay with integrate_kernel.
+
+constexpr int kQCap = 128;                 // entries per queue and wavefront (>= 63 + 64)
+
+template <bool COLOR> struct QueueEntry { typedef u32x4 T; };     // {voxel, d bits, (float)cosine | biased pixel index, rgb}
+template <> struct QueueEntry<false> { typedef u32x2 T; };        // {voxel, d bits}
+
+template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
+__global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_queue_kernel(
+    IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ set,
+    unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
+    float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
+    unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */,
+    unsigned* __restrict__ xcd_fb) {
+    typedef typename QueueEntry<COLOR>::T Entry;
+    constexpr int kRec = COLOR ? 32 : 24, kHalf = kRec / 2;        // bytes of a pixel record / of the piece a lane fetches
+    extern __shared__ double s_tab[];
+    const int m = p.g.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
+    constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
+    __shared__ unsigned s_vstart[kBins + 2], s_delta[kBins + 1];
+    build_segment_table(set, next_set, ovf_base, totals, s_vstart, s_delta, tid);
+    if (KTAB) build_k_table(p, s_tab, tid, kIntegrateBlock);
+    else __syncthreads();
+    const unsigned n_items = __builtin_amdgcn_readfirstlane(s_vstart[kBins + 1]);
+    ProjConst pc;
+    make_proj_const(p, tl, lane, pc);
+    // the XCD's part of the list and the workgroup's share of it: as integrate_kernel
+    const unsigned xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const unsigned x_lo = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd])) >> 24);
+    const unsigned x_hi = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd + 1])) >> 24);
+    const unsigned wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * in_xcd) / per_xcd)));
+    const unsigned wg_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * (in_xcd + 1)) / per_xcd)));
+    const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
+    unsigned n_own = 0, n_halo = 0;
+    const unsigned long long loop_t0 = __builtin_amdgcn_s_memrealtime();      // for the XCD shares of the next launch
+
+    const long long npix = (long long)p.width * p.height;
+    const long long bias = (long long)pc.su + pc.sv;
+    const __amdgpu_buffer_rsrc_t pn_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(pn - bias * kRec), 0, (int)((npix + bias) * kRec), kRsrcWord3);
+    // the f64 cosines behind the records (colour volumes), addressed by the same biased record index
+    const __amdgpu_buffer_rsrc_t cos_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(pn + npix * (long long)kPixelRecordBytes - bias * 8), 0, (int)((npix + bias) * 8), kRsrcWord3);
+    const unsigned half_off = (unsigned)(lane & 1) * (unsigned)kHalf;
+    __shared__ u32x4 s_pieces[NW][128];                      // wave-private un-shuffle buffer of the paired gather
+    __shared__ Entry s_queue[NW][2][kQCap];                  // wave-private queues: [0] weight-1 lanes, [1] exp()-band lanes
+    Entry* const q_plain = s_queue[wv][0];
+    Entry* const q_band = s_queue[wv][1];
+    const unsigned dropped = kDroppedOffset;
+    const unsigned own_row0 = (unsigned)((p.g.own_x0 - p.g.xs) * m), own_row1 = (unsigned)((p.g.own_x1 - p.g.xs) * m);   // rows < 2^26
+
+    unsigned seg_end = 0u, seg_delta = 0u;
+    auto locate = [&](unsigned v) {
+        const unsigned e = s_vstart[(lane < kBins ? lane : kBins - 1) + 1];
+        const unsigned sg = (unsigned)__popcll(__ballot(lane < kBins && v >= e));
+        seg_end = __builtin_amdgcn_readfirstlane(s_vstart[sg + 1]);
+        seg_delta = s_delta[sg];
+    };
+
+    struct Gather {             // S1 done: pixel record requested
+        unsigned long long live;   // lanes that pass the geometric tests (wave-uniform mask)
+        unsigned code;          // the item (wave-uniform)
+        double pcx, pcy, pcz;   // camera-frame voxel centre
+        unsigned pixb;          // biased record index of the lane's pixel
+        u32x4 A, B;             // halves of the pixel records, as in integrate_kernel (in flight until S2)
+    };
+    struct Batch {              // 64 queued voxels whose volume data is in flight
+        unsigned long long valid;  // lanes that hold a voxel (all of them, except when the queues are drained at the end)
+        unsigned vox;           // index into the stored volume
+        float d_new, w_new, wc;
+        unsigned rgb;
+        u32x2 old;              // {D, W}
+        u32x4 col;              // {Color_W, R, G, B}
+    };
+    // wave-uniform queue state: entries [0, fill) are queued
+    unsigned fill_p = 0u, fill_b = 0u;
+
+    auto stage1 = [&](int j, Gather& g /*out: item j*/) {
+        const bool have = j < cnt;
+        unsigned entry = 0u;                                    // (no item left: entry 0, masked below)
+        if (have) {
+            const unsigned v = wg_first + (unsigned)wv + NW * (unsigned)j;
+            if (__builtin_expect(v >= seg_end, 0)) locate(v);
+            entry = v + seg_delta;
+        }
+        const ItemDesc ds = list[__builtin_amdgcn_readfirstlane(entry)];    // wave-uniform: one scalar 32-byte load
+        unsigned long long okm;
+        unsigned pixb;
+        project_item<KSTD, KTAB>(pc, ds, s_tab, lane, g.pcx, g.pcy, g.pcz, okm, pixb);
+        if (!have) okm = 0ull;
+        const unsigned roff = select_by_mask(okm, COLOR ? pixb << 5 : __umul24(pixb, (unsigned)kRec), dropped);
+        const unsigned ra = (unsigned)__shfl((int)roff, lane >> 1) + half_off;
+        const unsigned rb = (unsigned)__shfl((int)roff, 32 + (lane >> 1)) + half_off;
+        if (COLOR) {
+            g.A = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)ra, 0, 0);
+            g.B = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)rb, 0, 0);
+        } else {
+            const u32x3 a3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)ra, 0, 0);
+            const u32x3 b3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)rb, 0, 0);
+            g.A = u32x4{a3.x, a3.y, a3.z, 0u}; g.B = u32x4{b3.x, b3.y, b3.z, 0u};
+        }
+        g.live = okm;
+        g.code = ds.code;
+        g.pixb = pixb;
+    };
+    // append the lanes of `mask` to a queue (a stack: the order in which voxels are updated is free): position = fill +
+    // number of mask lanes below this one
+    auto push = [&](unsigned long long mask, Entry* q, unsigned& fill, const Entry& e) {
+        const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (__builtin_amdgcn_inverse_ballot_w64(mask)) q[fill + pre] = e;
+        fill += (unsigned)__popcll(mask);
+    };
+    auto stage2 = [&](const Gather& gin /*item j-1, record arrived*/) {
+        u32x4* stage = s_pieces[wv];
+        if (COLOR) { stage[lane] = gin.A; stage[64 + lane] = gin.B; }
+        else {
+            *reinterpret_cast<u32x3*>(&stage[lane]) = u32x3{gin.A.x, gin.A.y, gin.A.z};
+            *reinterpret_cast<u32x3*>(&stage[64 + lane]) = u32x3{gin.B.x, gin.B.y, gin.B.z};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32x4 P, N;                                            // own record: {Px,Py,Pz,rgb} {Nx,Ny,Nz,(float)cosine}
+        if (COLOR) { P = stage[2 * lane + 0]; N = stage[2 * lane + 1]; }
+        else {
+            const u32x3 p3 = *reinterpret_cast<const u32x3*>(&stage[2 * lane + 0]), n3 = *reinterpret_cast<const u32x3*>(&stage[2 * lane + 1]);
+            P = u32x4{p3.x, p3.y, p3.z, 0u}; N = u32x4{n3.x, n3.y, n3.z, 0u};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads above stay before the next step's writes
+        __builtin_amdgcn_wave_barrier();
+        const float Px = __uint_as_float(P.x), Py = __uint_as_float(P.y), Pz = __uint_as_float(P.z);
+        const float Nx = __uint_as_float(N.x), Ny = __uint_as_float(N.y), Nz = __uint_as_float(N.z);
+        // sdf.cpp:260: NaN in P.x, P.y or the normal
+        const unsigned long long nanm = lanes(__builtin_isunordered(Px, Py)) | lanes(__builtin_isunordered(Nx, Ny)) | lanes(is_nan(Nz));
+        // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
+        const double dx = (double)Px - gin.pcx, dy = (double)Py - gin.pcy, dz = (double)Pz - gin.pcz;
+        const double p2p = dx * (double)Nx + (dy * (double)Ny + dz * (double)Nz);
+        float d = (float)p2p;                                               // sdf.cpp:274
+        const unsigned long long okm = gin.live & ~nanm & ~lanes(d > delta);   // sdf.cpp:280-283
+        const unsigned long long bandm = okm & lanes(d >= eps);             // sdf.cpp:277-279 (d <= delta holds in okm)
+        const unsigned long long plainm = okm & ~bandm;
+        // update counts (wave-uniform): rows of the owned x layers / of the halo
+        const unsigned row = gin.code >> 6;
+        const bool owned = row >= own_row0 && row < own_row1;
+        const unsigned n_live = (unsigned)__popcll(okm);
+        n_own += owned ? n_live : 0u;
+        n_halo += owned ? 0u : n_live;
+        if (okm == 0ull) return;                                            // nothing of this item is updated
+        d = d < neg_delta ? neg_delta : d;                                  // sdf.cpp:285-287 (band lanes: d >= eps, unchanged)
+        Entry e;
+        e.x = row * (unsigned)m + (gin.code & 63u) * 64u + (unsigned)lane;  // voxel index in the stored volume (< 2^32: launch_integrate)
+        e.y = __float_as_uint(d);
+        if constexpr (COLOR) {
+            // sdf.cpp:294-299: weight-1 lanes take the pre-rounded cosine of the record as their colour weight; band lanes
+            // carry their pixel and get the f64 cosine when their batch is formed
+            e.z = select_by_mask(bandm, gin.pixb, N.w);
+            e.w = P.w;
+        }
+        push(plainm, q_plain, fill_p, e);
+        if (bandm != 0ull) push(bandm, q_band, fill_b, e);
+    };
+    // pop the top (up to 64) entries of a queue into the lanes of a batch
+    auto pop = [&](const Entry* q, unsigned& fill, unsigned long long& valid) -> Entry {
+        const unsigned n = fill < 64u ? fill : 64u;
+        valid = n == 64u ? ~0ull : ((1ull << n) - 1ull);
+        fill -= n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes' queue writes before these reads
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return q[fill + (unsigned)lane];                           // (lanes >= n read stale entries: masked by `valid`)
+    };
+    // form a batch from whichever queue has reached `thresh` entries and request its volume data
+    auto form_batch = [&](Batch& b, unsigned thresh) {
+        if (fill_p >= thresh) {
+            const Entry e = pop(q_plain, fill_p, b.valid);
+            b.vox = e.x; b.d_new = __uint_as_float(e.y); b.w_new = 1.0f;    // sdf.cpp:276
+            if constexpr (COLOR) { b.wc = __uint_as_float(e.z); b.rgb = e.w; }
+        } else {
+            const Entry e = pop(q_band, fill_b, b.valid);
+            const float d = __uint_as_float(e.y);
+            b.vox = e.x; b.d_new = d;
+            float wn;
+            if constexpr (COLOR) {
+                // cosine of sdf.cpp:294 in f64 from pack_kernel's plane; wc = (float)(w_new * cosine), sdf.cpp:295
+                const unsigned off = select_by_mask(b.valid, e.z << 3, dropped);
+                const u32x2 cb = __builtin_amdgcn_raw_buffer_load_b64(cos_rsrc, (int)off, 0, 0);
+                wn = band_weight<EXPPOLY>(d, eps);                          // sdf.cpp:277-279 (while the gather is under way)
+                const double cosine = __hiloint2double((int)cb.y, (int)cb.x);
+                b.wc = (float)((double)wn * cosine);
+                b.rgb = e.w;
+            } else {
+                wn = band_weight<EXPPOLY>(d, eps);
+            }
+            b.w_new = wn;
+        }
+        b.old = u32x2{0u, 0x3f800000u}; b.col = u32x4{0x3f800000u, 0u, 0u, 0u};   // (harmless operands in the lanes of a partial batch)
+        if (__builtin_amdgcn_inverse_ballot_w64(b.valid)) {
+            b.old = *reinterpret_cast<const u32x2*>(dw + b.vox);           // {D,W}: the tracker re-reads these lines -> keep them cached
+            if constexpr (COLOR)   // colour is streamed once per frame and never read by the tracker: non-temporal
+                b.col = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(crgb + b.vox));
+        }
+    };
+    // the running averages of sdf.cpp:289-304 for a batch whose volume data has arrived, and the stores
+    auto finish_batch = [&](const Batch& b) {
+        // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
+        const float W = __uint_as_float(b.old.y), D = __uint_as_float(b.old.x);
+        const float cx = __uint_as_float(b.col.x);
+        const float wc = COLOR ? b.wc : 0.f;
+        v2f sum1, num1, num2 = v2f{0.f, 0.f};
+        sum1.x = W + b.w_new;
+        num1.x = W * D + b.w_new * b.d_new;
+        if (COLOR) {
+            const unsigned rgb = b.rgb;
+            const float pr = (float)(rgb & 255u), pg = (float)((rgb >> 8) & 255u), pb = (float)((rgb >> 16) & 255u);
+            sum1.y = cx + wc;
+            num1.y = cx * __uint_as_float(b.col.y) + wc * pr;
+            num2 = v2f{cx, cx} * v2f{__uint_as_float(b.col.z), __uint_as_float(b.col.w)} + v2f{wc, wc} * v2f{pg, pb};
+        } else {
+            sum1.y = 1.0f; num1.y = 0.0f;
+        }
+        const v2f r = rcp_refined(sum1);
+        v2f q1 = div_core(num1, sum1, r), q2 = v2f{0.f, 0.f};
+        if (COLOR) q2 = div_core(num2, v2f{sum1.y, sum1.y}, v2f{r.y, r.y});
+        unsigned long long bad = tiny_lanes(num1) | lanes(b.old.y >= kBits2p64);
+        if (COLOR) bad |= tiny_lanes(num2) | lanes(b.col.x >= kBits2p64);
+        if (__builtin_expect((bad & b.valid) != 0ull, 0)) {
+            q1.x = num1.x / sum1.x;
+            if (COLOR) { q1.y = num1.y / sum1.y; q2.x = num2.x / sum1.y; q2.y = num2.y / sum1.y; }
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(b.valid)) {
+            u32x2 o2; o2.x = __float_as_uint(q1.x); o2.y = __float_as_uint(sum1.x);
+            *reinterpret_cast<u32x2*>(dw + b.vox) = o2;
+            if constexpr (COLOR) {
+                u32x4 c4; c4.x = __float_as_uint(sum1.y); c4.y = __float_as_uint(q1.y); c4.z = __float_as_uint(q2.x); c4.w = __float_as_uint(q2.y);
+                __builtin_nontemporal_store(c4, reinterpret_cast<u32x4*>(crgb + b.vox));   // nt: colour is streamed
+            }
+        }
+    };
+
+    Gather G[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        G[q].live = 0ull; G[q].code = 0u; G[q].pixb = 0u;
+        G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
+        G[q].A = u32x4{0u, 0u, 0u, 0u}; G[q].B = G[q].A;
+    }
+    Batch B;
+    B.valid = 0ull; B.vox = 0u; B.d_new = 0.f; B.w_new = 1.f; B.wc = 0.f; B.rgb = 0u;
+    B.old = u32x2{0u, 0x3f800000u}; B.col = u32x4{0x3f800000u, 0u, 0u, 0u};
+    // One step = S1(j) request the pixel records of item j | S2(j-1) distance test, queue the updated lanes of item j-1 |
+    // finish the batch whose volume data was requested a step ago | form the next batch when a queue has 64 entries.
+    // (both queues reaching 64 in the same step is rare and handled apart, so that the common path keeps its exact
+    // s_waitcnt counts)
+    for (int j = 0; j < cnt + 1; j += 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            stage1(j + q, G[q]);
+            stage2(G[q ^ 1]);
+            if (B.valid != 0ull) finish_batch(B);
+            B.valid = 0ull;
+            if (fill_p >= 64u || fill_b >= 64u) {
+                form_batch(B, 64u);
+                if (__builtin_expect(fill_p >= 64u || fill_b >= 64u, 0)) { finish_batch(B); form_batch(B, 64u); }
+            }
+        }
+    }
+    // (j runs to cnt or cnt + 1: the last item's record has been consumed by an S2 inside the loop)
+    // drain: what is left in the queues goes out as partial batches
+#pragma unroll 1
+    do {
+        if (B.valid != 0ull) finish_batch(B);
+        B.valid = 0ull;
+        if ((fill_p | fill_b) != 0u) form_batch(B, 1u);
+    } while (B.valid != 0ull);
+
+    if (wv == 0 && lane == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(xcd_fb + kFbTicksWord) + xcd, __builtin_amdgcn_s_memrealtime() - loop_t0 + 1ull);
+    __shared__ unsigned s_cnt[2][kIntegrateBlock / 64];
+    if (lane == 0) { s_cnt[0][tid >> 6] = n_own; s_cnt[1][tid >> 6] = n_halo; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned a = 0, b = 0;
+        for (int q = 0; q < kIntegrateBlock / 64; ++q) { a += s_cnt[0][q]; b += s_cnt[1][q]; }
+        if (a) counters[2 * blockIdx.x + 0] += (unsigned long long)a;
+        if (b) counters[2 * blockIdx.x + 1] += (unsigned long long)b;
+    }
+}
+
 size_t integrate_worklist_entries(const Grid& g) {
     return (size_t)(g.xe - g.xs) * g.m * ((g.m + 63) / 64);
 }
@@ -979,12 +1298,17 @@ size_t integrate_worklist_entries(const Grid& g) {
 // (a wavefront without items reads entry 0)
 size_t integrate_worklist_bytes(const Grid& g) { return (2 * integrate_worklist_entries(g) + 8) * sizeof(ItemDesc); }
 
-int integrate_blocks_per_cu() {
+int integrate_blocks_per_cu(bool queue) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true, true, true>, kIntegrateBlock, 512 * 24) != hipSuccess || n < 1)
-        n = TSDF_INTEGRATE_MIN_WAVES;
+    const hipError_t e = queue
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_queue_kernel<true, true, true, true>, kIntegrateBlock, 512 * 24)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true, true, true>, kIntegrateBlock, 512 * 24);
+    if (e != hipSuccess || n < 1) n = TSDF_INTEGRATE_MIN_WAVES;
     return n;
 }
+
+// the queue kernel carries voxel indices in 32 bits
+bool integrate_queue_fits(const Grid& g) { return (long long)(g.xe - g.xs) * g.m * g.m < (1ll << 32); }
 
 size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords + kFbWords; }
 static_assert((2 * kBinSetWords) % 2 == 0, "the 64-bit tick sums of the feedback block must be 8-byte aligned");
@@ -1013,7 +1337,7 @@ static bool use_exp_poly(const IntegrateParams& p) {
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             void* worklist, unsigned* work_count, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts) {
+                            unsigned launch_parity, unsigned long long* wg_counts, bool queue) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
@@ -1035,8 +1359,10 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     const bool ktab = m <= 1024;                                       // 24 bytes of LDS per k
     const size_t lds = ktab ? (size_t)m * 24 : 0;
     const char* planes = reinterpret_cast<const char*>(pn);
-#define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) \
-    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb)
+    if (queue && !integrate_queue_fits(p.g)) return hipErrorInvalidValue;
+#define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) do { \
+    if (queue) integrate_queue_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb); \
+    else integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb); } while (0)
 #define TSDF_LAUNCH_INTEGRATE3(C, KS, EP) do { if (ktab) TSDF_LAUNCH_INTEGRATE(C, KS, EP, true); else TSDF_LAUNCH_INTEGRATE(C, KS, EP, false); } while (0)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE3(C, KS, true); else TSDF_LAUNCH_INTEGRATE3(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
