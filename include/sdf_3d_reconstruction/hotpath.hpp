@@ -21,6 +21,13 @@
 //   CameraTracking::set_camera_transformation(rot, trans)               camera_tracking.h:84
 //   CameraTracking::camera_info_cb -> set_K(K)                          camera_tracking.cpp:22-36
 //   public rot, trans, rot_inv, rot_inv_trans, K, isKFilled             camera_tracking.h:43-59
+// and, in the exact-type classes only (host-side one-liners over the pose / configuration of the handle, with the
+// reference's arithmetic and evaluation order):
+//   SDF::get_array_index / get_voxel_coordinates (both) / get_global_coordinates / projectivePoint*Distance   sdf.h:113-181
+//   CameraTracking::project_camera_to_image_plane / project_world_to_camera / project_camera_to_world   camera_tracking.cpp:40-58
+//   CameraTracking::get_partial_derivative (13 look-ups in ONE tsdf_sample call)                       camera_tracking.cpp:246-363
+// Not mirrored: SDF::visualize (the 1 Hz ROS marker thread, sdf.cpp:317-391; its mesh is SDF::mesh), the analytic
+// fillers create_circle / create_cuboid (no callers in the reference).
 #pragma once
 
 #include <array>
@@ -300,6 +307,47 @@ public:
     }
     using tsdf_shim::SDF::update;
     using tsdf_shim::SDF::interpolate_distance;
+
+    // sdf.h:113-127: (i,j,k) -> array index, -1 outside the grid.  The reference's `int` index is kept (and with it its
+    // wrap at m >= 1291): callers of this helper index host arrays of the reference's size.
+    int get_array_index(Eigen::Vector3i& voxel_coordinates) const {
+        if (voxel_coordinates(0) < 0 || voxel_coordinates(1) < 0 || voxel_coordinates(2) < 0) return -1;
+        if (voxel_coordinates(0) >= m || voxel_coordinates(1) >= m || voxel_coordinates(2) >= m) return -1;
+        const int idx = m * m * voxel_coordinates(0) + m * voxel_coordinates(1) + voxel_coordinates(2);
+        return (idx < 0 || idx >= get_number_of_voxels()) ? -1 : idx;
+    }
+    // sdf.h:132-136
+    void get_voxel_coordinates(int array_idx, Eigen::Vector3i& voxel_coordinates) const {
+        voxel_coordinates(1) = (int)(array_idx % (m * m)) / m;
+        voxel_coordinates(0) = (int)(array_idx / (m * m));
+        voxel_coordinates(2) = (int)array_idx % m;
+    }
+    // sdf.h:143-147: float m_div_* widened against double coordinates
+    void get_voxel_coordinates(Eigen::Vector3d& global_coordinates, Eigen::Vector3d& voxel_coordinates) const {
+        const tsdf_config c = config();
+        voxel_coordinates(0) = ((global_coordinates(0) - c.origin[0]) * m_div_width - 0.5);
+        voxel_coordinates(1) = ((global_coordinates(1) - c.origin[1]) * m_div_height - 0.5);
+        voxel_coordinates(2) = ((global_coordinates(2) - c.origin[2]) * m_div_depth - 0.5);
+    }
+    // sdf.h:153-157: (extent / (float)m) is a float quotient
+    void get_global_coordinates(Eigen::Vector3i& voxel_coordinates, Eigen::Vector3d& global_coordinates) const {
+        const tsdf_config c = config();
+        global_coordinates(0) = (c.width / ((float)m)) * (voxel_coordinates(0) + 0.5) + c.origin[0];
+        global_coordinates(1) = (c.height / ((float)m)) * (voxel_coordinates(1) + 0.5) + c.origin[1];
+        global_coordinates(2) = (c.depth / ((float)m)) * (voxel_coordinates(2) + 0.5) + c.origin[2];
+    }
+    // sdf.h:169-181
+    void projectivePointToPointDistance(const double& voxelDepthInCameraFrame, const double& observedDepthOfProjectedVoxelInDepthImage,
+                                        double& pointToPointDistance) const {
+        pointToPointDistance = voxelDepthInCameraFrame - observedDepthOfProjectedVoxelInDepthImage;
+    }
+    void projectivePointToPlaneDistance(const Eigen::Vector3d& camera_point, const Eigen::Vector3d& camera_point_img,
+                                        const Eigen::Vector3d& normal, double& pointToPlaneDistance) const {
+        const double d0 = camera_point_img(0) - camera_point(0), d1 = camera_point_img(1) - camera_point(1),
+                     d2 = camera_point_img(2) - camera_point(2);
+        pointToPlaneDistance = d0 * normal(0) + (d1 * normal(1) + d2 * normal(2));        // Vector3d::dot (redux order)
+    }
+    tsdf_config config() const { tsdf_config c; tsdf_get_config(handle(), &c); return c; }
 };
 
 class CameraTracking {
@@ -355,6 +403,87 @@ public:
         token_ = FrameToken();
         return same;
 #endif
+    }
+    // camera_tracking.cpp:40-47: ij = K * camera_point, (u, v) = ij.xy / ij.z   (fixed-size product, Eigen 3.2 order)
+    void project_camera_to_image_plane(Eigen::Vector3d& camera_point, Eigen::Vector2d& image_point) {
+        double ij[3];
+        for (int r = 0; r < 3; ++r) ij[r] = (K(r, 0) * camera_point(0) + K(r, 1) * camera_point(1)) + K(r, 2) * camera_point(2);
+        image_point(0) = ij[0] / ij[2];
+        image_point(1) = ij[1] / ij[2];
+    }
+    // camera_tracking.cpp:51-54
+    void project_world_to_camera(Eigen::Vector3d& world_point, Eigen::Vector3d& camera_point) {
+        double o[3];
+        for (int r = 0; r < 3; ++r)
+            o[r] = ((rot_inv(r, 0) * world_point(0) + rot_inv(r, 1) * world_point(1)) + rot_inv(r, 2) * world_point(2)) + rot_inv_trans(r);
+        for (int r = 0; r < 3; ++r) camera_point(r) = o[r];
+    }
+    // camera_tracking.cpp:55-58
+    void project_camera_to_world(const Eigen::Vector3d& camera_point, Eigen::Vector3d& world_point) {
+        double o[3];
+        for (int r = 0; r < 3; ++r)
+            o[r] = ((rot(r, 0) * camera_point(0) + rot(r, 1) * camera_point(1)) + rot(r, 2) * camera_point(2)) + trans(r);
+        for (int r = 0; r < 3; ++r) world_point(r) = o[r];
+    }
+    // camera_tracking.cpp:246-363: data association + numeric Jacobian of ONE camera-frame point against the volume in
+    // HBM.  The reference's 13 sequential SDF::interpolate_distance calls become one tsdf_sample call of 13 voxel
+    // positions; the outputs are then written in the reference's order and with its early returns: out of the grid ->
+    // nothing is touched (:261-268); a look-up without a valid corner -> is_interpolated = false and what was written
+    // before it stays (:269-361).  For tools and tests: the tracker itself never comes through here.
+    void get_partial_derivative(const SDF* sdf, const Eigen::Vector3d& camera_point, Eigen::Matrix<double, 6, 1>& SDF_derivative,
+                                bool& is_interpolated, double& sdf_val) {
+        push(sdf);
+        const tsdf_config c = sdf->config();
+        const float mdiv[3] = {sdf->m_div_width, sdf->m_div_height, sdf->m_div_depth};
+        auto voxel_of = [&](const double R[9], double v[3]) {           // project_camera_to_world + get_voxel_coordinates
+            for (int r = 0; r < 3; ++r) {
+                const double w = ((R[3 * r] * camera_point(0) + R[3 * r + 1] * camera_point(1)) + R[3 * r + 2] * camera_point(2)) + trans(r);
+                v[r] = ((w - c.origin[r]) * mdiv[r] - 0.5);
+            }
+        };
+        double R0[9];
+        for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) R0[3 * r + q] = rot(r, q);
+        double vox[13][3];
+        voxel_of(R0, vox[0]);
+        for (int a = 0; a < 3; ++a) {
+            if (vox[0][a] < 0) return;                                  // :261-264
+        }
+        for (int a = 0; a < 3; ++a) {
+            if (vox[0][a] >= sdf->m) return;                            // :265-268
+        }
+        for (int a = 0; a < 3; ++a) {                                   // :273-316, voxel space
+            for (int q = 0; q < 3; ++q) { vox[1 + 2 * a][q] = vox[0][q]; vox[2 + 2 * a][q] = vox[0][q]; }
+            vox[1 + 2 * a][a] += c.v_h;
+            vox[2 + 2 * a][a] -= c.v_h;
+        }
+        for (int a = 0; a < 3; ++a) {                                   // :92-145 + :318-361: (I +- w_h [e_a]x) rot, about the world axes
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                const double w = sgn == 0 ? (double)c.w_h : -(double)c.w_h;
+                double Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Rp[9];
+                const int b1 = (a + 1) % 3, b2 = (a + 2) % 3;
+                Rd[3 * b1 + b2] = -w; Rd[3 * b2 + b1] = w;
+                for (int r = 0; r < 3; ++r)
+                    for (int q = 0; q < 3; ++q)
+                        Rp[3 * r + q] = (Rd[3 * r] * R0[q] + Rd[3 * r + 1] * R0[3 + q]) + Rd[3 * r + 2] * R0[6 + q];
+                voxel_of(Rp, vox[7 + 2 * a + sgn]);
+            }
+        }
+        float val[13];
+        int32_t ok[13];
+        sdf->check(tsdf_sample(sdf->handle(), &vox[0][0], 13, val, ok), "tsdf_sample");
+        sdf_val = val[0];                                               // :269
+        is_interpolated = ok[0] != 0;
+        if (!is_interpolated) return;
+        const float v_h2 = 2 * c.v_h;
+        const float vh2[3] = {v_h2 / sdf->m_div_width, v_h2 / sdf->m_div_height, v_h2 / sdf->m_div_depth};   // camera_tracking.cpp:13-17
+        for (int e = 0; e < 6; ++e) {
+            const int ip = e < 3 ? 1 + 2 * e : 7 + 2 * (e - 3), im = ip + 1;
+            is_interpolated = ok[ip] != 0;
+            if (!is_interpolated) return;
+            is_interpolated = ok[im] != 0;
+            if (!is_interpolated) return;
+            SDF_derivative(e) = e < 3 ? (val[ip] - val[im]) / vh2[e] : (val[ip] - val[im]) / (2 * c.w_h);     // float quotients widened
+        }
     }
     tsdf_shim::CameraTracking* impl() { return &impl_; }
     void pull() {                          // native handle -> the public Eigen fields

@@ -62,6 +62,24 @@ struct Node {
         CameraTracking* coarse = new CameraTracking(5, 0.002, 0.5, 0.02, sdf);           // other constants than the SDF's defaults
         coarse->estimate_new_position(sdf, cloud_filtered);
         delete coarse;
+        // the rest of the public surface (sdf.h:113-181, camera_tracking.h:69-101): any other caller compiles, too
+        Vector3i ijk; ijk(0) = 1; ijk(1) = 2; ijk(2) = 3;
+        Vector3d g, vox, cam, world;
+        Vector2d px;
+        const int idx = sdf->get_array_index(ijk);
+        sdf->get_voxel_coordinates(idx, ijk);
+        sdf->get_global_coordinates(ijk, g);
+        sdf->get_voxel_coordinates(g, vox);
+        this->camera_tracking->project_world_to_camera(g, cam);
+        this->camera_tracking->project_camera_to_image_plane(cam, px);
+        this->camera_tracking->project_camera_to_world(cam, world);
+        double d = 0;
+        sdf->projectivePointToPlaneDistance(cam, world, g, d);
+        sdf->projectivePointToPointDistance(cam(2), world(2), d);
+        Eigen::Matrix<double, 6, 1> SDF_derivative;
+        bool is_interpolated = false;
+        double sdf_val = 0;
+        this->camera_tracking->get_partial_derivative(sdf, cam, SDF_derivative, is_interpolated, sdf_val);
     }
 };
 

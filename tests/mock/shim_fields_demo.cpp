@@ -3,7 +3,9 @@
 //   1. a pose ASSIGNED to the public rot / trans fields (plain members in the reference, camera_tracking.h:43-59) reaches
 //      the integration exactly like set_camera_transformation does;
 //   2. CameraTracking(max_iter, max_twist, v_h, w_h, sdf) with other constants than the SDF's reconfigures the handle;
-//   3. a cloud changed IN PLACE between estimate_new_position and update is uploaded again (no stale points).
+//   3. a cloud changed IN PLACE between estimate_new_position and update is uploaded again (no stale points);
+//   4. the rest of the two classes' public surface (sdf.h:113-181, camera_tracking.h:69-101): index / coordinate maps,
+//      projections and get_partial_derivative -- printed as "H ..." lines that the test compares with the oracle's.
 // Usage: shim_fields_demo frames.bin m        prints "ok" lines; exit code 0 = all three hold
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +95,44 @@ int main(int argc, char** argv) {
         d.update(&td, fresh, nrms[1]);
         const bool ok3 = same_volume(&c, &d);
         std::printf("%s a cloud changed in place is uploaded again\n", ok3 ? "ok" : "FAIL"); bad += !ok3;
+
+        // 4. public helpers: values go to stdout for the oracle comparison (tests/test_cpp_shim.py)
+        SDF e(m, 6.0, 6.0, 3.5, origin, 0.3, 0.025);
+        CameraTracking te(20, 0.001, 1.0, 0.01, &e);
+        te.set_K(K);
+        e.update(&te, clouds[0], nrms[0]);
+        Vector3i ijk; ijk(0) = 3; ijk(1) = m - 1; ijk(2) = 7;
+        Vector3i back, outside; outside(0) = 0; outside(1) = m; outside(2) = 0;
+        const int idx = e.get_array_index(ijk);
+        e.get_voxel_coordinates(idx, back);
+        Vector3d g, vox, cam, img3, world;
+        Vector2d img;
+        e.get_global_coordinates(ijk, g);
+        e.get_voxel_coordinates(g, vox);
+        te.project_world_to_camera(g, cam);
+        te.project_camera_to_image_plane(cam, img);
+        te.project_camera_to_world(cam, world);
+        std::printf("H idx %d %d %d %d %d\n", idx, e.get_array_index(outside), back(0), back(1), back(2));
+        std::printf("H geo %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", g(0), g(1), g(2), vox(0), vox(1), vox(2),
+                    cam(0), cam(1), cam(2), img(0), img(1), world(0), world(1), world(2));
+        double p2p = 0;
+        e.projectivePointToPlaneDistance(cam, g, world, p2p);
+        std::printf("H p2p %.17g\n", p2p);
+        int n_interp = 0;
+        for (int k = 0; k < 40; ++k) {
+            const pcl::PointXYZRGB& p = clouds[0]->points[((size_t)(h / 2 - 20 + k) * w + (size_t)(w / 4 + 3 * k))];
+            if (!(p.x == p.x)) continue;
+            Vector3d cp((double)p.x, (double)p.y, (double)p.z);
+            Eigen::Matrix<double, 6, 1> J;
+            for (int q = 0; q < 6; ++q) J(q) = -7.0;            // untouched entries stay recognisable
+            bool isi = false; double val = -7.0;
+            te.get_partial_derivative(&e, cp, J, isi, val);
+            n_interp += isi ? 1 : 0;
+            std::printf("H J %.9g %.9g %.9g %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (double)p.x, (double)p.y, (double)p.z, isi ? 1 : 0, val,
+                        J(0), J(1), J(2), J(3), J(4), J(5));
+        }
+        const bool ok4 = idx == m * m * 3 + m * (m - 1) + 7 && back(0) == 3 && back(1) == m - 1 && back(2) == 7 && n_interp > 10;
+        std::printf("%s public helpers of the two classes\n", ok4 ? "ok" : "FAIL"); bad += !ok4;
     } catch (const tsdf_shim::Error& e) {
         std::fprintf(stderr, "tsdf error %d: %s\n", e.code, e.what());
         return 1;

@@ -69,14 +69,55 @@ def test_exact_type_call_sites_give_the_same_trajectory_as_the_plain_shim(tmp_pa
 @pytest.mark.gpu
 def test_exact_type_shim_field_writes_constructor_constants_and_cloud_token(tmp_path):
     """Traps beyond sdf_reconstruction.cpp's own statements (camera_tracking.h:43-63): assigning the public pose / K fields,
-    a CameraTracking built with other constants than the SDF's, a cloud modified in place between the two hot calls."""
+    a CameraTracking built with other constants than the SDF's, a cloud modified in place between the two hot calls; and
+    the rest of the two classes' public surface (sdf.h:113-181, camera_tracking.h:69-101) against the oracle: index and
+    coordinate maps, projections (bit for bit) and get_partial_derivative (13 look-ups in HBM; J, value and the flag)."""
+    import oracle as orc
     from dump_frames import dump
     subprocess.check_call(["make", "-C", ROOT, "-s", "shim_fields_demo"])
     frames_bin = str(tmp_path / "frames.bin")
-    dump(frames_bin, n=2, width=160, height=120, step=2)
-    p = subprocess.run([os.path.join(ROOT, "build", "shim_fields_demo"), frames_bin, "64"], capture_output=True, text=True)
+    m = 64
+    seq = dump(frames_bin, n=2, width=160, height=120, step=2)
+    p = subprocess.run([os.path.join(ROOT, "build", "shim_fields_demo"), frames_bin, str(m)], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert p.stdout.count("ok ") == 3 and "FAIL" not in p.stdout
+    assert p.stdout.count("ok ") == 4 and "FAIL" not in p.stdout
+    # the helper values against the oracle's restatement of the same reference lines
+    H = {}
+    for line in p.stdout.splitlines():
+        if line.startswith("H "):
+            H.setdefault(line.split()[1], []).append([float(x) for x in line.split()[2:]])
+    oo = orc.SDF(m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025)
+    ot = orc.CameraTracking(oo)
+    ot.set_K(seq.K)
+    xyz, nrm, rgb = seq.frame(0)
+    oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+    L, C = orc.lib(), orc.C
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ijk = np.array([3, m - 1, 7], dtype=np.int32)
+    g, vox = np.zeros(3), np.zeros(3)
+    L.orc_get_global_coordinates(oo._p, ijk.ctypes.data_as(C.POINTER(C.c_int32)), dp(g))
+    L.orc_get_voxel_coordinates(oo._p, dp(g), dp(vox))
+    geo = H["geo"][0]
+    assert geo[0:3] == list(g) and geo[3:6] == list(vox)
+    cam = [(ot.rot_inv[r, 0] * g[0] + ot.rot_inv[r, 1] * g[1]) + ot.rot_inv[r, 2] * g[2] + ot.rot_inv_trans[r] for r in range(3)]
+    assert geo[6:9] == cam
+    K = np.asarray(seq.K, dtype=np.float64)
+    ij = [(K[r, 0] * cam[0] + K[r, 1] * cam[1]) + K[r, 2] * cam[2] for r in range(3)]
+    assert geo[9:11] == [ij[0] / ij[2], ij[1] / ij[2]]
+    world = [(ot.rot[r, 0] * cam[0] + ot.rot[r, 1] * cam[1]) + ot.rot[r, 2] * cam[2] + ot.trans[r] for r in range(3)]
+    assert geo[11:14] == world and np.allclose(world, g, atol=1e-12)
+    assert H["idx"][0] == [m * m * 3 + m * (m - 1) + 7, -1, 3, m - 1, 7]
+    n_ok = 0
+    for row in H["J"]:
+        cp = np.array(row[0:3], dtype=np.float32).astype(np.float64)
+        in_grid, J, ok, val = ot.get_partial_derivative(oo, cp)
+        assert in_grid                                     # (the demo's points lie inside the default volume)
+        assert int(row[3]) == int(ok)
+        assert row[4] == val or (np.isnan(row[4]) and np.isnan(val))
+        if ok:
+            assert row[5:11] == list(J)
+            n_ok += 1
+    assert n_ok > 10
 
 
 @pytest.mark.gpu

@@ -153,6 +153,44 @@ def test_config5_shapes_1280x960_at_1024():
     s.close()
 
 
+FR3_K = np.array([[535.4, 0.0, 320.1], [0.0, 539.2, 247.6], [0.0, 0.0, 1.0]])
+
+
+def test_config4_workload_1024_cubed_with_colour_and_fr3_intrinsics():
+    """BASELINE config 4 as it is specified: fr3 intrinsics (535.4 / 539.2 / 320.1 / 247.6), 640x480 images, 1024^3
+    voxels WITH the colour lanes the reference always updates (sdf.cpp:294-304): 8 GiB of {D,W} + 16 GiB of colour on
+    the one GPU (the 8-way slab split of this volume is test_multirank_gpu / bench --config 4).  The volume never leaves
+    the device: counters, device-side SDF samples, and the colours of the extracted mesh."""
+    import tracking_sdf_amd as ts
+    m = 1024
+    seq = synth.Sequence(n_frames=2, width=640, height=480, noise=True, holes=0.02, step=3, K=FR3_K)
+    fr = [seq.frame(k) for k in range(2)]
+    s = ts.SDF(m, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    st1 = s.update(t, *fr[0])
+    # colours after ONE update are the pixel's own bytes: Color_W = wc, R = (0 * 0.4 + wc * r) / wc = r (up to rounding)
+    v1, c1 = s.mesh(with_color=True)
+    st2 = s.update(t, *fr[0])
+    assert st1["n_voxels"] == m ** 3 and st1["n_updated"] == st2["n_updated"] and 0.03 < st1["n_updated"] / m ** 3 < 0.2
+    val, ok, smooth = surface_samples(s, seq, fr[0][0], m)
+    assert ok.mean() > 0.95 and smooth.mean() > 0.5
+    assert np.all(np.abs(val[ok & smooth]) < 0.03) and np.all(np.abs(val[ok]) <= 0.3)
+    # the same frame twice leaves D where it was ((W d + w d) / (W + w) with identical terms is exact): the mesh does not
+    # move; the colour averages move by roundings only ((wc r) / wc is r up to an ulp, then averaged with r again)
+    v2, c2 = s.mesh(with_color=True)
+    assert len(v1) > 200000 and np.array_equal(v1.view(np.int32), v2.view(np.int32))
+    rgb1, rgb2 = c1[..., :3], c2[..., :3]
+    fin = np.isfinite(rgb1).all(axis=-1) & np.isfinite(rgb2).all(axis=-1)
+    assert fin.mean() > 0.99 and np.allclose(rgb1[fin], rgb2[fin], rtol=1e-5, atol=1e-4)
+    assert np.nanmin(rgb1) >= 0.0 and np.nanmax(rgb1) <= 255.0 and np.nanmax(rgb1) > 0.5      # real colours, not the 0.4 grey of the constructor
+    s.set_frame(fr[1][0])
+    t.set_camera_transformation(seq.R[1], seq.t[1])
+    A, b, st = t.accumulate()
+    assert st["n_samples"] == 214 * 160 and st["n_ok"] > 25000 and np.array_equal(A, A.T)
+    s.close()
+
+
 def test_config5_2048_cubed_on_one_gpu():
     """BASELINE config 5 is 2048^3 over 8 GPUs; one MI355X (288 GB) holds the 64 GiB of {D,W} by itself, which
     exercises 64-bit voxel indexing (the reference's int voxel count wraps at m >= 1291, sdf.cpp:9) and the

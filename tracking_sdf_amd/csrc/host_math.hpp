@@ -123,6 +123,29 @@ inline bool solve_normal(const double* A, const double* b, double* x) {
 }
 
 // exp of the twist (v, w) * dt as a 3x4 [R|t], with the reference's small-angle guards.
+//
+// Bit parity with the reference requires its closed form term for term: this function restates
+// eigen_utils::direct_exponential_map / UThetaToAffine3d / f_sinc / f_mcosc / f_msinc of the reference's
+// src/src/eigen_utils.cpp:40-128, which is distributed under the following terms (BSD 3-clause):
+//
+//   Copyright (c) 2013, Willow Garage, Inc.  All rights reserved.
+//   Author: Mario Prats.  Much of this code has been adapted from the ViSP library (http://www.irisa.fr/lagadic/visp).
+//
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the
+//   following conditions are met:
+//     * Redistributions of source code must retain the above copyright notice, this list of conditions and the
+//       following disclaimer.
+//     * Redistributions in binary form must reproduce the above copyright notice, this list of conditions and the
+//       following disclaimer in the documentation and/or other materials provided with the distribution.
+//     * Neither the name of the Willow Garage, Inc. nor the names of its contributors may be used to endorse or promote
+//       products derived from this software without specific prior written permission.
+//   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES,
+//   INCLUDING, BUT NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE
+//   DISCLAIMED.  IN NO EVENT SHALL THE COPYRIGHT OWNER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL,
+//   SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR
+//   SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY,
+//   WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE
+//   OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
 inline void exp_se3(const double* xi, double dt, double* R /*9*/, double* t /*3*/) {
     double v[3] = {xi[0] * dt, xi[1] * dt, xi[2] * dt};
     double u[3] = {xi[3] * dt, xi[4] * dt, xi[5] * dt};
