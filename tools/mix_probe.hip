@@ -149,7 +149,52 @@ __global__ __launch_bounds__(256) void mix2(const u4* __restrict__ rec, unsigned
     if (acc == 0x12345678u) out[wave] = acc;
 }
 
-int main() {
+// TILE pattern (round 4): what if a wavefront's 64 lanes were 16 consecutive rows (j: the viewing direction for the
+// reference's initial pose, 4 KiB apart in {D,W}) x 4 consecutive k instead of 64 consecutive k of one row?  The four
+// wavefronts of a workgroup take the four k-quads of a 16 x 16 tile (together whole 128-byte lines of 16 rows), walk the
+// four tiles of a 64-voxel chunk, then the next chunk, then the next 16 rows.  The 16 rows of a lane group see nearly the
+// same pixels (a ray through the volume), so a gather instruction touches a few cache lines instead of ~39.
+// Same number of lanes, same live fraction (a run of 34 of the 64 k of every row and chunk), same bytes.
+template <int MODE>
+__global__ __launch_bounds__(256) void mix3(const u4* __restrict__ rec, unsigned nrec, u2* __restrict__ dw, u4* __restrict__ col,
+                                            unsigned nrows, int steps, unsigned* __restrict__ out, int drift16 /* pixel columns crossed by 16 rows, x16 */) {
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave = blockIdx.x * 4 + wv;
+    const unsigned jj = lane >> 2, kk = lane & 3;
+    unsigned acc = 0;
+    const unsigned row0 = (unsigned)(((unsigned long long)blockIdx.x * 2654435761ull) % (nrows - 16u * ((unsigned)steps / 20u + 2u))) & ~15u;
+    const unsigned colbase = (blockIdx.x * 747796405u + 2891336453u) % 600u;
+    for (int it = 0; it < steps; ++it) {
+        const unsigned tk = (unsigned)it & 3u, grp = (unsigned)it >> 2, chunk = grp % 5u + 1u, rowblk = grp / 5u;
+        const unsigned row = row0 + rowblk * 16u + jj;
+        const unsigned k = chunk * 64u + tk * 16u + wv * 4u + kk;
+        unsigned h = (blockIdx.x * 2654435761u) ^ (grp * 40503u + jj * 7u);   // the row's live run in this chunk
+        h = (h ^ (h >> 13)) * 1274126177u;
+        const unsigned first = (h >> 8) % 30u;
+        const bool live = (k & 63u) >= first && (k & 63u) < first + 34u;
+        u4 ga = u4{0, 0, 0, 0}, gb = ga;
+        if (MODE != 1) {
+            // record of lane pair p: pixel column drifts with the row (jj), pixel row = 2.4 k; column-major records
+            auto recidx = [&](unsigned p) {
+                const unsigned pj = p >> 2, pk = chunk * 64u + tk * 16u + wv * 4u + (p & 3u);
+                const unsigned colpx = colbase + rowblk + ((pj * (unsigned)drift16) >> 8), rowpx = (pk * 12u / 5u) % 480u;
+                return (colpx * 480u + rowpx) % nrec;
+            };
+            ga = rec[(size_t)recidx(lane >> 1) * 2 + (lane & 1)];
+            gb = rec[(size_t)recidx(32u + (lane >> 1)) * 2 + (lane & 1)];
+        }
+        acc ^= ga.x + gb.w;
+        if (MODE != 2) {
+            const size_t vox = (size_t)row * 512u + k;
+            u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
+            if (live) { d = dw[vox]; c = __builtin_nontemporal_load(&col[vox]); }
+            d.x += acc; c.y ^= d.y;
+            if (live) { dw[vox] = d; __builtin_nontemporal_store(c, &col[vox]); }
+        }
+    }
+    if (acc == 0x12345678u) out[wave] = acc;
+}
+
+int main(int argc, char**) {
     const unsigned nrec = 307200, nseg = 2097152;                  // 512^3 / 64 segments
     u4 *rec, *col; u2* dw; unsigned* out;
     CHECK(hipMalloc(&rec, (size_t)nrec * 32)); CHECK(hipMalloc(&dw, (size_t)nseg * 512)); CHECK(hipMalloc(&col, (size_t)nseg * 1024));
@@ -157,9 +202,10 @@ int main() {
     CHECK(hipMemset(rec, 1, (size_t)nrec * 32)); CHECK(hipMemset(dw, 0, (size_t)nseg * 512)); CHECK(hipMemset(col, 0, (size_t)nseg * 1024));
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     const char* names[5] = {"all", "no_gathers", "no_volume", "no_stores", "no_gathers_stores_elsewhere"};
+    const bool only_new = argc > 1;     // any argument: only the round-4 sweeps
     // grid sweep (199.7k items in all): wavefronts per CU = blocks * 4 / 256
     const int grids[6] = {1280, 256, 512, 768, 1024, 2048};
-    for (int gi = 0; gi < 6; ++gi) {
+    for (int gi = 0; gi < (only_new ? 0 : 6); ++gi) {
         const int blocks = grids[gi], ipw = (199680 + blocks * 4 - 1) / (blocks * 4);
         for (int rep = 0; rep < 3; ++rep)
             for (int pipe = 0; pipe < (gi == 0 ? 4 : 1); ++pipe)
@@ -177,7 +223,7 @@ int main() {
                     if (rep == 2) printf("{\"workgroups\": %d, \"items_per_wavefront\": %d, \"mode\": \"%s\", \"pipe\": %d, \"us_per_launch\": %.1f}\n", blocks, ipw, names[mode], pipe, ms * 100.0);
                 }
     }
-    for (int wi = 0; wi < 5; ++wi) {
+    for (int wi = 0; wi < (only_new ? 0 : 5); ++wi) {
         const unsigned windows[5] = {0, 480, 960, 480, 480}, shares[5] = {1, 1, 1, 8, 256};
         for (int rep = 0; rep < 3; ++rep) {
             CHECK(hipEventRecord(a));
@@ -208,5 +254,26 @@ int main() {
                     printf("{\"probe\": \"mix2\", \"address_order\": \"%s\", \"volume_access\": \"%s\", \"mode\": \"%s\", \"workgroups\": %d, \"us_per_launch\": %.1f}\n",
                            order ? "kernel" : "random", dense ? "dense_batches_2x32" : "items_34_of_64", names[mode], blocks, best * 100.0);
                 }
+    // round 4: 16 rows x 4 k per wavefront (tile pattern)
+    for (int drift = 0; drift < 3; ++drift)
+        for (int mode = 0; mode < 3; ++mode)
+            for (int gi = 0; gi < 2; ++gi) {
+                const int blocks = gi == 0 ? 1280 : 1024, steps = (199680 + blocks * 4 - 1) / (blocks * 4);
+                const int drift16 = drift == 0 ? 16 * 16 / 8 : (drift == 1 ? 16 * 16 * 5 / 16 : 16 * 16);      // 2, 5 or 16 pixel columns per 16 rows
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    CHECK(hipEventRecord(a));
+                    for (int k = 0; k < 10; ++k) {
+                        if (mode == 0) mix3<0><<<blocks, 256>>>(rec, nrec, dw, col, 512u * 512u, steps, out, drift16);
+                        if (mode == 1) mix3<1><<<blocks, 256>>>(rec, nrec, dw, col, 512u * 512u, steps, out, drift16);
+                        if (mode == 2) mix3<2><<<blocks, 256>>>(rec, nrec, dw, col, 512u * 512u, steps, out, drift16);
+                    }
+                    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+                    if (rep > 0 && ms < best) best = ms;
+                }
+                printf("{\"probe\": \"mix3\", \"pattern\": \"16_rows_x_4_k_per_wavefront\", \"pixel_columns_per_16_rows\": %d, \"mode\": \"%s\", \"workgroups\": %d, \"us_per_launch\": %.1f}\n",
+                       drift16 / 16, names[mode], blocks, best * 100.0);
+            }
     return 0;
 }

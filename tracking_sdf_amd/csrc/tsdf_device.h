@@ -108,8 +108,7 @@ size_t integrate_worklist_bytes(const Grid& g);      // 32-byte item descriptors
 constexpr size_t kPixelRecordBytes = 32;             // per pixel: two float4 records (24 of them used when the volume has no colour)
 constexpr size_t kPixelBufferBytes = 40;             // what a frame's pixel buffer holds per pixel: the record + the f64 cosine (colour volumes)
 size_t integrate_bookkeeping_words();
-// queue = the round-4 kernel that updates dense batches of queued voxels (integrate_queue_kernel; needs
-// integrate_queue_fits(): fewer than 2^32 stored voxels), otherwise round 3's item-at-a-time integrate_kernel
+// queue = the round-4 kernel that updates dense batches of queued voxels (integrate_queue_kernel), otherwise round 3's item-at-a-time integrate_kernel
 int integrate_blocks_per_cu(bool queue);
 bool integrate_queue_fits(const Grid& g);
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,

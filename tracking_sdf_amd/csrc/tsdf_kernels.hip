@@ -475,6 +475,13 @@ __device__ __forceinline__ unsigned select_by_mask(unsigned long long mask, unsi
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
     return r;
 }
+// the same for a mask that IS wave-uniform but that hipcc's uniformity analysis may have given up on (the "s" constraint
+// would then receive a vector register pair): readfirstlane, folded away when the mask already sits in scalar registers
+__device__ __forceinline__ unsigned select_by_uniform_mask(unsigned long long mask, unsigned a, unsigned b) {
+    const unsigned long long m = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mask) |
+                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask >> 32)) << 32);
+    return select_by_mask(m, a, b);
+}
 
 // What both integrate kernels need to turn an item into pixel indices: constants of the launch in registers.
 struct ProjConst {
@@ -1000,9 +1007,22 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 // grouping of voxels into wavefront instructions differs.  Wave-private queues: no barrier, no atomics; LDS operations
 // of one wavefront execute in order.  A queue never holds more than 63 + 64 entries: after an item at most one queue can
 // have reached 64 unless both were nearly full, and the consume loop pops until both are below 64 again.
-// Voxel indices are 32-bit: volumes (slab + halo) of 2^32 voxels and more stay with integrate_kernel.
+// Volume accesses are raw buffer operations with 32-bit offsets into a WINDOW of 2^27 voxels (1 GiB of {D,W}, 2 GiB of
+// colour; a 512^3 volume is one window): the queues hold window-relative voxel indices, an item of another window than
+// the current one first flushes them (a wavefront's items follow the row order of the list, so this is rare), and lanes
+// without a voxel carry an out-of-range offset and touch no memory -- which keeps every vector-memory operation of the
+// batch stages unconditional (see form_batch).
 
+#ifndef TSDF_QUEUE_ALIGN
+#define TSDF_QUEUE_ALIGN 1                // lanes are queued in aligned groups of this many (1: lane by lane)
+#endif
+#ifndef TSDF_QUEUE_FIFO
+#define TSDF_QUEUE_FIFO 1                 // queues are rings (voxels leave in the order they came: a batch = the lanes of neighbouring items)
+#endif
 constexpr int kQCap = 128;                 // entries per queue and wavefront (>= 63 + 64)
+constexpr int kWindowBits = 27;            // voxels per volume window: offsets (index << 4 for colour) stay below 2^31
+constexpr unsigned kDroppedVolumeOffset = 0xfffffff0u;   // beyond every window, also when doubled for the colour array
+constexpr unsigned kHoleVoxel = 0x1ffffffeu;              // queue entry without a voxel (aligned compaction): (x << 3) is out of range
 
 template <bool COLOR> struct QueueEntry { typedef u32x4 T; };     // {voxel, d bits, (float)cosine | biased pixel index, rgb}
 template <> struct QueueEntry<false> { typedef u32x2 T; };        // {voxel, d bits}
@@ -1070,15 +1090,41 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         u32x4 A, B;             // halves of the pixel records, as in integrate_kernel (in flight until S2)
     };
     struct Batch {              // 64 queued voxels whose volume data is in flight
-        unsigned long long valid;  // lanes that hold a voxel (all of them, except when the queues are drained at the end)
-        unsigned vox;           // index into the stored volume
-        float d_new, w_new, wc;
+        unsigned long long valid;  // lanes that hold a voxel (all of them or none, except when the queues are drained at the end)
+        bool band;              // wave-uniform: the voxels come from the exp()-band queue (their weights are formed when the batch is finished)
+        unsigned off8;          // byte offset of the voxel's {D,W} in the current window (lanes without a voxel: out of range)
+        float d_new, wc;        // wc: the colour weight of a weight-1 voxel
         unsigned rgb;
-        u32x2 old;              // {D, W}
-        u32x4 col;              // {Color_W, R, G, B}
+        u32x2 cosb;             // band voxels: the f64 cosine of the pixel (in flight)
+        u32x2 old;              // {D, W}             (in flight)
+        u32x4 col;              // {Color_W, R, G, B} (in flight)
     };
-    // wave-uniform queue state: entries [0, fill) are queued
-    unsigned fill_p = 0u, fill_b = 0u;
+    // wave-uniform queue state: `fill` entries are queued (FIFO: a ring starting at `head`; otherwise a stack)
+    unsigned fill_p = 0u, fill_b = 0u, head_p = 0u, head_b = 0u;
+    // Two batches rotate: the volume data of the batch formed in step j is requested BEFORE the batch of step j-1 is
+    // finished and stored, so that no wait for loads ever has to sit behind a store (a wavefront's vector-memory
+    // operations complete in order: with the stores in front of the next batch's loads every batch waited for the
+    // previous one's stores to be acknowledged -- 50 us of the launch).
+    Batch BB[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        BB[q].valid = 0ull; BB[q].band = false; BB[q].off8 = kDroppedVolumeOffset; BB[q].d_new = 0.f; BB[q].wc = 0.f; BB[q].rgb = 0u;
+        BB[q].cosb = u32x2{0u, 0u}; BB[q].old = u32x2{0u, 0x3f800000u}; BB[q].col = u32x4{0x3f800000u, 0u, 0u, 0u};
+    }
+    // the window of the volume the queued voxels belong to, and its two buffer resources
+    const unsigned long long n_stored = (unsigned long long)(p.g.xe - p.g.xs) * (unsigned)m * (unsigned)m;
+    const bool multi_window = n_stored > (1ull << kWindowBits);
+    unsigned w_cur = 0u;
+    __amdgpu_buffer_rsrc_t dw_rsrc, col_rsrc;
+    auto set_window = [&](unsigned w) {
+        const unsigned long long first = (unsigned long long)w << kWindowBits;
+        const unsigned long long left = n_stored > first ? n_stored - first : 0ull;
+        const unsigned nvox = (unsigned)(left < (1ull << kWindowBits) ? left : (1ull << kWindowBits));
+        dw_rsrc = __builtin_amdgcn_make_buffer_rsrc(dw + first, 0, (int)(nvox * (unsigned)sizeof(float2)), kRsrcWord3);
+        col_rsrc = __builtin_amdgcn_make_buffer_rsrc(COLOR ? crgb + first : crgb, 0, COLOR ? (int)(nvox * (unsigned)sizeof(float4)) : 0, kRsrcWord3);
+        w_cur = w;
+    };
+    set_window(0u);
 
     auto stage1 = [&](int j, Gather& g /*out: item j*/) {
         const bool have = j < cnt;
@@ -1093,6 +1139,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         unsigned pixb;
         project_item<KSTD, KTAB>(pc, ds, s_tab, lane, g.pcx, g.pcy, g.pcz, okm, pixb);
         if (!have) okm = 0ull;
+#if TSDF_INTEGRATE_DEBUG
+        if (p.debug & 1) pixb = __builtin_amdgcn_readfirstlane(pixb);       // timing experiment only: one record per wave
+#endif
         const unsigned roff = select_by_mask(okm, COLOR ? pixb << 5 : __umul24(pixb, (unsigned)kRec), dropped);
         const unsigned ra = (unsigned)__shfl((int)roff, lane >> 1) + half_off;
         const unsigned rb = (unsigned)__shfl((int)roff, 32 + (lane >> 1)) + half_off;
@@ -1110,12 +1159,119 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     };
     // append the lanes of `mask` to a queue (a stack: the order in which voxels are updated is free): position = fill +
     // number of mask lanes below this one
-    auto push = [&](unsigned long long mask, Entry* q, unsigned& fill, const Entry& e) {
+    auto push = [&](unsigned long long mask, Entry* q, unsigned head, unsigned& fill, const Entry& e) {
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+#if TSDF_QUEUE_FIFO
+        if (__builtin_amdgcn_inverse_ballot_w64(mask)) q[(head + fill + pre) & (unsigned)(kQCap - 1)] = e;
+#else
+        (void)head;
         if (__builtin_amdgcn_inverse_ballot_w64(mask)) q[fill + pre] = e;
+#endif
         fill += (unsigned)__popcll(mask);
     };
-    auto stage2 = [&](const Gather& gin /*item j-1, record arrived*/) {
+    // pop the top (up to 64) entries of a queue into the lanes of a batch
+    auto pop = [&](const Entry* q, unsigned& head, unsigned& fill, unsigned long long& valid) -> Entry {
+        const unsigned n = fill < 64u ? fill : 64u;
+        valid = n == 64u ? ~0ull : ((1ull << n) - 1ull);
+        fill -= n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes' queue writes before these reads
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if TSDF_QUEUE_FIFO
+        const Entry e = q[(head + (unsigned)lane) & (unsigned)(kQCap - 1)];   // (lanes >= n read stale entries: masked by `valid`)
+        head = (head + n) & (unsigned)(kQCap - 1);
+        return e;
+#else
+        (void)head;
+        return q[fill + (unsigned)lane];                           // (lanes >= n read stale entries: masked by `valid`)
+#endif
+    };
+    // Vector-memory operations of the batch stages are issued UNCONDITIONALLY, whether there is a batch or not: a wavefront
+    // waits by COUNTING its outstanding operations (s_waitcnt vmcnt(N): all but the N youngest), and hipcc can only
+    // count what every path issues.  With the batch's loads and stores inside `if (batch)` it had to assume the smallest
+    // count at every join, and the pixel records of S2 then waited for the volume data requested just before them (measured:
+    // wavefronts parked 47 % of their life instead of 23 %, 147 us against 136).  Lanes without a voxel (all of them when no
+    // queue has 64 entries) carry an out-of-range buffer offset: no memory access, but the operation counts.
+    // form a batch from whichever queue has reached `thresh` entries (none: an empty batch) and request its volume data
+    auto form_batch = [&](Batch& b, unsigned thresh) {
+        Entry e;
+        e.x = 0u; e.y = 0u;
+        if constexpr (COLOR) { e.z = 0u; e.w = 0u; }
+        b.valid = 0ull;
+        b.band = false;
+        if (fill_p >= thresh) e = pop(q_plain, head_p, fill_p, b.valid);
+        else if (fill_b >= thresh) { e = pop(q_band, head_b, fill_b, b.valid); b.band = true; }
+        b.off8 = select_by_uniform_mask(b.valid, e.x << 3, kDroppedVolumeOffset);
+#if TSDF_INTEGRATE_DEBUG
+        if (p.debug & 64) b.off8 = select_by_uniform_mask(b.valid, ((unsigned)(blockIdx.x & 255) * 4096u + (unsigned)wv * 64u + (unsigned)lane) << 3, kDroppedVolumeOffset);   // timing experiment only: cache-resident volume accesses
+        if (p.debug & 2) b.off8 = kDroppedVolumeOffset;                      // timing experiment only: no volume RMW
+#endif
+        b.d_new = __uint_as_float(e.y);
+        if constexpr (COLOR) {
+            b.wc = __uint_as_float(e.z); b.rgb = e.w;
+            // band lanes carry their pixel: the f64 cosine of sdf.cpp:294 comes from pack_kernel's plane
+            const unsigned off = select_by_uniform_mask(b.band ? b.valid : 0ull, e.z << 3, dropped);
+            b.cosb = __builtin_amdgcn_raw_buffer_load_b64(cos_rsrc, (int)off, 0, 0);
+        }
+        b.old = __builtin_amdgcn_raw_buffer_load_b64(dw_rsrc, (int)b.off8, 0, 0);   // {D,W}: the tracker re-reads these lines -> keep them cached
+        if constexpr (COLOR)       // colour is streamed once per frame and never read by the tracker: non-temporal
+            b.col = __builtin_amdgcn_raw_buffer_load_b128(col_rsrc, (int)(b.off8 << 1), 0, 2);
+    };
+    // the running averages of sdf.cpp:289-304 for a batch whose volume data has arrived, and the stores
+    auto finish_batch = [&](const Batch& b) {
+        u32x2 o2 = u32x2{0u, 0u};
+        u32x4 c4 = u32x4{0u, 0u, 0u, 0u};
+        if (b.valid != 0ull) {
+            float w_new = 1.0f, wc = COLOR ? b.wc : 0.f;                    // sdf.cpp:276; colour weight of a weight-1 voxel = the record's (float)cosine
+            if (b.band) {
+                w_new = band_weight<EXPPOLY>(b.d_new, eps);                 // sdf.cpp:277-279
+                if constexpr (COLOR)                                       // sdf.cpp:295: (float)(w_new * cosine)
+                    wc = (float)((double)w_new * __hiloint2double((int)b.cosb.y, (int)b.cosb.x));
+            }
+            // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
+            const float W = __uint_as_float(b.old.y), D = __uint_as_float(b.old.x);
+            const float cx = __uint_as_float(b.col.x);
+            v2f sum1, num1, num2 = v2f{0.f, 0.f};
+            sum1.x = W + w_new;
+            num1.x = W * D + w_new * b.d_new;
+            if (COLOR) {
+                const unsigned rgb = b.rgb;
+                const float pr = (float)(rgb & 255u), pg = (float)((rgb >> 8) & 255u), pb = (float)((rgb >> 16) & 255u);
+                sum1.y = cx + wc;
+                num1.y = cx * __uint_as_float(b.col.y) + wc * pr;
+                num2 = v2f{cx, cx} * v2f{__uint_as_float(b.col.z), __uint_as_float(b.col.w)} + v2f{wc, wc} * v2f{pg, pb};
+            } else {
+                sum1.y = 1.0f; num1.y = 0.0f;
+            }
+            const v2f r = rcp_refined(sum1);
+            v2f q1 = div_core(num1, sum1, r), q2 = v2f{0.f, 0.f};
+            if (COLOR) q2 = div_core(num2, v2f{sum1.y, sum1.y}, v2f{r.y, r.y});
+            unsigned long long bad = tiny_lanes(num1) | lanes(b.old.y >= kBits2p64);
+            if (COLOR) bad |= tiny_lanes(num2) | lanes(b.col.x >= kBits2p64);
+            if (__builtin_expect((bad & b.valid) != 0ull, 0)) {
+                q1.x = num1.x / sum1.x;
+                if (COLOR) { q1.y = num1.y / sum1.y; q2.x = num2.x / sum1.y; q2.y = num2.y / sum1.y; }
+            }
+            o2.x = __float_as_uint(q1.x); o2.y = __float_as_uint(sum1.x);
+            if (COLOR) { c4.x = __float_as_uint(sum1.y); c4.y = __float_as_uint(q1.y); c4.z = __float_as_uint(q2.x); c4.w = __float_as_uint(q2.y); }
+        }
+        unsigned st8 = b.off8;
+#if TSDF_INTEGRATE_DEBUG
+        if (p.debug & 32) st8 = kDroppedVolumeOffset;                       // timing experiment only: no stores
+#endif
+        __builtin_amdgcn_raw_buffer_store_b64(o2, dw_rsrc, (int)st8, 0, 0);        // (lanes without a voxel: dropped)
+        if constexpr (COLOR) __builtin_amdgcn_raw_buffer_store_b128(c4, col_rsrc, (int)(st8 << 1), 0, 2);   // nt: colour is streamed
+    };
+    // everything queued goes out (partial batches): at the end, and before the window of the volume changes.
+    // `pending`: the batch whose volume data is in flight; `done`: the other one, already stored.
+    auto flush_queues = [&](Batch& pending, Batch& done) {
+        finish_batch(pending);
+#pragma unroll 1
+        while ((fill_p | fill_b) != 0u) { form_batch(done, 1u); finish_batch(done); }
+        pending.valid = 0ull; pending.band = false; pending.off8 = kDroppedVolumeOffset;
+        done.valid = 0ull; done.band = false; done.off8 = kDroppedVolumeOffset;
+    };
+    auto stage2 = [&](const Gather& gin /*item j-1, record arrived*/, Batch& pending, Batch& done) {
         u32x4* stage = s_pieces[wv];
         if (COLOR) { stage[lane] = gin.A; stage[64 + lane] = gin.B; }
         else {
@@ -1152,8 +1308,14 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         n_halo += owned ? 0u : n_live;
         if (okm == 0ull) return;                                            // nothing of this item is updated
         d = d < neg_delta ? neg_delta : d;                                  // sdf.cpp:285-287 (band lanes: d >= eps, unchanged)
+        // the item's 64 voxels: index in the stored volume = row * m + chunk * 64 + lane; window and window-relative index
+        const unsigned long long vox0 = (unsigned long long)row * (unsigned)m + (gin.code & 63u) * 64u;
+        if (multi_window) {
+            const unsigned w_item = (unsigned)(vox0 >> kWindowBits);
+            if (__builtin_expect(w_item != w_cur, 0)) { flush_queues(pending, done); set_window(w_item); }
+        }
         Entry e;
-        e.x = row * (unsigned)m + (gin.code & 63u) * 64u + (unsigned)lane;  // voxel index in the stored volume (< 2^32: launch_integrate)
+        e.x = ((unsigned)vox0 & ((1u << kWindowBits) - 1u)) + (unsigned)lane;
         e.y = __float_as_uint(d);
         if constexpr (COLOR) {
             // sdf.cpp:294-299: weight-1 lanes take the pre-rounded cosine of the record as their colour weight; band lanes
@@ -1161,85 +1323,34 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             e.z = select_by_mask(bandm, gin.pixb, N.w);
             e.w = P.w;
         }
-        push(plainm, q_plain, fill_p, e);
-        if (bandm != 0ull) push(bandm, q_band, fill_b, e);
-    };
-    // pop the top (up to 64) entries of a queue into the lanes of a batch
-    auto pop = [&](const Entry* q, unsigned& fill, unsigned long long& valid) -> Entry {
-        const unsigned n = fill < 64u ? fill : 64u;
-        valid = n == 64u ? ~0ull : ((1ull << n) - 1ull);
-        fill -= n;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes' queue writes before these reads
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        return q[fill + (unsigned)lane];                           // (lanes >= n read stale entries: masked by `valid`)
-    };
-    // form a batch from whichever queue has reached `thresh` entries and request its volume data
-    auto form_batch = [&](Batch& b, unsigned thresh) {
-        if (fill_p >= thresh) {
-            const Entry e = pop(q_plain, fill_p, b.valid);
-            b.vox = e.x; b.d_new = __uint_as_float(e.y); b.w_new = 1.0f;    // sdf.cpp:276
-            if constexpr (COLOR) { b.wc = __uint_as_float(e.z); b.rgb = e.w; }
-        } else {
-            const Entry e = pop(q_band, fill_b, b.valid);
-            const float d = __uint_as_float(e.y);
-            b.vox = e.x; b.d_new = d;
-            float wn;
-            if constexpr (COLOR) {
-                // cosine of sdf.cpp:294 in f64 from pack_kernel's plane; wc = (float)(w_new * cosine), sdf.cpp:295
-                const unsigned off = select_by_mask(b.valid, e.z << 3, dropped);
-                const u32x2 cb = __builtin_amdgcn_raw_buffer_load_b64(cos_rsrc, (int)off, 0, 0);
-                wn = band_weight<EXPPOLY>(d, eps);                          // sdf.cpp:277-279 (while the gather is under way)
-                const double cosine = __hiloint2double((int)cb.y, (int)cb.x);
-                b.wc = (float)((double)wn * cosine);
-                b.rgb = e.w;
-            } else {
-                wn = band_weight<EXPPOLY>(d, eps);
-            }
-            b.w_new = wn;
+#if TSDF_QUEUE_ALIGN > 1
+        // Compaction in ALIGNED groups of TSDF_QUEUE_ALIGN lanes: a group with an updated voxel is queued whole (its other
+        // lanes as holes that touch no memory), so that a batch's lane groups stay aligned with the 32 / 64-byte sectors
+        // the vector L1 works in (lane-granular compaction costs ~13 more L1 accesses per item: a group of 4 lanes of a
+        // colour access then straddles two sectors three times out of four).
+        {
+            constexpr int GA = TSDF_QUEUE_ALIGN;
+            auto widen = [](unsigned long long mk) {
+                unsigned long long g = mk;
+#pragma unroll
+                for (int sft = 1; sft < GA; sft <<= 1) g |= g >> sft;
+                constexpr unsigned long long first = GA == 4 ? 0x1111111111111111ull : (GA == 8 ? 0x0101010101010101ull : (GA == 16 ? 0x0001000100010001ull : 1ull));
+                g &= first;
+                return GA == 64 ? (g ? ~0ull : 0ull) : g * ((1ull << (GA & 63)) - 1ull);
+            };
+            const unsigned long long wide_p = widen(plainm), wide_b = widen(bandm);
+            Entry ep = e, eb = e;
+            unsigned hole = kHoleVoxel;
+            asm volatile("" : "+v"(hole));
+            ep.x = select_by_mask(plainm, e.x, hole);
+            eb.x = select_by_mask(bandm, e.x, hole);
+            push(wide_p, q_plain, head_p, fill_p, ep);
+            if (bandm != 0ull) push(wide_b, q_band, head_b, fill_b, eb);
+            return;
         }
-        b.old = u32x2{0u, 0x3f800000u}; b.col = u32x4{0x3f800000u, 0u, 0u, 0u};   // (harmless operands in the lanes of a partial batch)
-        if (__builtin_amdgcn_inverse_ballot_w64(b.valid)) {
-            b.old = *reinterpret_cast<const u32x2*>(dw + b.vox);           // {D,W}: the tracker re-reads these lines -> keep them cached
-            if constexpr (COLOR)   // colour is streamed once per frame and never read by the tracker: non-temporal
-                b.col = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(crgb + b.vox));
-        }
-    };
-    // the running averages of sdf.cpp:289-304 for a batch whose volume data has arrived, and the stores
-    auto finish_batch = [&](const Batch& b) {
-        // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
-        const float W = __uint_as_float(b.old.y), D = __uint_as_float(b.old.x);
-        const float cx = __uint_as_float(b.col.x);
-        const float wc = COLOR ? b.wc : 0.f;
-        v2f sum1, num1, num2 = v2f{0.f, 0.f};
-        sum1.x = W + b.w_new;
-        num1.x = W * D + b.w_new * b.d_new;
-        if (COLOR) {
-            const unsigned rgb = b.rgb;
-            const float pr = (float)(rgb & 255u), pg = (float)((rgb >> 8) & 255u), pb = (float)((rgb >> 16) & 255u);
-            sum1.y = cx + wc;
-            num1.y = cx * __uint_as_float(b.col.y) + wc * pr;
-            num2 = v2f{cx, cx} * v2f{__uint_as_float(b.col.z), __uint_as_float(b.col.w)} + v2f{wc, wc} * v2f{pg, pb};
-        } else {
-            sum1.y = 1.0f; num1.y = 0.0f;
-        }
-        const v2f r = rcp_refined(sum1);
-        v2f q1 = div_core(num1, sum1, r), q2 = v2f{0.f, 0.f};
-        if (COLOR) q2 = div_core(num2, v2f{sum1.y, sum1.y}, v2f{r.y, r.y});
-        unsigned long long bad = tiny_lanes(num1) | lanes(b.old.y >= kBits2p64);
-        if (COLOR) bad |= tiny_lanes(num2) | lanes(b.col.x >= kBits2p64);
-        if (__builtin_expect((bad & b.valid) != 0ull, 0)) {
-            q1.x = num1.x / sum1.x;
-            if (COLOR) { q1.y = num1.y / sum1.y; q2.x = num2.x / sum1.y; q2.y = num2.y / sum1.y; }
-        }
-        if (__builtin_amdgcn_inverse_ballot_w64(b.valid)) {
-            u32x2 o2; o2.x = __float_as_uint(q1.x); o2.y = __float_as_uint(sum1.x);
-            *reinterpret_cast<u32x2*>(dw + b.vox) = o2;
-            if constexpr (COLOR) {
-                u32x4 c4; c4.x = __float_as_uint(sum1.y); c4.y = __float_as_uint(q1.y); c4.z = __float_as_uint(q2.x); c4.w = __float_as_uint(q2.y);
-                __builtin_nontemporal_store(c4, reinterpret_cast<u32x4*>(crgb + b.vox));   // nt: colour is streamed
-            }
-        }
+#endif
+        push(plainm, q_plain, head_p, fill_p, e);
+        if (bandm != 0ull) push(bandm, q_band, head_b, fill_b, e);
     };
 
     Gather G[2];
@@ -1249,34 +1360,24 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         G[q].pcx = G[q].pcy = G[q].pcz = 0.0;
         G[q].A = u32x4{0u, 0u, 0u, 0u}; G[q].B = G[q].A;
     }
-    Batch B;
-    B.valid = 0ull; B.vox = 0u; B.d_new = 0.f; B.w_new = 1.f; B.wc = 0.f; B.rgb = 0u;
-    B.old = u32x2{0u, 0x3f800000u}; B.col = u32x4{0x3f800000u, 0u, 0u, 0u};
     // One step = S1(j) request the pixel records of item j | S2(j-1) distance test, queue the updated lanes of item j-1 |
-    // finish the batch whose volume data was requested a step ago | form the next batch when a queue has 64 entries.
-    // (both queues reaching 64 in the same step is rare and handled apart, so that the common path keeps its exact
-    // s_waitcnt counts)
+    // form the next batch when a queue has 64 entries and request its volume data | finish and store the batch formed a
+    // step ago.  Per step and wavefront: 2 record gathers, 1 cosine gather, 2 volume loads, 2 stores, always in this order.
+    // (both queues reaching 64 in the same step is rare; its second batch is finished on the spot)
     for (int j = 0; j < cnt + 1; j += 2) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             stage1(j + q, G[q]);
-            stage2(G[q ^ 1]);
-            if (B.valid != 0ull) finish_batch(B);
-            B.valid = 0ull;
-            if (fill_p >= 64u || fill_b >= 64u) {
-                form_batch(B, 64u);
-                if (__builtin_expect(fill_p >= 64u || fill_b >= 64u, 0)) { finish_batch(B); form_batch(B, 64u); }
-            }
+            stage2(G[q ^ 1], BB[q ^ 1], BB[q]);
+            form_batch(BB[q], 64u);
+            finish_batch(BB[q ^ 1]);
+            if (__builtin_expect(fill_p >= 64u || fill_b >= 64u, 0)) { finish_batch(BB[q]); form_batch(BB[q], 64u); }
         }
     }
-    // (j runs to cnt or cnt + 1: the last item's record has been consumed by an S2 inside the loop)
+    // (j runs to cnt or cnt + 1: the last item's record has been consumed by an S2 inside the loop; the loop ends after an
+    // odd step, so BB[1] is the batch in flight)
     // drain: what is left in the queues goes out as partial batches
-#pragma unroll 1
-    do {
-        if (B.valid != 0ull) finish_batch(B);
-        B.valid = 0ull;
-        if ((fill_p | fill_b) != 0u) form_batch(B, 1u);
-    } while (B.valid != 0ull);
+    flush_queues(BB[1], BB[0]);
 
     if (wv == 0 && lane == 0)
         atomicAdd(reinterpret_cast<unsigned long long*>(xcd_fb + kFbTicksWord) + xcd, __builtin_amdgcn_s_memrealtime() - loop_t0 + 1ull);
@@ -1307,8 +1408,8 @@ int integrate_blocks_per_cu(bool queue) {
     return n;
 }
 
-// the queue kernel carries voxel indices in 32 bits
-bool integrate_queue_fits(const Grid& g) { return (long long)(g.xe - g.xs) * g.m * g.m < (1ll << 32); }
+// the queue kernel addresses the volume in windows of 2^27 voxels: any size the row code can express fits
+bool integrate_queue_fits(const Grid& g) { return (long long)(g.xe - g.xs) * g.m < (1ll << 26); }
 
 size_t integrate_bookkeeping_words() { return 2 * (size_t)kBinSetWords + kFbWords; }
 static_assert((2 * kBinSetWords) % 2 == 0, "the 64-bit tick sums of the feedback block must be 8-byte aligned");
