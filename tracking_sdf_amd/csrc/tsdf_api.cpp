@@ -179,6 +179,7 @@ struct tsdf_handle {
     bool host_fanin = true;        // the second level of the tracker fan-in runs on the host (TSDF_HOST_FANIN=0: on the device)
     unsigned integrate_launches = 0;
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
+    unsigned long long* track_stamps = nullptr;   // TSDF_TRACK_STAMPS=1: 8 device words per tracker workgroup (phase stamps of the last pass)
     // TSDF_TRACK_PROFILE=1: host-side clock of a pass, printed by tsdf_destroy (ns sums: parameters, launch call, wait
     // for the row, fold + solve + pose)
     bool track_profile = false;
@@ -579,7 +580,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     const auto tp1 = h->track_profile ? std::chrono::steady_clock::now() : tp0;
     HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
                                    use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq,
-                                   use_peer ? &px : nullptr));
+                                   use_peer ? &px : nullptr, h->track_stamps));
     const auto tp2 = h->track_profile ? std::chrono::steady_clock::now() : tp0;
     if (h->track_profile) {
         h->tp_fill += std::chrono::duration<double, std::nano>(tp1 - tp0).count();
@@ -904,6 +905,11 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipHostMalloc((void**)&h->shard_host, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double), hipHostMallocDefault));
     std::memset(h->shard_host, 0, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double));
     { const char* ev = std::getenv("TSDF_HOST_FANIN"); h->host_fanin = !(ev && std::atoi(ev) == 0); }
+    { const char* ev = std::getenv("TSDF_TRACK_STAMPS");      // diagnosis: where inside the launch does a tracker pass spend its time?
+      if (ev && std::atoi(ev) != 0) {
+          CREATE_TRY(hipMalloc((void**)&h->track_stamps, 8 * 4096 * sizeof(unsigned long long)));
+          CREATE_TRY(hipMemsetAsync(h->track_stamps, 0, 8 * 4096 * sizeof(unsigned long long), h->stream));
+      } }
     { const char* ev = std::getenv("TSDF_TRACK_PROFILE"); h->track_profile = ev && std::atoi(ev) != 0; }
     CREATE_TRY(hipMalloc((void**)&h->fold_ctr, track_fold_counter_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, track_fold_counter_words() * sizeof(unsigned), h->stream));
@@ -919,6 +925,27 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
 void tsdf_destroy(tsdf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->track_stamps) {
+        // phase stamps of the LAST tracker pass: per workgroup, microseconds after the earliest workgroup's start
+        std::vector<unsigned long long> st(8 * 4096);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(st.data(), h->track_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            const int nb = track_num_blocks(h->n_samples) < 4096 ? track_num_blocks(h->n_samples) : 4096;
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < nb; ++b) if (st[8 * b] && st[8 * b] < t0) t0 = st[8 * b];
+            const char* names[7] = {"start", "window classified", "own sample", "look-ups done", "row written", "arrived", "shard row out"};
+            for (int k = 0; k < 7; ++k) {
+                double mn = 1e30, mx = 0, sum = 0; int n = 0;
+                for (int b = 0; b < nb; ++b) {
+                    if (!st[8 * b + k] || st[8 * b + k] < t0) continue;
+                    const double v = 0.01 * (double)(st[8 * b + k] - t0);
+                    mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; ++n;
+                }
+                if (n) std::fprintf(stderr, "TRACK_STAMPS %-18s workgroups %4d  min %7.2f  mean %7.2f  max %7.2f us\n", names[k], n, mn, sum / n, mx);
+            }
+        }
+        (void)hipFree(h->track_stamps);
+    }
     if (h->track_profile && h->tp_passes)
         std::fprintf(stderr, "TRACKPROFILE passes %lld  ns per pass: parameters %.0f  launch call %.0f  wait for the row %.0f  fold+solve+pose %.0f\n",
                      h->tp_passes, h->tp_fill / h->tp_passes, h->tp_launch / h->tp_passes, h->tp_wait / h->tp_passes, h->tp_post / h->tp_passes);

@@ -136,7 +136,8 @@ struct PeerExchange {
 };
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
-                               unsigned long long word, unsigned long long pass, const PeerExchange* peers = nullptr);
+                               unsigned long long word, unsigned long long pass, const PeerExchange* peers = nullptr,
+                               unsigned long long* stamps = nullptr /* diagnosis: 8 words per workgroup */);
 // the same exchange for a row that is already in red_dev (tsdf_allreduce): one wavefront; n_sum leading entries are added
 hipError_t launch_peer_exchange(hipStream_t s, const PeerExchange& px, double* red_dev, int n_sum, double* host_row,
                                 unsigned long long host_word);

@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 constexpr int kQCap = 128;                 // entries per queue and wavefront (>= 63 + 64)
 constexpr int kWindowBits = 27;            // voxels per volume window: offsets (index << 4 for colour) stay below 2^31
 constexpr unsigned kDroppedVolumeOffset = 0xfffffff0u;   // beyond every window, also when doubled for the colour array
-constexpr unsigned kHoleVoxel = 0x1ffffffeu;              // queue entry without a voxel (aligned compaction): (x << 3) is out of range
+[[maybe_unused]] constexpr unsigned kHoleVoxel = 0x1ffffffeu;              // queue entry without a voxel (aligned compaction): (x << 3) is out of range
 
 template <bool COLOR> struct QueueEntry { typedef u32x4 T; };     // {voxel, d bits, (float)cosine | biased pixel index, rgb}
 template <> struct QueueEntry<false> { typedef u32x2 T; };        // {voxel, d bits}
@@ -1698,6 +1698,7 @@ struct TrackFold {               // in-launch fan-in of the per-workgroup rows
     unsigned long long word;     // what is released behind host_row once it is complete
     double tag;                  // pass number carried by every row (last column): a stale row cannot pass for a fresh one
     PeerExchange peers;          // n > 0: the finished row is exchanged with the other ranks before it is handed out
+    unsigned long long* stamps = nullptr;   // diagnosis (TSDF_TRACK_STAMPS=1): 8 words per workgroup, s_memrealtime at the phase boundaries
 };
 
 // sc1 (device-scope, L1-bypassing, write-through) accesses for data handed from one workgroup to another inside a
@@ -1789,6 +1790,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's own samples
+    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // p.rpm[9*q] with a per-lane q is a vector load from the kernel-argument segment: a memory round trip in
     // front of the look-ups.  Stage the matrices in LDS while the samples are being classified.
     if (tid < 54) s_rpm[tid] = p.rpm[tid];
@@ -1814,6 +1816,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     }
     __syncthreads();
 
+    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     // ---- phase B: this thread's own sample (group g; no second trip to memory, no second classification) and
     // its look-ups (q and q + 7)
     const int g = tid >> 3, q = tid & 7;
@@ -1880,6 +1883,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         }
     }
 
+    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- the look-ups of this lane (camera_tracking.cpp:269-361): slot A = look-up q (centre, +x -x +y -y +z -z)
     // on lanes 0..6, slot B = look-up 7 + q (r1p r1m r2p r2m r3p r3m) on lanes 0..5
     const bool owned = (cls == kClsIn) && (sg.vx >= (double)p.g.own_x0) && (sg.vx < (double)p.g.own_x1);
@@ -1915,6 +1919,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     const unsigned long long violmask = __ballot(viol != 0u);
     const bool any_viol = ((violmask >> gl) & 0xFFull) != 0ull;
 
+    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     // ---- J[q] on lanes 0..5 of the group, from the +/- partners (float quotient widened, :286,331)
     const float r0 = __shfl(valA, gl);
     const int qa = q < 6 ? q : 0;
@@ -1982,6 +1987,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         if (slot >= 0) store_sc1(&partials[(long long)blockIdx.x * kPartWidth + slot], v);
     }
 
+    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     // ---- in-launch fan-in (no second launch, no host-side fold): every workgroup has written its row write-through;
     // one lane arrives on the counter of its shard (blockIdx % 8: workgroups b and b + 8 share an XCD, so a shard's
     // arrivals stay on one L2 -- speed only, nothing depends on the placement); the workgroup whose arrival completes a
@@ -2004,6 +2010,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         }
     }
     __syncthreads();
+    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     if (s_role == 0) return;
 
     constexpr int RG = kTrackBlock / kPartWidth;                      // row groups of kPartWidth columns
@@ -2057,6 +2064,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             double* slot = fold.host_shards + (size_t)shard * kShardSlotDoubles;
             if (tid < kPartWidth) slot[tid] = shard_v;
             if (tid == 0) __hip_atomic_store(&fold.ctr[32 * shard], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next pass
+            if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
             __threadfence_system();
             if (tid == 0)
                 __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + kPartWidth), fold.word, __ATOMIC_RELEASE,
@@ -2168,7 +2176,7 @@ size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blo
 // before the first pass (the kernel re-zeroes them); shard rows live behind the per-workgroup rows in `partials`.
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
-                               unsigned long long word, unsigned long long pass, const PeerExchange* peers) {
+                               unsigned long long word, unsigned long long pass, const PeerExchange* peers, unsigned long long* stamps) {
     const int nb = track_num_blocks(p.n_samples);
     if (nb <= 0) return hipErrorInvalidValue;
     if (peers && (peers->n < 0 || peers->n > kPeerMaxRanks || host_shards)) return hipErrorInvalidValue;
@@ -2181,6 +2189,7 @@ hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2
     f.word = word;
     f.tag = (double)(pass & 0xFFFFFFFFFFFFull);
     if (peers) f.peers = *peers;
+    f.stamps = stamps;
     track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, f);
     return hipGetLastError();
 }
