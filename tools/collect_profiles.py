@@ -83,7 +83,7 @@ def main():
     with open(os.path.join(out, tag + "_bench.json"), "w") as f:
         json.dump(line, f, indent=1)
     # 3. / 4.
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_memside.py"), out, tag, "--passes=9,10,0,1,2,4,5,6,7"],
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_memside.py"), out, tag, "--passes=9,10,0,1,4,5,6,7"],
                    cwd=ROOT, env=env)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_ta.py"), os.path.join(out, tag + "_pmc_ta_integrate.json")], cwd=ROOT, env=env)
     if os.path.exists(os.path.join(ROOT, "build", "pmc_calibrate")):
