@@ -130,16 +130,16 @@ def surface_samples(s, seq, xyz, m):
 
 
 def test_config5_shapes_1280x960_at_1024():
-    """Config 5's image size against a 1024^3 volume (8 GiB of D/W on one GPU, no colour lanes): counters and
-    samples only -- the volume never leaves the device."""
+    """Config 5's image size against a 1024^3 volume WITH the colour lanes (8 GiB of D/W + 16 GiB of colour on one GPU):
+    counters and samples only -- the volume never leaves the device."""
     import tracking_sdf_amd as ts
     m = 1024
     seq, fr = seq_frames(2, w=1280, h=960, step=3)
-    s = ts.SDF(m, with_color=False)
+    s = ts.SDF(m, with_color=True)
     t = ts.CameraTracking(sdf=s)
     t.set_K(seq.K)
-    st1 = s.update(t, fr[0][0], fr[0][1])
-    st2 = s.update(t, fr[0][0], fr[0][1])
+    st1 = s.update(t, *fr[0])
+    st2 = s.update(t, *fr[0])
     assert st1["n_updated"] == st2["n_updated"] and 0.03 < st1["n_updated"] / m ** 3 < 0.2
     # sample the SDF at the voxel positions of some valid pixels: |value| must be below one truncation distance
     val, ok, smooth = surface_samples(s, seq, fr[0][0], m)
@@ -192,17 +192,18 @@ def test_config4_workload_1024_cubed_with_colour_and_fr3_intrinsics():
 
 
 def test_config5_2048_cubed_on_one_gpu():
-    """BASELINE config 5 is 2048^3 over 8 GPUs; one MI355X (288 GB) holds the 64 GiB of {D,W} by itself, which
-    exercises 64-bit voxel indexing (the reference's int voxel count wraps at m >= 1291, sdf.cpp:9) and the
-    4 M-row work list.  Counters and device-side samples only."""
+    """BASELINE config 5 is 2048^3 over 8 GPUs; one MI355X (288 GB) holds the whole volume by itself -- 64 GiB of {D,W}
+    AND the 128 GiB of colour the reference always updates (sdf.cpp:294-304) -- which exercises 64-bit voxel indexing
+    (the reference's int voxel count wraps at m >= 1291, sdf.cpp:9) and the 4 M-row work list.  Counters and
+    device-side samples only."""
     import tracking_sdf_amd as ts
     m = 2048
     seq, fr = seq_frames(2, w=1280, h=960, step=3)
-    s = ts.SDF(m, with_color=False)
+    s = ts.SDF(m, with_color=True)
     t = ts.CameraTracking(sdf=s)
     t.set_K(seq.K)
-    st1 = s.update(t, fr[0][0], fr[0][1])
-    st2 = s.update(t, fr[0][0], fr[0][1])
+    st1 = s.update(t, *fr[0])
+    st2 = s.update(t, *fr[0])
     assert st1["n_voxels"] == m ** 3 and st1["n_updated"] == st2["n_updated"]
     assert 0.03 < st1["n_updated"] / m ** 3 < 0.2
     val, ok, smooth = surface_samples(s, seq, fr[0][0], m)
