@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Texture-addresser (TA) and L1 (TCP) stall counters of integrate_kernel, ONE counter per rocprofv3 --pmc pass and only
-that kernel profiled (--kernel-include-regex): the four-counter TA group of tools/pmc_memside.py times out on this pool,
+that kernel profiled (--kernel-include-regex; TSDF_INTEGRATE_KERNEL=queue in the environment profiles
+integrate_queue_kernel instead): the four-counter TA group of tools/pmc_memside.py times out on this pool,
 single counters on one kernel take seconds.  Workload: tools/bench_kernels.py (fusion-only integrate launches at the
 ground-truth poses).  Run on the GPU box:   python3 tools/pmc_ta.py out.json
 rocprofv3 gets the program itself after `--`; --pmc is never combined with a trace domain."""
@@ -18,6 +19,7 @@ COUNTERS = ["GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_s
             "TA_TOTAL_WAVEFRONTS_sum", "TA_BUFFER_WAVEFRONTS_sum", "TA_BUFFER_READ_WAVEFRONTS_sum", "TA_BUFFER_WRITE_WAVEFRONTS_sum",
             "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_TA_TCP_STATE_READ_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum",
             "TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]
+KERNEL = "tsdf::integrate_queue_kernel" if os.environ.get("TSDF_INTEGRATE_KERNEL") == "queue" else "tsdf::integrate_kernel"
 CMD = [sys.executable, os.path.join(ROOT, "tools", "bench_kernels.py"), "--frames", "12", "--passes", "2", "--no-track-timing"]
 
 
@@ -29,7 +31,7 @@ def main():
     try:
         for c in COUNTERS:
             d = os.path.join(work, c)
-            cmd = ["rocprofv3", "--pmc", c, "--kernel-include-regex", "tsdf::integrate_kernel", "--output-format", "csv", "-d", d, "--"] + CMD
+            cmd = ["rocprofv3", "--pmc", c, "--kernel-include-regex", KERNEL, "--output-format", "csv", "-d", d, "--"] + CMD
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             except subprocess.TimeoutExpired:
@@ -65,9 +67,9 @@ def main():
         for k, name in (("TA_DATA_STALLED_BY_TC_CYCLES_sum", "ta_waiting_for_data_from_the_L1"), ("TA_ADDR_STALLED_BY_TC_CYCLES_sum", "ta_address_path_blocked_by_the_L1")):
             if g(k) is not None:
                 derived[name + " / ta_busy"] = g(k) / g("TA_TA_BUSY_sum")
-    doc = {"command": "one pass per counter: rocprofv3 --pmc <counter> --kernel-include-regex tsdf::integrate_kernel --output-format csv -- python3 "
+    doc = {"command": "one pass per counter: rocprofv3 --pmc <counter> --kernel-include-regex " + KERNEL + " --output-format csv -- python3 "
                       "tools/bench_kernels.py --frames 12 --passes 2 --no-track-timing   (tools/pmc_ta.py)",
-           "kernel": "tsdf::integrate_kernel<true,true,true,true>, 512^3, 640x480, colour on; values per launch, summed over the chip's instances",
+           "kernel": KERNEL + "<true,true,true,true>, 512^3, 640x480, colour on; values per launch, summed over the chip's instances",
            "counters": res, "derived": derived, "failed_passes": failed}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
