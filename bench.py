@@ -623,8 +623,9 @@ def run(args):
             return best
         if MAIN_MODE == "device":
             extras["value_device_resident_queued"] = args.steps / best_of_two("device_q", None)
-            extras["device_queued_note"] = ("the same HBM-resident frames through tsdf_queue_frame_device / tsdf_next_frame: frame k+1's packing "
-                                            "kernel runs next to frame k's tracker passes instead of in front of frame k+1's")
+            extras["device_queued_note"] = ("the same HBM-resident frames through tsdf_queue_frame_device / tsdf_next_frame: frame k+1 is packed, sample "
+                                            "list included, by workgroups appended to frame k's integrate launch (the plain loop packs frame k there "
+                                            "and reads the first pass's samples from the xyz plane)")
         e2 = best_of_two("host", host_frames)
         extras["value_h2d_inclusive"] = args.steps / e2
         extras["h2d_inclusive_note"] = ("best of two repetitions; xyz + normals + rgb (27 B/pixel) handed over as HOST buffers every frame through "
@@ -774,7 +775,11 @@ def run(args):
         launches = max(1, cn["integrate_calls"])                   # all launches of the timed region (counters)
         timed = max(1, tm["integrate_launches"])                   # the ones bracketed by HIP events (every n-th)
         upd_per_launch = (cn["n_updated"] + cn["n_updated_halo"]) / launches
-        alg_bytes = bpv * upd_per_launch + img_bytes
+        # frames set with tsdf_set_frame_device are packed INSIDE the integrate launch (workgroups appended to
+        # list_rows_kernel): the launch then also reads the three planes once and writes the records once
+        pack_in_launch = tm["pack_launches"] == 0
+        pack_bytes = width * height * ((27 if not args.no_color else 24) + (32 if not args.no_color else 24)) if pack_in_launch else 0
+        alg_bytes = bpv * upd_per_launch + img_bytes + pack_bytes
         avg_ms = tm["integrate_ms"] / timed
         pack_ms = tm["pack_ms"] / max(1, tm["pack_launches"])
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -797,10 +802,17 @@ def run(args):
             "ate_rmse_m": ate, "ate_frames": len(est_main) - 1, "abs_trajectory_rmse_m": raw,
             "gn_iterations_per_frame": cn["track_iterations"] / max(1, cn["track_calls"]),
             "stage_ms_per_frame": {"track_wall": 1e3 * track_wall_main / args.steps,
-                                   "integrate_launch": avg_ms, "pack_kernel": pack_ms},
-            "roofline": {"kernel": "integrate (list_rows_kernel + integrate_kernel, one launch of the two per frame; integrate_kernel is 90 % of the interval)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                   "integrate_launch": avg_ms, "pack_kernel": pack_ms,
+                                   "pack_note": ("no launch of its own: frames set with tsdf_set_frame_device are packed by workgroups "
+                                                 "appended to list_rows_kernel, inside the integrate launch (TSDF_DEFER_PACK=0: as before)")
+                                                if tm["pack_launches"] == 0 else "pack_kernel, one launch per frame"},
+            "roofline": {"kernel": "integrate (list_rows_kernel, whose appended workgroups also pack the frame's pixel records, + integrate_kernel: one launch of the two per frame; integrate_kernel is 88 % of the interval)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_updated_voxel": bpv,
+                         "frac_without_the_packing_bytes": (alg_bytes - pack_bytes) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
+                         "algorithmic_bytes_note": "updated voxels x 48 B + the frame's 32-byte pixel records read once" + (
+                             " + the frame's packing, which runs inside this launch (planes read once, records written once: "
+                             f"{pack_bytes} B)" if pack_in_launch else ""),
                          "updated_voxels_per_launch": upd_per_launch, "avg_launch_ms": avg_ms,
                          "timed_launches": tm["integrate_launches"], "launches": cn["integrate_calls"],
                          "work_items_per_launch": cn["integrate_items"] / launches,

@@ -136,8 +136,11 @@ int tsdf_get_pose(const tsdf_handle *h, double rot[9], double trans[3],
  * tsdf_set_frame copies host images to the device (through pinned staging; page-locked caller buffers -- hipHostMalloc /
  * hipHostRegister -- are copied from directly; either way the buffers are only borrowed for the call).  nrm / rgb may be NULL
  * (tracking needs xyz only; integration needs nrm; rgb is needed only when with_color = 1).
- * tsdf_set_frame_device borrows DEVICE pointers (same layouts) that must stay valid until the next
- * set_frame* call or destroy, and whose contents must be complete when the call is made.
+ * tsdf_set_frame_device borrows DEVICE pointers (same layouts) whose contents must be complete when the call is made.
+ * Nothing is launched by the call: the tracker's first pass reads its samples from the xyz plane and the pixel records
+ * are packed inside the frame's integrate launch (workgroups appended to its first kernel, asynchronous), so the
+ * buffers must stay valid and unchanged until the set_frame* call AFTER the next one, tsdf_synchronize or destroy
+ * (TSDF_DEFER_PACK=0 in the environment of tsdf_create: packed by a launch of its own when the frame is set).
  * The frame-side work of tsdf_set_frame / tsdf_set_depth_frame (staging copies, pre-processing, the packing
  * kernel) runs on an internal second stream, so setting frame k+1 right after tsdf_integrate(k) overlaps it
  * with that integration; the hot calls wait for it on the device. */
@@ -158,9 +161,9 @@ int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm
 int tsdf_queue_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uint8_t *rgb, int32_t width, int32_t height);
 /* The same for a frame that is already in device memory (tsdf_set_frame_device's layouts and borrowing rule: the
  * buffers must be complete when the call is made and stay valid and unchanged until the frame AFTER this one has been
- * made current, or tsdf_synchronize).  Only the packing kernel is left to hide: it runs on the frame stream as soon as
- * the integration of the frame before the current one has released the record buffer, i.e. next to the current
- * frame's tracker passes instead of in front of the next frame's. */
+ * made current, or tsdf_synchronize).  Only the packing is left to hide: the integrate launch of the CURRENT frame
+ * does it, sample list included, in workgroups appended to its first kernel; a queued frame that no integrate launch
+ * came by is taken over unpacked by tsdf_next_frame, exactly like a frame of tsdf_set_frame_device. */
 int tsdf_queue_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb, int32_t width, int32_t height);
 int tsdf_next_frame(tsdf_handle *h);
 /* Number of frames made current so far (every successful tsdf_set_frame* / tsdf_set_depth_frame adds one; -1 for a

@@ -1,0 +1,127 @@
+"""Deferred packing of frames handed over in device memory (tsdf_set_frame_device / tsdf_queue_frame_device).
+
+Nothing is launched when such a frame is set: the tracker's first pass reads its samples from the caller's xyz plane
+(and leaves them in the sample list), and the pixel records are written inside the integrate launch by workgroups
+appended to list_rows_kernel.  Only WHEN the records are written changes -- every pose and every voxel must equal the
+host-plane path (tsdf_set_frame: pack_kernel at once) bit for bit, in every order of calls the C ABI allows.
+TSDF_DEFER_PACK is read by tsdf_create: 0 = pack when the frame is set, 2 = every pass reads the plane."""
+import numpy as np
+import pytest
+
+from tracking_sdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, M, N = 160, 120, 48, 5
+
+
+def frames_on_device(seq, n):
+    import torch
+    out = []
+    for k in range(n):
+        out.append([torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in seq.frame(k)])
+    torch.cuda.synchronize()
+    return out
+
+
+def finish(s, t, poses):
+    D, Wt = s.download()
+    col = s.download_color()
+    s.close()
+    return poses, D, Wt, col
+
+
+def host_loop(n=N, integrate_every=1):
+    """the reference's callback on host planes: pack_kernel runs when the frame is set"""
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=n, width=W, height=H, noise=True, holes=0.02, step=4)
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    poses, ab = [], []
+    for k in range(n):
+        s.set_frame(*seq.frame(k))
+        if k > 0:
+            t.estimate_new_position()
+        if k % integrate_every == 0:
+            s.update()
+        poses.append((t.rot.copy(), t.trans.copy()))
+        ab.append(t.accumulate())                 # one more pass at the final pose, after the integration
+    return finish(s, t, poses) + (ab,)
+
+
+def device_loop(n=N, integrate_every=1):
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=n, width=W, height=H, noise=True, holes=0.02, step=4)
+    fr = frames_on_device(seq, n)
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    poses, ab = [], []
+    for k in range(n):
+        s.set_frame_device(fr[k][0].data_ptr(), fr[k][1].data_ptr(), fr[k][2].data_ptr(), W, H, keep=fr[k])
+        if k > 0:
+            t.estimate_new_position()             # first pass: samples from the plane; later passes: from the list it wrote
+        if k % integrate_every == 0:
+            s.update()                            # records packed inside this launch
+        poses.append((t.rot.copy(), t.trans.copy()))
+        ab.append(t.accumulate())                 # k == 0: the list the packing workgroups wrote (no tracker pass before)
+    return finish(s, t, poses) + (ab,)
+
+
+def assert_same(want, got):
+    for (r0, t0), (r1, t1) in zip(want[0], got[0]):
+        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+    assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2])
+    for a, b in zip(want[3], got[3]):
+        assert np.array_equal(a, b)
+    if len(want) > 4:
+        for (A0, b0, st0), (A1, b1, st1) in zip(want[4], got[4]):
+            assert np.array_equal(A0, A1) and np.array_equal(b0, b1) and st0 == st1
+
+
+@pytest.mark.parametrize("mode", [None, "0", "2"])
+def test_device_frames_equal_host_frames_bit_for_bit(mode, monkeypatch):
+    if mode is None:
+        monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    else:
+        monkeypatch.setenv("TSDF_DEFER_PACK", mode)
+    assert_same(host_loop(), device_loop())
+
+
+def test_frames_that_are_tracked_but_not_integrated(monkeypatch):
+    """a deferred packing that no integrate launch picks up is dropped with the frame; the next frame starts clean"""
+    monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    assert_same(host_loop(integrate_every=2), device_loop(integrate_every=2))
+
+
+def test_queued_device_frames_in_every_order(monkeypatch):
+    """tsdf_queue_frame_device: packed by the CURRENT frame's integrate launch when one comes by (sample list included),
+    otherwise taken over unpacked by tsdf_next_frame like a frame of tsdf_set_frame_device"""
+    import tracking_sdf_amd as ts
+    monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    n = 6
+    want = host_loop(n=n, integrate_every=2)
+    seq = synth.Sequence(n_frames=n, width=W, height=H, noise=True, holes=0.02, step=4)
+    fr = frames_on_device(seq, n)
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    poses, ab = [], []
+
+    def queue(k):
+        s.queue_frame_device(fr[k][0].data_ptr(), fr[k][1].data_ptr(), fr[k][2].data_ptr(), W, H, keep=fr[k])
+    queue(0)
+    for k in range(n):
+        s.next_frame()
+        if k + 1 < n and k % 3 != 2:
+            queue(k + 1)                          # before the hot calls: this frame's integrate launch (if any) packs it
+        if k > 0:
+            t.estimate_new_position()
+        if k % 2 == 0:
+            s.update()
+        if k + 1 < n and k % 3 == 2:
+            queue(k + 1)                          # after them: stays unpacked until it is current
+        poses.append((t.rot.copy(), t.trans.copy()))
+        ab.append(t.accumulate())
+    assert_same(want, finish(s, t, poses) + (ab,))

@@ -450,15 +450,16 @@ class SDF:
         self._queued_keep = None
 
     def set_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
-        """Borrow device pointers (ints, e.g. torch.Tensor.data_ptr()) of images already in HBM."""
-        self._keep = [keep]
+        """Borrow device pointers (ints, e.g. torch.Tensor.data_ptr()) of images already in HBM.  The frame is packed
+        inside its integrate launch (asynchronous), so `keep` is held until the set_frame* call after the next one."""
+        self._keep = getattr(self, "_keep", [])[-1:] + [keep]
         self._check(lib().tsdf_set_frame_device(self._h, C.c_void_p(d_xyz), C.c_void_p(d_normals or 0),
                                                 C.c_void_p(d_rgb or 0), int(width), int(height)))
 
     def queue_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
-        """tsdf_queue_frame_device: queue a frame that is already in HBM (device pointers as ints); its packing kernel
-        runs next to the current frame's tracker passes.  The buffers must stay valid until the frame after this one
-        has been made current (`keep` holds references that long)."""
+        """tsdf_queue_frame_device: queue a frame that is already in HBM (device pointers as ints); the current frame's
+        integrate launch packs it.  The buffers must stay valid until the frame after this one has been made current
+        (`keep` holds references that long)."""
         self._check(lib().tsdf_queue_frame_device(self._h, C.c_void_p(d_xyz), C.c_void_p(d_normals or 0),
                                                   C.c_void_p(d_rgb or 0), int(width), int(height)))
         self._queued_keep_dev = getattr(self, "_queued_keep_dev", [])[-1:] + [keep]

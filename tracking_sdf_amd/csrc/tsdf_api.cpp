@@ -123,6 +123,10 @@ struct tsdf_handle {
     // buffer the current frame does not use while the current one is tracked and integrated
     struct Queued {
         bool active = false, direct = false, device = false, has_nrm = false, has_rgb = false;
+        // device frames with deferred packing: nothing is launched when the frame is queued; the current frame's integrate
+        // launch packs it (packed = true), or it becomes current unpacked like a frame of tsdf_set_frame_device
+        bool deferred = false, packed = false;
+        const float* d_xyz = nullptr; const float* d_nrm = nullptr; const uint8_t* d_rgb = nullptr;
         int nb = 0;
         int32_t su = 1, sv = 0;
         hipError_t err = hipSuccess;       // what the staging thread's HIP calls returned
@@ -165,6 +169,14 @@ struct tsdf_handle {
     bool used_valid[2] = {false, false};
     bool used_untracked[2] = {false, false};   // read by an integration that recorded no event
     bool frame_side = false;                   // the current frame was packed on the frame stream
+    // the current frame's records (pn) and sample list are still to be written: tsdf_set_frame_device leaves the
+    // packing to the integrate launch, and the tracker reads the samples from the xyz plane meanwhile (defer_pack)
+    struct DeferredPack {
+        bool pending = false, samples_listed = false;      // samples_listed: a tracker pass has written the sample list
+        const float* xyz = nullptr; const float* nrm = nullptr; const uint8_t* rgb = nullptr;
+    } deferred;
+    bool deferred_list_samples = true;         // TSDF_DEFER_PACK=2 (diagnosis): every pass reads the plane
+    bool defer_device_pack = true;             // TSDF_DEFER_PACK=0: pack when the frame is set
     float4* pn_buf[2] = {nullptr, nullptr};
     bool integrate_queue = false;  // integrate_queue_kernel (dense batches, TSDF_INTEGRATE_KERNEL=queue) rather than integrate_kernel
     float4* samples_buf[2] = {nullptr, nullptr};
@@ -413,6 +425,17 @@ int wait_buffer_free(tsdf_handle* h, int nb, hipStream_t st) {
     return TSDF_OK;
 }
 
+PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t su, int32_t sv, int nb) {
+    PackArgs a;
+    a.xyz = xyz; a.nrm = nrm; a.rgb = rgb;
+    a.width = h->fw; a.height = h->fh; a.stride = h->cfg.pixel_stride;
+    a.pix_su = su; a.pix_sv = sv;
+    a.pn = h->pn_buf[nb]; a.samples = h->samples_buf[nb];
+    a.ncols = h->ncols; a.nrows = h->nrows;
+    a.color_layout = h->cfg.with_color ? (h->integrate_queue ? 2 : 1) : 0;
+    return a;
+}
+
 // st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
 // overlaps the running integration like they do.  Device-resident inputs pack on the main stream: measured, a
 // pack_kernel squeezed in beside the persistent integrate_kernel slows that one down by as much as it takes.
@@ -426,8 +449,7 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     EventPair* ep;
     int rc = timed_begin(h, 1, &ep, st);
     if (rc) return rc;
-    HIP_TRY(h, launch_pack(st, xyz, nrm, rgb, h->fw, h->fh, h->cfg.pixel_stride, h->pix_su, h->pix_sv,
-                           h->pn_buf[nb], h->samples_buf[nb], h->ncols, h->nrows, h->cfg.with_color ? 1 : 0));
+    HIP_TRY(h, launch_pack(st, pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb)));
     rc = timed_end(h, ep, st);
     if (rc) return rc;
     if (side) {
@@ -439,6 +461,26 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     h->frame_serial++;
     h->frame_has_nrm = nrm != nullptr;
     h->frame_has_rgb = rgb != nullptr;
+    h->deferred = tsdf_handle::DeferredPack();
+    return TSDF_OK;
+}
+
+// A frame handed over in device memory is not packed when it is set: the tracker reads its samples from the xyz plane
+// (TrackParams::xyz_plane) and the pixel records are written inside the integrate launch, by workgroups appended to
+// list_rows_kernel (launch_integrate) -- the packing then hides under that kernel's latency chain instead of being 11 us
+// of its own in front of the first tracker pass.  The borrowing rule of tsdf_set_frame_device (valid until the next
+// set_frame* call) covers it.  TSDF_DEFER_PACK=0: pack at once, as rounds 1-3 did.
+int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb) {
+    choose_pixel_layout(h);
+    const int nb = h->fidx ^ 1;
+    h->frame_side = false;
+    h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
+    h->have_frame = true;
+    h->frame_serial++;
+    h->frame_has_nrm = nrm != nullptr;
+    h->frame_has_rgb = rgb != nullptr;
+    h->deferred = tsdf_handle::DeferredPack();
+    h->deferred.pending = true; h->deferred.xyz = xyz; h->deferred.nrm = nrm; h->deferred.rgb = rgb;
     return TSDF_OK;
 }
 
@@ -559,6 +601,12 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     const auto tp0 = h->track_profile ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     TrackParams p;
     fill_track_params(h, p);
+    // deferred packing: the first pass over the frame reads its samples from the xyz plane and leaves them in the list
+    const bool from_plane = h->deferred.pending && !h->deferred.samples_listed;
+    if (from_plane) {
+        p.xyz_plane = h->deferred.xyz; p.plane_width = h->fw; p.pixel_stride = h->cfg.pixel_stride;
+        p.sample_list_out = h->samples;
+    }
     const bool use_rccl = reduce_ranks && h->comm.active();
     const bool use_peer = reduce_ranks && !use_rccl && h->peer.active();
     const bool use_shm = reduce_ranks && !use_rccl && !use_peer && h->shm.active();
@@ -583,6 +631,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
                                    use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq,
                                    use_peer ? &px : nullptr, h->track_stamps));
+    if (from_plane && h->deferred_list_samples) h->deferred.samples_listed = true;
     const auto tp2 = h->track_profile ? std::chrono::steady_clock::now() : tp0;
     if (h->track_profile) {
         h->tp_fill += std::chrono::duration<double, std::nano>(tp1 - tp0).count();
@@ -903,6 +952,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipHostMalloc((void**)&h->red_host, (kRedWidth + 2) * sizeof(double), hipHostMallocDefault));
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
     { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
+    { const char* ev = std::getenv("TSDF_DEFER_PACK"); h->defer_device_pack = !(ev && std::atoi(ev) == 0); h->deferred_list_samples = !(ev && std::atoi(ev) == 2); }
     { const char* ev = std::getenv("TSDF_HOST_FOLD"); h->host_fold = !(ev && std::atoi(ev) == 0); }
     CREATE_TRY(hipHostMalloc((void**)&h->shard_host, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double), hipHostMallocDefault));
     std::memset(h->shard_host, 0, (size_t)kTrackShards * kShardSlotDoubles * sizeof(double));
@@ -1257,17 +1307,13 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     pick_pixel_layout(h, &q.su, &q.sv);      // from the pose of this moment: only the order of the records depends on it
     rc = wait_buffer_free(h, q.nb, h->fstream);
     if (rc) return rc;
-    float4* const pn = h->pn_buf[q.nb];
-    float4* const smp = h->samples_buf[q.nb];
-    const int32_t stride = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows, with_color = h->cfg.with_color ? 1 : 0;
-    const int32_t su = q.su, sv = q.sv;
+    const PackArgs pa = pack_args(h, h->in_xyz, has_nrm ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, q.su, q.sv, q.nb);
     if (q.direct) {
         HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
         if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
         if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
         HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
-        HIP_TRY(h, launch_pack(h->fstream, h->in_xyz, has_nrm ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, width, height, stride,
-                               su, sv, pn, smp, ncols, nrows, with_color));
+        HIP_TRY(h, launch_pack(h->fstream, pa));
         HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
         q.active = true;
         return TSDF_OK;
@@ -1282,10 +1328,9 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     {
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
-        h->qjob = [h, npix, has_nrm, has_rgb, fill, width, height, stride, su, sv, pn, smp, ncols, nrows, with_color] {
+        h->qjob = [h, npix, has_nrm, has_rgb, fill, pa] {
             hipError_t e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill);
-            if (e == hipSuccess) e = launch_pack(h->fstream, h->in_xyz, has_nrm ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, width, height,
-                                                 stride, su, sv, pn, smp, ncols, nrows, with_color);
+            if (e == hipSuccess) e = launch_pack(h->fstream, pa);
             if (e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
             h->queued.err = e;
         };
@@ -1338,13 +1383,20 @@ int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_n
     if (rc) return rc;
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true; q.err = hipSuccess;
+    q.deferred = q.packed = false;
+    if (h->defer_device_pack) {
+        // no launch now: the integrate launch of the CURRENT frame packs this one in workgroups appended to its
+        // list_rows_kernel (tsdf_integrate), on the main stream, i.e. behind the last reader of the record buffer
+        q.deferred = true; q.d_xyz = d_xyz; q.d_nrm = d_nrm; q.d_rgb = d_rgb;
+        q.active = true;
+        return TSDF_OK;
+    }
     pick_pixel_layout(h, &q.su, &q.sv);
     // the record buffer of the frame before the current one: free once that frame's integration is done -- from then
     // on the pack runs on the frame stream, next to the current frame's tracker passes
     rc = wait_buffer_free(h, q.nb, h->fstream);
     if (rc) return rc;
-    HIP_TRY(h, launch_pack(h->fstream, d_xyz, d_nrm, d_rgb, width, height, h->cfg.pixel_stride, q.su, q.sv, h->pn_buf[q.nb],
-                           h->samples_buf[q.nb], h->ncols, h->nrows, h->cfg.with_color ? 1 : 0));
+    HIP_TRY(h, launch_pack(h->fstream, pack_args(h, d_xyz, d_nrm, d_rgb, q.su, q.sv, q.nb)));
     HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
     q.active = true;
     return TSDF_OK;
@@ -1359,6 +1411,21 @@ int tsdf_next_frame(tsdf_handle* h) {
     q.active = false;
     const bool from_device = q.device;
     q.device = false;
+    if (from_device && q.deferred) {
+        q.deferred = false;
+        h->staged_xyz = false;
+        if (!q.packed) return defer_pack(h, q.d_xyz, q.d_nrm, q.d_rgb);      // no integrate launch came by: as tsdf_set_frame_device
+        // packed inside the previous frame's integrate launch, on the main stream: nothing to wait for
+        h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
+        h->deferred = tsdf_handle::DeferredPack();
+        h->pix_su = q.su; h->pix_sv = q.sv;
+        h->frame_side = false;
+        h->have_frame = true;
+        h->frame_serial++;
+        h->frame_has_nrm = q.has_nrm;
+        h->frame_has_rgb = q.has_rgb;
+        return TSDF_OK;
+    }
     if (from_device) {
         // nothing to wait for on the host: device buffers stay borrowed as tsdf_set_frame_device's do
     } else if (q.direct) {
@@ -1370,6 +1437,7 @@ int tsdf_next_frame(tsdf_handle* h) {
     }
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
     h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
+    h->deferred = tsdf_handle::DeferredPack();
     h->pix_su = q.su; h->pix_sv = q.sv;
     h->frame_side = true;
     h->have_frame = true;
@@ -1388,6 +1456,7 @@ int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm
     rc = ensure_frame_buffers(h, width, height, false);
     if (rc) return rc;
     h->staged_xyz = false;
+    if (h->defer_device_pack) return defer_pack(h, d_xyz, d_nrm, d_rgb);
     return run_pack(h, d_xyz, d_nrm, d_rgb, h->stream);
 }
 
@@ -1550,6 +1619,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     std::memcpy(p.rot_inv_trans, h->pose.rot_inv_trans, sizeof p.rot_inv_trans);
     std::memcpy(p.K, h->K, sizeof p.K);
     p.width = h->fw; p.height = h->fh;
+    if (h->deferred.pending) choose_pixel_layout(h);      // the records are written in this launch: lay them out for the pose they are read at
     p.pix_su = h->pix_su; p.pix_sv = h->pix_sv;
     p.with_color = h->cfg.with_color;
     p.debug = h->integrate_debug;
@@ -1562,8 +1632,32 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     EventPair* ep;
     rc = timed_begin(h, 0, &ep, h->stream);
     if (rc) return rc;
+    // Deferred packing: one frame's records can be written inside this launch (workgroups appended to list_rows_kernel).
+    // A queued device frame goes first -- that is the packing of the NEXT frame, sample list included, hidden under this
+    // frame's list kernel; the current frame's own records then need a launch in front (the first frame of a stream only).
+    PackArgs pa;
+    bool fused = false;
+    tsdf_handle::Queued& q = h->queued;
+    if (q.active && q.device && q.deferred && !q.packed) {
+        if (h->deferred.pending) {
+            PackArgs own = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
+            if (h->deferred.samples_listed) own.samples = nullptr;
+            HIP_TRY(h, launch_pack(h->stream, own));
+            h->deferred.pending = false;
+        }
+        q.su = h->pix_su; q.sv = h->pix_sv;      // laid out for this frame's pose: the next one's is close to it
+        pa = pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, q.nb);
+        q.packed = true;
+        fused = true;
+    } else if (h->deferred.pending) {
+        pa = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
+        if (h->deferred.samples_listed) pa.samples = nullptr;     // a tracker pass has written them already
+        fused = true;
+    }
     HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                                h->integrate_blocks, h->integrate_launches++, h->wg_counts, h->integrate_queue));
+                                h->integrate_blocks, h->integrate_launches++, h->wg_counts, h->integrate_queue,
+                                fused ? &pa : nullptr));
+    h->deferred.pending = false;             // records and sample list of the current frame are complete from here on
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
     if (h->frame_side) {     // the next-but-one pack (on the frame stream) may overwrite this buffer after this launch

@@ -82,6 +82,22 @@ struct TrackParams {
     int32_t stale_carry;
     int32_t carry_threads;   // >= 1: OpenMP threads of the reference run whose carry resets are reproduced
     int32_t ncols, nrows;    // sample grid: sample n = col * nrows + row (columns outer, camera_tracking.cpp:162-163)
+    // non-null: the frame's packing is deferred (tsdf_set_frame_device) and the samples are read from the caller's
+    // xyz plane: sample (col, row) = pixel (col * pixel_stride, row * pixel_stride) of a plane_width-wide image
+    const float* xyz_plane = nullptr;
+    int32_t plane_width = 0, pixel_stride = 1;
+    float4* sample_list_out = nullptr;   // with xyz_plane: every workgroup also writes its own samples here (for the later passes)
+};
+
+// What pack_kernel needs: the frame's planes (device memory; nrm / rgb may be null) and where the packed records go.
+struct PackArgs {
+    const float* xyz = nullptr; const float* nrm = nullptr; const uint8_t* rgb = nullptr;
+    int32_t width = 0, height = 0, stride = 1;
+    int32_t pix_su = 0, pix_sv = 0;       // record index of pixel (col,row) = col*pix_su + row*pix_sv
+    float4* pn = nullptr;                 // kPixelBufferBytes per pixel
+    float4* samples = nullptr;            // ncols x nrows tracker samples (null: not written)
+    int32_t ncols = 0, nrows = 0;
+    int32_t color_layout = 0;             // 0: 24-byte {P,N} records; 1: 32-byte records (volume with colour); 2: + the f64 cosine plane (integrate_queue_kernel)
 };
 
 // mesh extraction (mesh_kernels.hip): cubes with base voxel layer i in [ci0, ci1), j,k in [1, m-2]
@@ -96,10 +112,7 @@ struct MeshParams {
 enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntItems = 2, kCntOverflowItems = 3, kNumCounters = 4 };
 
 hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0);
-hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
-                       int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
-                       float4* pn, float4* samples, int32_t ncols, int32_t nrows,
-                       int32_t color_layout /* 1: 32-byte records + f64 cosine plane (volume with colour), 0: 24-byte {P,N} records */);   // pn: kPixelBufferBytes per pixel
+hipError_t launch_pack(hipStream_t s, const PackArgs& a);
 // worklist: integrate_worklist_bytes(g) bytes, zero before the first launch; work_count:
 // integrate_bookkeeping_words() unsigned, zero before the first launch; n_blocks: persistent grid size (CUs x
 // integrate_blocks_per_cu(), a multiple of 8).
@@ -114,7 +127,8 @@ bool integrate_queue_fits(const Grid& g);
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             void* worklist, unsigned* work_count, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */, bool queue);
+                            unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */, bool queue,
+                            const PackArgs* pack = nullptr /* the frame's records are still to be packed: done inside this launch */);
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit

@@ -75,15 +75,16 @@ hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, f
 // (measured: 0.6 ms of L2->L1 line traffic per 512^3 frame, the v1 bottleneck).  The tracker's sample list is
 // written in the reference's visiting order: columns outer, rows inner, both with `stride`.
 
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz, const float* __restrict__ nrm,
-                                                    const uint8_t* __restrict__ rgb, int width, int height,
-                                                    int stride, int pix_su, int pix_sv, float4* __restrict__ pn,
-                                                    float4* __restrict__ samples, int ncols, int nrows, int color_layout) {
-    // 16 x 16 pixel tiles; consecutive threads follow the direction in which the records are contiguous, so a
-    // wavefront writes four runs of 512 bytes whichever layout is chosen (the plane reads of a tile stay within
+__device__ __forceinline__ void pack_tile(const PackArgs& a_, int tile) {
+    const float* __restrict__ xyz = a_.xyz; const float* __restrict__ nrm = a_.nrm; const uint8_t* __restrict__ rgb = a_.rgb;
+    const int width = a_.width, height = a_.height, stride = a_.stride, pix_su = a_.pix_su, pix_sv = a_.pix_sv;
+    float4* __restrict__ pn = a_.pn; float4* __restrict__ samples = a_.samples;
+    const int ncols = a_.ncols, nrows = a_.nrows, color_layout = a_.color_layout;
+    // 16 x 16 pixel tiles (256 threads); consecutive threads follow the direction in which the records are contiguous,
+    // so a wavefront writes four runs of 512 bytes whichever layout is chosen (the plane reads of a tile stay within
     // a few cache lines per image row either way)
     const int tiles_x = (width + 15) >> 4;
-    const int tx0 = (blockIdx.x % tiles_x) << 4, ty0 = (blockIdx.x / tiles_x) << 4;
+    const int tx0 = (tile % tiles_x) << 4, ty0 = (tile / tiles_x) << 4;
     const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
     const int col = tx0 + (pix_sv == 1 ? a : b), row = ty0 + (pix_sv == 1 ? b : a);
     if (col >= width || row >= height) return;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
         pn[2 * rec + 1] = make_float4(nx, ny, nz, (float)cosine);
         // ... and the f64 value itself goes to a plane behind the records (8 bytes per pixel, same record index): the
         // queue kernel gathers it for DENSE batches of exp()-band voxels only (one 8-byte gather per 64 band voxels)
-        reinterpret_cast<double*>(pn + 2 * (size_t)width * height)[rec] = cosine;
+        if (color_layout == 2) reinterpret_cast<double*>(pn + 2 * (size_t)width * height)[rec] = cosine;
     } else {
         // without colour: 24-byte records {Px,Py,Pz, Nx,Ny,Nz} (a quarter fewer cache lines per gathered pixel run)
         float* const r6 = reinterpret_cast<float*>(pn) + rec * 6;
@@ -113,16 +114,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ xyz
     }
     if (col % stride == 0 && row % stride == 0) {
         const int ci = col / stride, rj = row / stride;
-        if (ci < ncols && rj < nrows) samples[ci * nrows + rj] = make_float4(px, py, pz, 0.0f);
+        if (samples && ci < ncols && rj < nrows) samples[ci * nrows + rj] = make_float4(px, py, pz, 0.0f);
     }
 }
 
-hipError_t launch_pack(hipStream_t s, const float* xyz, const float* nrm, const uint8_t* rgb,
-                       int32_t width, int32_t height, int32_t stride, int32_t pix_su, int32_t pix_sv,
-                       float4* pn, float4* samples, int32_t ncols, int32_t nrows, int32_t color_layout) {
-    const int tiles = ((width + 15) >> 4) * ((height + 15) >> 4);
-    pack_kernel<<<dim3(tiles), dim3(256), 0, s>>>(xyz, nrm, rgb, width, height, stride, pix_su, pix_sv, pn,
-                                                   samples, ncols, nrows, color_layout);
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) { pack_tile(a, (int)blockIdx.x); }
+
+static int pack_tiles(const PackArgs& a) { return ((a.width + 15) >> 4) * ((a.height + 15) >> 4); }
+
+hipError_t launch_pack(hipStream_t s, const PackArgs& a) {
+    pack_kernel<<<dim3(pack_tiles(a)), dim3(256), 0, s>>>(a);
     return hipGetLastError();
 }
 
@@ -261,13 +262,21 @@ static_assert(sizeof(ItemDesc) == 32, "one s_load_dwordx8 per item");
 // 1.2 MB) then live in that XCD's L2: with the list in row order every XCD gathered from the whole image, and 63 % of
 // the launch's fabric reads were pixel records fetched again and again (296 MB for a 9.8 MB image).  The order inside a
 // band is whatever the atomics give -- every voxel belongs to exactly one item, so no result depends on it.
+//
+// Deferred frame packing (round 4): the workgroups behind the list's own (blockIdx >= list_blocks) write the frame's pixel
+// records (pack_tile) -- for frames handed over in device memory the tracker reads its samples straight from the xyz
+// plane, so nothing needs the records before integrate_kernel and the packing hides under this kernel's latency
+// chain (one thread per row, three barriers, two atomic round trips) instead of being a launch of its own.
+static_assert(kClipBlock == 256, "pack_tile works on 256-thread workgroups");
 __global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p, IntegrateTiling tl,
                                                                 unsigned* __restrict__ set, ItemDesc* __restrict__ list,
-                                                                unsigned ovf_base, unsigned* __restrict__ xcd_fb) {
+                                                                unsigned ovf_base, unsigned* __restrict__ xcd_fb,
+                                                                unsigned list_blocks, PackArgs pack) {
+    if (blockIdx.x >= list_blocks) { pack_tile(pack, (int)(blockIdx.x - list_blocks)); return; }
     const int m = p.g.m;
     const int tid = threadIdx.x;
     const long long row = (long long)blockIdx.x * kClipBlock + tid;
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) update_xcd_shares(xcd_fb);   // (the last launch's integrate kernel is done: same stream)
+    if (blockIdx.x == list_blocks - 1 && tid == 0) update_xcd_shares(xcd_fb);   // (the last launch's integrate kernel is done: same stream)
     __shared__ unsigned s_wg[kBins], s_dest[kBins];
     for (int t = tid; t < kBins; t += kClipBlock) s_wg[t] = 0u;
     __syncthreads();
@@ -430,8 +439,10 @@ __device__ __forceinline__ double exp_taylor8(double x) {
 //   * the four f32 divisions of the running averages (one for D, three for the colour) run two at a time as packed
 //     f32 operations with the division's own FMA sequence (exactly the instruction sequence hipcc emits for
 //     a correctly rounded `/`, minus the range scaling, which a guard proves unnecessary or else takes the `/` path);
-//   * the f64 cosine of the colour weight rides in a per-pixel plane written by pack_kernel, so the exp() band costs
-//     three instructions instead of a square root and a division in f64.
+//   * the pre-rounded (float)cosine of the colour weight rides in the pixel record (weight-1 voxels use it as it is);
+//     a wavefront with lanes in the exp() band recomputes the f64 cosine from the record's normal for those lanes
+//     (a per-pixel plane of f64 cosines gathered per item was measured twice and lost both times: one more
+//     vector-memory instruction per item; integrate_queue_kernel gathers it once per 64 band voxels instead).
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -446,7 +457,8 @@ constexpr int kRsrcWord3 = 0x00020000;               // raw buffer, 32-bit data 
 
 // Per-pixel data of a frame, written by pack_kernel into ONE buffer of kPixelBufferBytes per pixel (record index
 // rec = col*pix_su + row*pix_sv):  with colour  [0, 32 npix) records {Px,Py,Pz,rgb}{Nx,Ny,Nz,(float)cosine}, then
-// [32 npix, 40 npix) the f64 cosines;  without colour  [0, 24 npix) records {Px,Py,Pz,Nx,Ny,Nz}.
+// [32 npix, 40 npix) the f64 cosines (written only for integrate_queue_kernel);  without colour  [0, 24 npix) records
+// {Px,Py,Pz,Nx,Ny,Nz}.
 static_assert(kPixelRecordBytes == 32 && kPixelBufferBytes == 40, "pixel records + f64 cosine plane");
 
 // v_cvt_i32_f64 as the hardware does it (saturating, NaN -> 0); a C cast of an out-of-range value is undefined
@@ -1438,7 +1450,7 @@ static bool use_exp_poly(const IntegrateParams& p) {
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             void* worklist, unsigned* work_count, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts, bool queue) {
+                            unsigned launch_parity, unsigned long long* wg_counts, bool queue, const PackArgs* pack) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
@@ -1453,7 +1465,11 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
     const unsigned ovf_base = (unsigned)integrate_worklist_entries(p.g);       // band regions in the first half of the list
-    list_rows_kernel<<<dim3((unsigned)cblocks), dim3(kClipBlock), 0, s>>>(p, tl, cur, list, ovf_base, xcd_fb);
+    // (pack: the frame's pixel records are still to be written -- workgroups behind the list's own do it, see the kernel)
+    const PackArgs no_pack{};
+    const unsigned ptiles = pack ? (unsigned)pack_tiles(*pack) : 0u;
+    list_rows_kernel<<<dim3((unsigned)cblocks + ptiles), dim3(kClipBlock), 0, s>>>(p, tl, cur, list, ovf_base, xcd_fb,
+                                                                                   (unsigned)cblocks, pack ? *pack : no_pack);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     const bool exp_poly = use_exp_poly(p);
@@ -1658,9 +1674,21 @@ __device__ __forceinline__ int classify_sample(const TrackParams& p, const float
     return kClsIn;
 }
 
+// Sample n of the reference's visiting order (columns outer, rows inner, both with the pixel stride): from the list
+// pack_kernel wrote, or -- frames handed over in device memory, whose packing is deferred to the integrate launch --
+// straight from the caller's xyz plane (three 4-byte loads; workgroup-uniform choice).
+__device__ __forceinline__ float4 load_sample(const TrackParams& p, const float4* __restrict__ samples, int n) {
+    if (p.xyz_plane) {
+        const int ci = n / p.nrows, rj = n - ci * p.nrows;
+        const float* __restrict__ s = p.xyz_plane + 3 * ((size_t)(rj * p.pixel_stride) * (size_t)p.plane_width + (size_t)(ci * p.pixel_stride));
+        return make_float4(s[0], s[1], s[2], 0.0f);
+    }
+    return samples[n];
+}
+
 __device__ __forceinline__ int classify(const TrackParams& p, const float4* __restrict__ samples, int n, SampleGeom& sg) {
     const bool exists = n < p.n_samples;
-    const float4 s = exists ? samples[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 s = exists ? load_sample(p, samples, n) : make_float4(0.f, 0.f, 0.f, 0.f);
     return classify_sample(p, s, exists, sg);
 }
 
@@ -1803,8 +1831,11 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     if (wv == 0) {
         SampleGeom win;
         const bool exists = base + lane < p.n_samples;
-        const float4 smp = exists ? samples[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 smp = exists ? load_sample(p, samples, base + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int wcls = classify_sample(p, smp, exists, win);
+        // first pass over a frame whose packing is deferred: leave the own samples in the list for the passes after it
+        // (a plane read is one cold line per lane, 23 KB apart; the list is 16 contiguous bytes per sample)
+        if (p.xyz_plane && p.sample_list_out && exists && lane < kSamplesPerBlock) p.sample_list_out[base + lane] = smp;
         if (lane < kSamplesPerBlock) {
             s_geom[lane][0] = win.px; s_geom[lane][1] = win.py; s_geom[lane][2] = win.pz;
             s_geom[lane][3] = win.vx; s_geom[lane][4] = win.vy; s_geom[lane][5] = win.vz;
