@@ -78,8 +78,8 @@ def parse(argv=None):
                          "auto = self-test and time all three, keep the fastest")
     ap.add_argument("--frame-queue", action="store_true",
                     help="queue the HBM-resident frame k+1 (tsdf_queue_frame_device) while frame k is processed instead of setting "
-                         "every frame in front of its own tracker passes (measured: no gain, the packing kernel slows the tracker "
-                         "passes it runs next to by what it saves)")
+                         "every frame in front of its own tracker passes: frame k+1 is then packed, sample list included, inside frame k's "
+                         "integrate launch")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--timing-period", type=int, default=4, help="HIP events around every n-th integrate/pack launch")

@@ -147,7 +147,12 @@ struct tsdf_handle {
     int32_t pix_su = 1, pix_sv = 0;   // layout of the packed pixel records of the current frame
     bool have_frame = false, frame_has_nrm = false, frame_has_rgb = false;
     float* in_xyz = nullptr; float* in_nrm = nullptr; uint8_t* in_rgb = nullptr;   // device staging (owned)
-    float* pin_xyz = nullptr; float* pin_nrm = nullptr; uint8_t* pin_rgb = nullptr;  // pinned host staging
+    float* pin_xyz = nullptr; float* pin_nrm = nullptr; uint8_t* pin_rgb = nullptr;  // pinned host staging (the set in use)
+    // second staging set of the frame queue's pageable path: frame k+1 is filled into one set while the DMA engine still
+    // reads frame k from the other (with one set the caller's thread waited for those copies before every queue call)
+    float* alt_xyz = nullptr; float* alt_nrm = nullptr; uint8_t* alt_rgb = nullptr; size_t alt_cap = 0;
+    hipEvent_t ev_stage_done[2] = {nullptr, nullptr};   // [0]: the copies out of the set in use have been issued up to here; [1]: the other set's
+    bool stage_recorded[2] = {false, false};
     size_t in_cap = 0;             // pixels the staging buffers hold
     bool staged_xyz = false;       // in_xyz (and in_rgb, if frame_has_rgb) hold the CURRENT frame (host / AoS / depth frames)
     std::unique_ptr<HostPool> pool;   // staging threads, started by the first pageable frame (TSDF_HOST_THREADS, default: usable cores - 2, at most 12)
@@ -198,6 +203,18 @@ struct tsdf_handle {
     // for the row, fold + solve + pose)
     bool track_profile = false;
     double tp_fill = 0, tp_launch = 0, tp_wait = 0, tp_post = 0; long long tp_passes = 0;
+    // TSDF_STAGE_PROFILE=1: host-side clock of the pageable-frame staging (ns sums per staged frame, printed by tsdf_destroy)
+    struct StageProfile {
+        bool on = false;
+        long long frames = 0;
+        double total = 0;        // stage_and_upload, first call to return
+        double fill_max = 0;     // the slowest worker's filling time (sum over chunks)
+        double first_chunk = 0;  // until the first chunk was complete
+        double upload_calls = 0; // inside hipMemcpyAsync
+        double sync_before = 0;  // queue_frame: waiting for the previous frame's copies to leave the staging planes
+        double next_wait = 0;    // tsdf_next_frame: waiting for the staging thread
+        double handoff = 0;      // queue call -> the staging thread starts the job
+    } sp;
 
     // comm
     rccl::Comm comm;
@@ -294,15 +311,19 @@ void free_preproc(tsdf_handle* h) {
     h->pre_minmax = h->pin_minmax = nullptr;
 }
 
+// layout of a frame block: xyz plane, nrm plane (each padded to 256 bytes), rgb plane
+inline size_t plane_stride_bytes(size_t npix) { return (npix * 3 * sizeof(float) + 255) & ~(size_t)255; }
+inline size_t frame_block_bytes(size_t npix) { return 2 * plane_stride_bytes(npix) + npix * 3; }
+
 void free_frame(tsdf_handle* h) {
+    // (xyz | nrm | rgb live in ONE block each: the xyz pointer is the block)
     if (h->in_xyz) (void)hipFree(h->in_xyz);
-    if (h->in_nrm) (void)hipFree(h->in_nrm);
-    if (h->in_rgb) (void)hipFree(h->in_rgb);
     if (h->pin_xyz) (void)hipHostFree(h->pin_xyz);
-    if (h->pin_nrm) (void)hipHostFree(h->pin_nrm);
-    if (h->pin_rgb) (void)hipHostFree(h->pin_rgb);
+    if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
     h->in_xyz = h->in_nrm = nullptr; h->in_rgb = nullptr;
     h->pin_xyz = h->pin_nrm = nullptr; h->pin_rgb = nullptr;
+    h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
+    h->stage_recorded[0] = h->stage_recorded[1] = false;
     h->in_cap = 0;
 }
 
@@ -339,12 +360,15 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
     }
     if (need_staging && npix > h->in_cap) {
         free_frame(h);
-        HIP_TRY(h, hipMalloc((void**)&h->in_xyz, npix * 3 * sizeof(float)));
-        HIP_TRY(h, hipMalloc((void**)&h->in_nrm, npix * 3 * sizeof(float)));
-        HIP_TRY(h, hipMalloc((void**)&h->in_rgb, npix * 3));
-        HIP_TRY(h, hipHostMalloc((void**)&h->pin_xyz, npix * 3 * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(h, hipHostMalloc((void**)&h->pin_nrm, npix * 3 * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(h, hipHostMalloc((void**)&h->pin_rgb, npix * 3, hipHostMallocDefault));
+        // the three planes of a frame in ONE block, on the device and in the pinned staging set alike: a staged frame is
+        // then ONE host-to-device copy (measured: the copies of a 640x480 frame are bound by their number, not their
+        // bytes -- 12 copies per frame 3450 frames/s from PCL clouds, 3 copies 4140)
+        const size_t plane = plane_stride_bytes(npix);
+        char* dev = nullptr; char* pin = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&dev, frame_block_bytes(npix)));
+        h->in_xyz = reinterpret_cast<float*>(dev); h->in_nrm = reinterpret_cast<float*>(dev + plane); h->in_rgb = reinterpret_cast<uint8_t*>(dev + 2 * plane);
+        HIP_TRY(h, hipHostMalloc((void**)&pin, frame_block_bytes(npix), hipHostMallocDefault));
+        h->pin_xyz = reinterpret_cast<float*>(pin); h->pin_nrm = reinterpret_cast<float*>(pin + plane); h->pin_rgb = reinterpret_cast<uint8_t*>(pin + 2 * plane);
         h->in_cap = npix;
     }
     h->fw = w; h->fh = hh; h->ncols = ncols; h->nrows = nrows; h->n_samples = (int32_t)ns;
@@ -912,6 +936,8 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_queued, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[0], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[1], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
@@ -963,6 +989,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
           CREATE_TRY(hipMemsetAsync(h->track_stamps, 0, 8 * 4096 * sizeof(unsigned long long), h->stream));
       } }
     { const char* ev = std::getenv("TSDF_TRACK_PROFILE"); h->track_profile = ev && std::atoi(ev) != 0; }
+    { const char* ev = std::getenv("TSDF_STAGE_PROFILE"); h->sp.on = ev && std::atoi(ev) != 0; }
     CREATE_TRY(hipMalloc((void**)&h->fold_ctr, track_fold_counter_words() * sizeof(unsigned)));
     CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, track_fold_counter_words() * sizeof(unsigned), h->stream));
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
@@ -998,6 +1025,14 @@ void tsdf_destroy(tsdf_handle* h) {
         }
         (void)hipFree(h->track_stamps);
     }
+    if (h->sp.on && h->sp.frames) {
+        const double f = (double)h->sp.frames * 1e3;
+        std::fprintf(stderr, "STAGE_PROFILE frames %lld  us per frame: staging call %.1f  slowest worker's filling %.1f  first chunk ready %.1f  "
+                             "inside hipMemcpyAsync %.1f  wait for the planes (previous copies) %.1f  hand-off to the staging thread %.1f  "
+                             "tsdf_next_frame waits %.1f  workers %d\n",
+                     h->sp.frames, h->sp.total / f, h->sp.fill_max / f, h->sp.first_chunk / f, h->sp.upload_calls / f, h->sp.sync_before / f,
+                     h->sp.handoff / f, h->sp.next_wait / f, h->pool ? h->pool->parts() - 1 : 0);
+    }
     if (h->track_profile && h->tp_passes)
         std::fprintf(stderr, "TRACKPROFILE passes %lld  ns per pass: parameters %.0f  launch call %.0f  wait for the row %.0f  fold+solve+pose %.0f\n",
                      h->tp_passes, h->tp_fill / h->tp_passes, h->tp_launch / h->tp_passes, h->tp_wait / h->tp_passes, h->tp_post / h->tp_passes);
@@ -1025,6 +1060,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
     if (h->ev_queued) (void)hipEventDestroy(h->ev_queued);
+    for (int b = 0; b < 2; ++b) if (h->ev_stage_done[b]) (void)hipEventDestroy(h->ev_stage_done[b]);
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
@@ -1189,26 +1225,42 @@ HostPool* host_pool(tsdf_handle* h) {
         int n = cores - 2 < 12 ? cores - 2 : 12;
         if (const char* e = std::getenv("TSDF_HOST_THREADS")) n = std::atoi(e);
         if (n > cores) n = cores;
-        n = n < 1 ? 1 : n > 16 ? 16 : n;
+        n = n < 1 ? 1 : n > 64 ? 64 : n;
         h->pool.reset(new (std::nothrow) HostPool(n - 1));
     }
     return h->pool.get();
 }
 
-// Pageable frame -> pinned staging -> HBM, pipelined: the pixels are cut into chunks; the pool's workers fill chunk
-// after chunk of the pinned planes (fill(i0, i1) writes pixels [i0, i1)), the calling thread issues the H2D copies of a
-// chunk the moment its last worker is done, so the DMA of chunk c runs while chunk c+1 is being filled (filling and
-// copying one after the other put both on the critical path of the frame: the tracker waits for the upload).
+// Pageable frame -> pinned staging -> HBM: the pool's workers fill the pinned planes (fill(i0, i1) writes pixels
+// [i0, i1)), the calling thread issues the H2D copy.  Rounds 2-3 cut the frame into 4 chunks so that the DMA of chunk c
+// ran while chunk c+1 was being filled; round 4 measured what that costs: a 640x480 frame's copies are bound by their
+// NUMBER (~15-20 us each whatever the size), so 12 copies per frame lose more than the overlap wins (PCL clouds through
+// the queue: 8 chunks 2490 frames/s, 4 chunks 3450, 2 chunks 4010, 1 chunk = 3 copies 4140).  Default now: one chunk,
+// and the three planes in one block = ONE copy per frame.  TSDF_STAGE_CHUNKS keeps the pipelined form for large images.
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
                             const std::function<void(size_t, size_t)>& fill) {
-    constexpr int kChunks = 4;
-    std::atomic<int> done[kChunks];
+    constexpr int kMaxChunks = 16;
+    static const int kChunks = [] { const char* e = std::getenv("TSDF_STAGE_CHUNKS"); const int n = e ? std::atoi(e) : 1; return n < 1 ? 1 : n > kMaxChunks ? kMaxChunks : n; }();
+    std::atomic<int> done[kMaxChunks];
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     hipError_t err = hipSuccess;
-    auto chunk_lo = [npix](int c) { return npix * (size_t)c / kChunks; };
+    using clk = std::chrono::steady_clock;
+    const bool prof = h->sp.on;
+    const clk::time_point t_begin = prof ? clk::now() : clk::time_point();
+    std::atomic<long long> fill_ns_max{0};
+    double upload_ns = 0, first_ns = 0;
+    auto chunk_lo = [npix](int c) { return npix * (size_t)c / (size_t)kChunks; };
     auto upload = [&](int c) {
         const size_t i0 = chunk_lo(c), n = chunk_lo(c + 1) - i0;
         if (!n || err != hipSuccess) return;
+        const clk::time_point tu = prof ? clk::now() : clk::time_point();
+        if (prof && c == 0) first_ns = std::chrono::duration<double, std::nano>(tu - t_begin).count();
+        struct Tail { const bool on; const clk::time_point t0; double& acc; ~Tail() { if (on) acc += std::chrono::duration<double, std::nano>(clk::now() - t0).count(); } } tail{prof, tu, upload_ns};
+        if (kChunks == 1 && has_xyz && has_nrm) {            // the whole frame: the planes are neighbours in both blocks -> one copy
+            const size_t bytes = has_rgb ? frame_block_bytes(h->in_cap) - (h->in_cap - npix) * 3 : 2 * plane_stride_bytes(h->in_cap);
+            err = hipMemcpyAsync(h->in_xyz, h->pin_xyz, bytes, hipMemcpyHostToDevice, h->fstream);
+            return;
+        }
         if (has_xyz) err = hipMemcpyAsync(h->in_xyz + 3 * i0, h->pin_xyz + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
         if (has_nrm && err == hipSuccess) err = hipMemcpyAsync(h->in_nrm + 3 * i0, h->pin_nrm + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
         if (has_rgb && err == hipSuccess) err = hipMemcpyAsync(h->in_rgb + 3 * i0, h->pin_rgb + 3 * i0, n * 3, hipMemcpyHostToDevice, h->fstream);
@@ -1224,14 +1276,25 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
             }
         } else {
             const size_t wk = (size_t)(part - 1), nw = (size_t)(parts - 1);
+            long long mine = 0;
             for (int c = 0; c < kChunks; ++c) {
                 const size_t c0 = chunk_lo(c), n = chunk_lo(c + 1) - c0;
+                const clk::time_point tf = prof ? clk::now() : clk::time_point();
                 fill(c0 + n * wk / nw, c0 + n * (wk + 1) / nw);
+                if (prof) mine += std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tf).count();
                 done[c].fetch_add(1, std::memory_order_release);
             }
+            if (prof) { long long cur = fill_ns_max.load(); while (mine > cur && !fill_ns_max.compare_exchange_weak(cur, mine)) {} }
         }
     };
     if (pool) pool->run(job); else job(0, 1);
+    if (prof) {
+        h->sp.frames++;
+        h->sp.total += std::chrono::duration<double, std::nano>(clk::now() - t_begin).count();
+        h->sp.fill_max += (double)fill_ns_max.load();
+        h->sp.first_chunk += first_ns;
+        h->sp.upload_calls += upload_ns;
+    }
     return err;
 }
 }  // namespace
@@ -1318,9 +1381,26 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
         q.active = true;
         return TSDF_OK;
     }
-    // pageable buffers: the pinned staging planes must be free (they may still feed the previous frame's copies), then a
-    // library thread fills them (with the staging pool) and issues copies and pack while the caller goes on
-    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    // pageable buffers: a library thread fills pinned staging planes (with the staging pool) and issues copies and pack
+    // while the caller goes on.  Two sets of staging planes alternate: the one that is filled now last fed the copies of
+    // the frame before the current one, and the library thread, not the caller, waits for those if it has to.
+    if (h->alt_cap < npix) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
+        h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
+        // the same block layout as the first set and the device block: sized like them (in_cap pixels)
+        const size_t plane = plane_stride_bytes(h->in_cap);
+        char* pin = nullptr;
+        HIP_TRY(h, hipHostMalloc((void**)&pin, frame_block_bytes(h->in_cap), hipHostMallocDefault));
+        h->alt_xyz = reinterpret_cast<float*>(pin); h->alt_nrm = reinterpret_cast<float*>(pin + plane); h->alt_rgb = reinterpret_cast<uint8_t*>(pin + 2 * plane);
+        h->alt_cap = h->in_cap;
+        h->stage_recorded[0] = h->stage_recorded[1] = false;
+    }
+    {   // TSDF_STAGE_SETS=1 (diagnosis): wait here, on the caller's thread, as the single staging set of round 3 made it do
+        static const bool one_set = [] { const char* e = std::getenv("TSDF_STAGE_SETS"); return e && std::atoi(e) == 1; }();
+        if (one_set) HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    }
+    const auto t_queued = std::chrono::steady_clock::now();
     if (!h->qthread.joinable()) {
         try { h->qthread = std::thread(queue_thread_main, h); }
         catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_frame: cannot start the staging thread"); }
@@ -1328,8 +1408,16 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     {
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
-        h->qjob = [h, npix, has_nrm, has_rgb, fill, pa] {
-            hipError_t e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill);
+        h->qjob = [h, npix, has_nrm, has_rgb, fill, pa, t_queued] {
+            const auto ts0 = std::chrono::steady_clock::now();
+            if (h->sp.on) h->sp.handoff += std::chrono::duration<double, std::nano>(ts0 - t_queued).count();
+            // switch to the other staging set (fill and stage_and_upload read h->pin_* when they run)
+            std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
+            std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
+            hipError_t e = h->stage_recorded[0] ? hipEventSynchronize(h->ev_stage_done[0]) : hipSuccess;
+            if (h->sp.on) h->sp.sync_before += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ts0).count();
+            if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill);
+            if (e == hipSuccess) { e = hipEventRecord(h->ev_stage_done[0], h->fstream); h->stage_recorded[0] = e == hipSuccess; }
             if (e == hipSuccess) e = launch_pack(h->fstream, pa);
             if (e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
             h->queued.err = e;
@@ -1431,8 +1519,10 @@ int tsdf_next_frame(tsdf_handle* h) {
     } else if (q.direct) {
         HIP_TRY(h, hipEventSynchronize(h->ev_copied));       // the caller's buffers have been read
     } else {
+        const auto tw0 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> g(h->qmu);
         h->qcv.wait(g, [&] { return !h->qbusy; });           // the staging thread is done with the caller's buffers
+        if (h->sp.on) h->sp.next_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
         if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
     }
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
