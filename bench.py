@@ -397,6 +397,13 @@ def run(args):
                 self.sdf.set_frame(*host[k])
             elif mode == "aos":
                 self.sdf.set_frame_aos(*host[k])
+            elif mode == "depth_q":
+                qd = lambda i: self.sdf.queue_depth_frame(depth16[i], host[i][2])
+                if k == 0:
+                    qd(0)
+                self.sdf.next_frame()
+                if k + 1 < len(host):
+                    qd(k + 1)
             elif mode in ("host_q", "aos_q"):
                 # two-deep queue: frame k was queued during step k-1 and becomes current now; frame k+1 is queued before
                 # frame k is tracked and integrated, so its upload runs under the whole of frame k's GPU work
@@ -669,6 +676,13 @@ def run(args):
         pin16 = [torch.from_numpy(d.view(np.int16)).pin_memory() for d in depth16]
         e3p = best_of_two("depth", pinned_frames, [t.numpy().view(np.uint16) for t in pin16])
         extras["value_depth_input_inclusive_pinned_buffers"] = args.steps / e3p
+        extras["value_depth_input_inclusive_queued"] = args.steps / best_of_two("depth_q", host_frames, depth16)
+        extras["value_depth_input_inclusive_pinned_buffers_queued"] = args.steps / best_of_two(
+            "depth_q", pinned_frames, [t.numpy().view(np.uint16) for t in pin16])
+        extras["value_host_inclusive"]["raw_depth_pageable"] = extras["value_depth_input_inclusive_queued"]
+        extras["depth_queued_note"] = ("raw depth + rgb through tsdf_queue_depth_frame: upload, pre-processing (with its host round trip for "
+                                       "the bilateral grid's depth range) and packing of frame k+1 on a library thread + the frame stream "
+                                       "while frame k is tracked and integrated")
     if n1_extras:
         guarded("h2d_inclusive", leg_h2d)
 

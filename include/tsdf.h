@@ -209,6 +209,13 @@ void tsdf_default_preproc(tsdf_preproc_params *p);
 /* depth16 (uint16) or depthf (float metres, <= 0 / NaN invalid): exactly one non-null; host pointers; rgb may be null */
 int tsdf_set_depth_frame(tsdf_handle *h, const uint16_t *depth16, const float *depthf, const uint8_t *rgb,
                          int32_t width, int32_t height, const tsdf_preproc_params *params);
+/* The same through the two-deep frame queue (tsdf_queue_frame's rules: one frame queued at a time, of the current
+ * frame's size, buffers borrowed until tsdf_next_frame returns): upload, pre-processing -- including its one host round
+ * trip for the bilateral grid's depth range -- and packing run on a library thread and the frame stream while the caller
+ * tracks and integrates the current frame.  What tsdf_set_depth_frame would have returned for the frame (bad depth
+ * range ...) is returned by tsdf_next_frame. */
+int tsdf_queue_depth_frame(tsdf_handle *h, const uint16_t *depth16, const float *depthf, const uint8_t *rgb,
+                         int32_t width, int32_t height, const tsdf_preproc_params *params);
 /* copy the current pre-processed frame back (any pointer may be null): xyz, normals as float[h*w*3] */
 int tsdf_get_preprocessed(tsdf_handle *h, float *xyz, float *nrm);
 

@@ -117,6 +117,72 @@ def test_infinite_and_far_depths_are_no_readings(grid_filter):
     s.close()
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_queued_depth_frames_give_the_same_trajectory_and_volume(pinned):
+    """tsdf_queue_depth_frame: frame k+1 is uploaded, pre-processed and packed while frame k is tracked and integrated;
+    poses, volume and the pre-processed planes must equal the tsdf_set_depth_frame loop bit for bit; a frame whose
+    pre-processing fails on the library thread reports it from tsdf_next_frame."""
+    import torch
+    import tracking_sdf_amd as ts
+    w, h, m, n = 160, 120, 48, 5
+    seq = synth.Sequence(n_frames=n, width=w, height=h, noise=True, holes=0.02, step=3)
+    params = dict(sigma_s=3.0, sigma_r=0.05, normal_radius=3)
+    frames, hold = [], []
+    for k in range(n):
+        xyz, _, rgb = seq.frame(k)
+        z16 = np.clip(np.where(np.isnan(xyz[..., 2]), 0.0, xyz[..., 2]) * 5000.0, 0, 65535).astype(np.uint16)
+        if pinned:
+            tz, tc = torch.from_numpy(z16.view(np.int16).copy()).pin_memory(), torch.from_numpy(np.ascontiguousarray(rgb)).pin_memory()
+            hold.append((tz, tc))
+            frames.append((tz.numpy().view(np.uint16), tc.numpy()))
+        else:
+            frames.append((z16, np.ascontiguousarray(rgb)))
+
+    def run(queued):
+        s = ts.SDF(m, with_color=True)
+        t = ts.CameraTracking(sdf=s)
+        t.set_K(seq.K)
+        poses = []
+        if queued:
+            s.queue_depth_frame(*frames[0], depth_scale=1.0 / 5000.0, **params)
+        for k in range(n):
+            if queued:
+                s.next_frame()
+                if k + 1 < n:
+                    s.queue_depth_frame(*frames[k + 1], depth_scale=1.0 / 5000.0, **params)
+                    with pytest.raises(ts.TsdfError):
+                        s.set_depth_frame(*frames[k], depth_scale=1.0 / 5000.0, **params)      # a frame is queued
+            else:
+                s.set_depth_frame(*frames[k], depth_scale=1.0 / 5000.0, **params)
+            if k > 0:
+                t.estimate_new_position()
+            s.update()
+            poses.append((t.rot.copy(), t.trans.copy()))
+        pre = s.get_preprocessed()
+        out = (poses, s.download(), s.download_color(), pre)
+        s.close()
+        return out
+    want, got = run(False), run(True)
+    for (r0, t0), (r1, t1) in zip(want[0], got[0]):
+        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+    for a, b in zip(want[1] + want[2], got[1] + got[2]):
+        assert np.array_equal(a, b)
+    for a, b in zip(want[3], got[3]):
+        assert np.array_equal(a, b, equal_nan=True)
+    # a depth range that is no usable bilateral grid: refused by the frame's tsdf_next_frame, the current frame stays
+    s = ts.SDF(32)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    s.set_depth_frame(*frames[0], depth_scale=1.0 / 5000.0, **params)
+    bad = np.linspace(1.0, 5.0, h * w, dtype=np.float32).reshape(h, w)     # 4000 depth cells of 1 mm x 164 x 124: too many
+    s.queue_depth_frame(bad, None, sigma_s=1.0, sigma_r=0.001, normal_radius=3)
+    with pytest.raises(ts.TsdfError) as ei:
+        s.next_frame()
+    assert "too large" in str(ei.value)
+    s.update()                                       # frame 0 is still the current one
+    s.close()
+
+
 def test_preproc_argument_checks():
     import tracking_sdf_amd as ts
     s = ts.SDF(32)

@@ -104,7 +104,7 @@ ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_set_tracker_params", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_frame_serial", "tsdf_queue_frame", "tsdf_queue_frame_device", "tsdf_queue_frame_aos", "tsdf_next_frame",
-    "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
+    "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_queue_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
@@ -163,6 +163,7 @@ def lib():
         "tsdf_set_frame_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32]),
         "tsdf_default_preproc": (None, [C.POINTER(PreprocParams)]),
         "tsdf_set_depth_frame": (C.c_int, [H, C.POINTER(C.c_uint16), fp, u8p, C.c_int32, C.c_int32, C.POINTER(PreprocParams)]),
+        "tsdf_queue_depth_frame": (C.c_int, [H, C.POINTER(C.c_uint16), fp, u8p, C.c_int32, C.c_int32, C.POINTER(PreprocParams)]),
         "tsdf_get_preprocessed": (C.c_int, [H, fp, fp]),
         "tsdf_integrate": (C.c_int, [H, C.POINTER(IntegrateStats)]),
         "tsdf_track": (C.c_int, [H, C.POINTER(TrackStats)]),
@@ -353,6 +354,15 @@ class SDF:
         """Raw depth image (uint16 with depth_scale, or float32 metres) -> GPU back-projection + bilateral filter +
         normals -> current frame.  Keyword overrides: depth_scale, sigma_s, sigma_r, radius, normal_radius,
         max_depth_change.  Needs the intrinsics (CameraTracking.set_K) first."""
+        self._depth_frame(lib().tsdf_set_depth_frame, depth, rgb, params)
+
+    def queue_depth_frame(self, depth, rgb=None, **params):
+        """tsdf_queue_depth_frame: the same through the two-deep frame queue (see queue_frame); the arrays are borrowed
+        until next_frame returns (references are kept that long)."""
+        keep = self._depth_frame(lib().tsdf_queue_depth_frame, depth, rgb, params)
+        self._queued_keep = keep
+
+    def _depth_frame(self, entry, depth, rgb, params):
         pp = PreprocParams()
         lib().tsdf_default_preproc(C.byref(pp))
         for k, v in params.items():
@@ -372,8 +382,9 @@ class SDF:
             rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
             assert rgb.shape == (h, w, 3)
             cptr = rgb.ctypes.data_as(C.POINTER(C.c_uint8))
-        self._check(lib().tsdf_set_depth_frame(self._h, d16, df, cptr, w, h, C.byref(pp)))
+        self._check(entry(self._h, d16, df, cptr, w, h, C.byref(pp)))
         self._frame_shape = (h, w)
+        return (depth, rgb)
 
     def get_preprocessed(self):
         h, w = self._frame_shape

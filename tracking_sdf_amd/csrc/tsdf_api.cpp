@@ -130,6 +130,7 @@ struct tsdf_handle {
         int nb = 0;
         int32_t su = 1, sv = 0;
         hipError_t err = hipSuccess;       // what the staging thread's HIP calls returned
+        int rc = 0;                        // tsdf_queue_depth_frame: what the pre-processing on the staging thread returned (message in the handle)
     } queued;
     hipEvent_t ev_queued = nullptr;        // the queued frame's records are packed
     std::thread qthread;                   // runs the pageable path's staging so that the caller can go on tracking
@@ -1365,7 +1366,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
     tsdf_handle::Queued& q = h->queued;
-    q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess;
+    q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess; q.rc = TSDF_OK;
     h->staged_xyz = false;                   // in_xyz / in_nrm / in_rgb are about to hold the QUEUED frame, not the current one
     pick_pixel_layout(h, &q.su, &q.sv);      // from the pose of this moment: only the order of the records depends on it
     rc = wait_buffer_free(h, q.nb, h->fstream);
@@ -1470,7 +1471,7 @@ int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_n
     rc = ensure_frame_buffers(h, width, height, false);
     if (rc) return rc;
     tsdf_handle::Queued& q = h->queued;
-    q.nb = h->fidx ^ 1; q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true; q.err = hipSuccess;
+    q.nb = h->fidx ^ 1; q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true; q.err = hipSuccess; q.rc = TSDF_OK;
     q.deferred = q.packed = false;
     if (h->defer_device_pack) {
         // no launch now: the integrate launch of the CURRENT frame packs this one in workgroups appended to its
@@ -1523,6 +1524,7 @@ int tsdf_next_frame(tsdf_handle* h) {
         std::unique_lock<std::mutex> g(h->qmu);
         h->qcv.wait(g, [&] { return !h->qbusy; });           // the staging thread is done with the caller's buffers
         if (h->sp.on) h->sp.next_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
+        if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; return r; }      // (the library thread left the message in the handle)
         if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
     }
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
@@ -1596,27 +1598,33 @@ void tsdf_default_preproc(tsdf_preproc_params* p) {
     p->grid_filter = 1;
 }
 
-int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
-                         int32_t width, int32_t height, const tsdf_preproc_params* params) {
+namespace {
+// argument checks and buffers shared by tsdf_set_depth_frame / tsdf_queue_depth_frame (caller's thread)
+int depth_frame_prepare(tsdf_handle* h, const char* who, const uint16_t* depth16, const float* depthf, int32_t width, int32_t height,
+                        const tsdf_preproc_params* params, tsdf_preproc_params* pp_out) {
     if (!h || (!depth16 == !depthf) || width <= 0 || height <= 0)
-        return h ? fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: exactly one of depth16 / depthf, positive size") : TSDF_E_BADARG;
-    if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "tsdf_set_depth_frame needs the intrinsics for the back-projection");
+        return h ? fail(h, TSDF_E_BADARG, "%s: exactly one of depth16 / depthf, positive size", who) : TSDF_E_BADARG;
+    if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "%s needs the intrinsics for the back-projection", who);
     tsdf_preproc_params pp;
     if (params) pp = *params; else tsdf_default_preproc(&pp);
     if (pp.radius < 0 || pp.radius > 32 || pp.normal_radius < 1 || pp.normal_radius > 8 || !(pp.sigma_s > 0) || !(pp.sigma_r > 0))
-        return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: bad parameters (radius %d, normal_radius %d)", pp.radius, pp.normal_radius);
+        return fail(h, TSDF_E_BADARG, "%s: bad parameters (radius %d, normal_radius %d)", who, pp.radius, pp.normal_radius);
     const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
     if (use_grid && !(pp.sigma_s >= 1.0f && pp.sigma_s <= 30.0f))
-        return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: the bilateral grid takes sigma_s in [1, 30] pixels, not %g", (double)pp.sigma_s);
+        return fail(h, TSDF_E_BADARG, "%s: the bilateral grid takes sigma_s in [1, 30] pixels, not %g", who, (double)pp.sigma_s);
     if (depth16 && !(pp.depth_scale > 0))
-        return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: depth_scale must be positive");
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_depth_frame");
+        return fail(h, TSDF_E_BADARG, "%s: depth_scale must be positive", who);
+    if (h->queued.active)
+        return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", who);
     int rc = bind_device(h);
     if (rc) return rc;
+    if (h->have_frame && std::strcmp(who, "tsdf_queue_depth_frame") == 0 && (h->fw != width || h->fh != height))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
     rc = ensure_frame_buffers(h, width, height, true);
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
     if (npix > h->pre_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
         free_preproc(h);
         HIP_TRY(h, hipMalloc((void**)&h->pre_z, npix * sizeof(float)));
         HIP_TRY(h, hipMalloc((void**)&h->pre_zf, npix * sizeof(float)));
@@ -1626,12 +1634,23 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
         HIP_TRY(h, hipHostMalloc((void**)&h->pin_minmax, 2 * sizeof(unsigned), hipHostMallocDefault));
         h->pre_cap = npix;
     }
+    *pp_out = pp;
+    return TSDF_OK;
+}
+
+// Upload, back-projection, filter and normals of a depth frame on the frame stream; in_xyz / in_nrm / in_rgb hold the
+// frame afterwards.  Runs on the caller's thread (tsdf_set_depth_frame) or on the queue's library thread
+// (tsdf_queue_depth_frame): the bilateral grid's depth extent is the one host round trip of this path.
+int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
+                     int32_t width, int32_t height, const tsdf_preproc_params& pp, bool* direct_out) {
+    const size_t npix = (size_t)width * height;
+    const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
     HIP_TRY(h, hipStreamSynchronize(h->fstream));          // pinned staging may still feed the previous frame
-    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     const size_t dbytes = npix * (depth16 ? sizeof(uint16_t) : sizeof(float));
     const void* dsrc = depth16 ? (const void*)depth16 : (const void*)depthf;
     // page-locked caller buffers are copied from directly, as in tsdf_set_frame
     const bool direct = is_pinned_host(dsrc, dbytes) && (!rgb || is_pinned_host(rgb, npix * 3));
+    *direct_out = direct;
     if (!direct) std::memcpy(h->pin_depth, dsrc, dbytes);
     HIP_TRY(h, hipMemcpyAsync(h->pre_depth, direct ? dsrc : h->pin_depth, dbytes, hipMemcpyHostToDevice, h->fstream));
     HIP_TRY(h, launch_depth_to_z(h->fstream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
@@ -1654,11 +1673,11 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
             const unsigned lo = h->pin_minmax[0], hi = ~h->pin_minmax[1];
             std::memcpy(&zmin, &lo, 4); std::memcpy(&zmax, &hi, 4);
             if (!bilateral_grid_plan(width, height, pp.sigma_s, pp.sigma_r, zmin, zmax, &bg))
-                return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: depth range [%g, %g] m is not a usable bilateral grid at sigma_r %g",
+                return fail(h, TSDF_E_BADARG, "%s: depth range [%g, %g] m is not a usable bilateral grid at sigma_r %g", who,
                             (double)zmin, (double)zmax, (double)pp.sigma_r);
             const size_t cells = (size_t)bg.gx * bg.gy * bg.gz;
             if (cells > ((size_t)1 << 26))
-                return fail(h, TSDF_E_BADARG, "tsdf_set_depth_frame: bilateral grid of %d x %d x %d cells is too large (sigma_s %g, sigma_r %g)",
+                return fail(h, TSDF_E_BADARG, "%s: bilateral grid of %d x %d x %d cells is too large (sigma_s %g, sigma_r %g)", who,
                             bg.gx, bg.gy, bg.gz, (double)pp.sigma_s, (double)pp.sigma_r);
             if (cells > h->pre_grid_cap) {
                 if (h->pre_grid_a) (void)hipFree(h->pre_grid_a);
@@ -1676,10 +1695,64 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
     HIP_TRY(h, launch_preproc(h->fstream, width, height, Kf, use_grid && !grid_on ? 0 : pp.radius, pp.sigma_s, pp.sigma_r,
                               pp.normal_radius, pp.max_depth_change, grid_on ? &bg : nullptr, h->pre_grid_a, h->pre_grid_b,
                               h->pre_z, h->pre_zf, h->in_xyz, h->in_nrm));
+    return TSDF_OK;
+}
+}  // namespace
+
+int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
+                         int32_t width, int32_t height, const tsdf_preproc_params* params) {
+    tsdf_preproc_params pp;
+    int rc = depth_frame_prepare(h, "tsdf_set_depth_frame", depth16, depthf, width, height, params, &pp);
+    if (rc) return rc;
+    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
+    bool direct = false;
+    rc = depth_frame_work(h, "tsdf_set_depth_frame", depth16, depthf, rgb, width, height, pp, &direct);
+    if (rc) return rc;
     h->staged_xyz = true;
     rc = run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
     if (rc) return rc;
+    const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
     if (direct && !use_grid) HIP_TRY(h, hipEventSynchronize(h->ev_copied));   // (the grid path has synchronised already)
+    return TSDF_OK;
+}
+
+// The two-deep queue for raw depth frames: upload, pre-processing (with its one host round trip for the bilateral grid's
+// depth range) and packing of frame k+1 run on the library thread + frame stream while the caller drives frame k's
+// Gauss-Newton passes; the buffers are borrowed until tsdf_next_frame returns.
+int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
+                           int32_t width, int32_t height, const tsdf_preproc_params* params) {
+    tsdf_preproc_params pp;
+    int rc = depth_frame_prepare(h, "tsdf_queue_depth_frame", depth16, depthf, width, height, params, &pp);
+    if (rc) return rc;
+    tsdf_handle::Queued& q = h->queued;
+    q.nb = h->fidx ^ 1; q.has_nrm = true; q.has_rgb = rgb != nullptr; q.direct = false; q.device = false; q.err = hipSuccess;
+    q.deferred = q.packed = false; q.rc = TSDF_OK;
+    h->staged_xyz = false;                   // in_xyz / in_nrm / in_rgb are about to hold the QUEUED frame, not the current one
+    pick_pixel_layout(h, &q.su, &q.sv);
+    rc = wait_buffer_free(h, q.nb, h->fstream);
+    if (rc) return rc;
+    const PackArgs pa = pack_args(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, q.su, q.sv, q.nb);
+    if (!h->qthread.joinable()) {
+        try { h->qthread = std::thread(queue_thread_main, h); }
+        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_depth_frame: cannot start the staging thread"); }
+    }
+    {
+        std::lock_guard<std::mutex> g(h->qmu);
+        h->qbusy = true;
+        h->qjob = [h, depth16, depthf, rgb, width, height, pp, pa] {
+            bool direct = false;
+            int r = depth_frame_work(h, "tsdf_queue_depth_frame", depth16, depthf, rgb, width, height, pp, &direct);
+            hipError_t e = hipSuccess;
+            if (r == TSDF_OK) e = launch_pack(h->fstream, pa);
+            if (r == TSDF_OK && e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
+            const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
+            if (r == TSDF_OK && e == hipSuccess && direct && !use_grid) e = hipEventSynchronize(h->ev_copied);   // the caller's buffers have been read
+            h->queued.rc = r;
+            h->queued.err = e;
+        };
+    }
+    h->qcv.notify_all();
+    q.active = true;
     return TSDF_OK;
 }
 
