@@ -778,6 +778,15 @@ int fetch_counters(tsdf_handle* h) {
                              t[5] ? (double)t[4] / (0.01 * (double)t[5]) : 0.0);
         }
     }
+    {   // TSDF_LIVE_HIST=1 with a -DTSDF_LIVE_HISTOGRAM build: work items by the number of lanes they update (cumulative)
+        static const bool live_hist = [] { const char* e = std::getenv("TSDF_LIVE_HIST"); return e && std::atoi(e) != 0; }();
+        if (live_hist) {
+            unsigned long long t[6] = {0, 0, 0, 0, 0, 0};
+            for (size_t w = 0; w < 4 * (size_t)h->integrate_blocks; ++w)
+                for (int q = 0; q < 6; ++q) t[q] += h->wg_counts_host[nw + 6 * w + q];
+            std::fprintf(stderr, "LIVEHIST items by updated lanes: 0: %llu  1-16: %llu  17-32: %llu  33-48: %llu  49-63: %llu  64: %llu\n", t[0], t[1], t[2], t[3], t[4], t[5]);
+        }
+    }
     unsigned long long own = 0, halo = 0;
     for (size_t b = 0; b < nw; b += 2) { own += h->wg_counts_host[b]; halo += h->wg_counts_host[b + 1]; }
     {   // TSDF_LIST_STATS=1: how much of the work list missed its band's predicted region (cumulative)

@@ -330,6 +330,9 @@ __global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p
         }
         if (klo <= khi) { c0 = klo >> 6; n = (khi >> 6) - c0 + 1; }
     }
+#ifdef TSDF_LIST_ABLATION
+    if (p.debug & 0x40000) return;                   // timing experiment: the clip alone
+#endif
     unsigned rank = 0u;
     if (n) rank = atomicAdd(&s_wg[bin], (unsigned)n);
     __syncthreads();
@@ -337,6 +340,9 @@ __global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p
     for (int t = tid; t < kBins; t += kClipBlock) {
         const unsigned cnt = s_wg[t];
         if (cnt) {
+#ifdef TSDF_LIST_ABLATION
+            if (p.debug & 0x10000) { s_dest[t] = ovf_base; continue; }      // timing experiment: no global atomics (the list stays empty)
+#endif
             const unsigned at = atomicAdd(&set[kSetCur + t], cnt);
             unsigned dest;
             if (at + cnt <= set[kSetCap + t]) dest = set[kSetBase + t] + at;
@@ -372,7 +378,10 @@ __global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p
         if (tid == 0) s_pre[0] = 0u;
     }
     __syncthreads();
-    const unsigned total = s_pre[kClipBlock];
+    unsigned total = s_pre[kClipBlock];
+#ifdef TSDF_LIST_ABLATION
+    if (p.debug & 0x20000) total = 0u;               // timing experiment: no descriptors written
+#endif
     for (unsigned e = tid; e < total; e += kClipBlock) {
         // the row of item e: the last r with s_pre[r] <= e
         unsigned lo = 0u, hi = kClipBlock;
@@ -737,7 +746,8 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     // split it evenly.
     const unsigned xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     // (readfirstlane: xcd_fb is written at the end of this kernel, so the compiler may fetch the shares with a vector
-    // load and then takes everything derived from them for per-lane values)
+    // load and then takes everything derived from them for per-lane values.  Requesting them in front of the segment
+    // table's loads changes nothing: measured.)
     const unsigned x_lo = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd])) >> 24);
     const unsigned x_hi = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd + 1])) >> 24);
     // The workgroup's contiguous share of the work list, dealt to its wavefronts ITEM BY ITEM: at any moment the NW
@@ -766,6 +776,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     // (seg_end is wave-uniform in an SGPR; seg_delta stays in a VGPR as the LDS load leaves it -- the kernel has no
     // scalar registers to spare -- and goes through v_readfirstlane once per item.)
     unsigned seg_end = 0u, seg_delta = 0u;
+#ifdef TSDF_LIVE_HISTOGRAM
+    unsigned hist[6] = {0u, 0u, 0u, 0u, 0u, 0u};              // measurement build: items by updated lanes (0, 1-16, 17-32, 33-48, 49-63, 64)
+#endif
     auto locate = [&](unsigned v) {
         // segment of v = number of segment ends <= v (lane l looks at the end of segment l; the overflow segment is the last)
         const unsigned e = s_vstart[(lane < kBins ? lane : kBins - 1) + 1];
@@ -879,6 +892,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         if (p.debug & 1024) base3 = (long long)(blockIdx.x & 255) * 4096 + wv * 64;   // timing experiment only: stores to a cache-resident region
 #endif
         const unsigned n_live = (unsigned)__popcll(uin.live);
+#ifdef TSDF_LIVE_HISTOGRAM
+        if (uin.code != 0u || n_live) { const unsigned bk = n_live == 0u ? 0u : n_live == 64u ? 5u : 1u + ((n_live - 1u) >> 4); hist[bk] += 1u; }
+#endif
         n_own += owned3 ? n_live : 0u;
         n_halo += owned3 ? 0u : n_live;
         // sdf.cpp:289-292 (D, W) and :294-304 (colour), as packed f32 pairs {D-average, R} and {G, B}
@@ -984,6 +1000,12 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     }
 #endif
     // (steps run up to j >= cnt + DEPTH, so S3 has retired item cnt-1 inside the loop: nothing to drain)
+#ifdef TSDF_LIVE_HISTOGRAM
+    if (lane == 0) {
+        unsigned long long* w = counters + 2 * (size_t)gridDim.x + 6 * ((size_t)blockIdx.x * NW + (size_t)wv);
+        for (int q = 0; q < 6; ++q) w[q] += hist[q];
+    }
+#endif
 
     if (wv == 0 && lane == 0)
         atomicAdd(reinterpret_cast<unsigned long long*>(xcd_fb + kFbTicksWord) + xcd, __builtin_amdgcn_s_memrealtime() - loop_t0 + 1ull);
