@@ -356,6 +356,9 @@ typedef struct tsdf_counters {
 int tsdf_set_timing(tsdf_handle *h, int32_t on);
 int tsdf_read_timing(tsdf_handle *h, tsdf_timing *out, int32_t reset);
 int tsdf_read_counters(tsdf_handle *h, tsdf_counters *out, int32_t reset);
+/* Waits for everything the handle has launched (main stream, frame stream, the queue's library thread).  Device
+ * frames whose packing is still deferred (tsdf_set_frame_device / tsdf_queue_frame_device) are packed first, by a
+ * launch of their own: when the call returns the library no longer reads any borrowed device plane. */
 int tsdf_synchronize(tsdf_handle *h);
 /* The hipStream_t the hot kernels (track, integrate, mesh) are launched on, as an opaque pointer (for callers
  * that record their own events).  tsdf_synchronize waits for this and for the internal frame stream. */

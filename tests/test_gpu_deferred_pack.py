@@ -125,3 +125,45 @@ def test_queued_device_frames_in_every_order(monkeypatch):
         poses.append((t.rot.copy(), t.trans.copy()))
         ab.append(t.accumulate())
     assert_same(want, finish(s, t, poses) + (ab,))
+
+
+def test_synchronize_ends_the_claim_on_the_planes(monkeypatch):
+    """tsdf_synchronize packs what is still deferred: afterwards the caller may overwrite or free its device planes --
+    also between a frame's tracking and its integration, and for a queued frame that no integrate launch has seen"""
+    import torch
+    import tracking_sdf_amd as ts
+    monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    want = host_loop(n=4)
+    seq = synth.Sequence(n_frames=4, width=W, height=H, noise=True, holes=0.02, step=4)
+    fr = frames_on_device(seq, 4)
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    poses, ab = [], []
+
+    def scratch(k):
+        buf = [a.clone() for a in fr[k]]
+        return buf
+
+    for k in range(4):
+        buf = scratch(k)
+        if k == 2:                                   # through the queue, overwritten while it is only queued
+            s.queue_frame_device(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), W, H, keep=buf)
+            s.synchronize()
+            for a in buf:
+                a.zero_()
+            torch.cuda.synchronize()
+            s.next_frame()
+        else:
+            s.set_frame_device(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), W, H, keep=buf)
+        if k > 0:
+            t.estimate_new_position()
+        if k != 2:
+            s.synchronize()                          # k == 0: nothing read the planes yet; otherwise only the tracker did
+            for a in buf:
+                a.zero_()
+            torch.cuda.synchronize()
+        s.update()
+        poses.append((t.rot.copy(), t.trans.copy()))
+        ab.append(t.accumulate())
+    assert_same(want, finish(s, t, poses) + (ab,))

@@ -2632,6 +2632,20 @@ int tsdf_synchronize(tsdf_handle* h) {
         std::unique_lock<std::mutex> g(h->qmu);
         h->qcv.wait(g, [&] { return !h->qbusy; });
     }
+    // Device frames whose packing is still deferred: tsdf_synchronize ends the library's claim on borrowed device
+    // planes (tsdf.h), so what has not been packed yet is packed now, by a launch of its own
+    if (h->deferred.pending) {
+        PackArgs own = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
+        if (h->deferred.samples_listed) own.samples = nullptr;
+        HIP_TRY(h, launch_pack(h->stream, own));
+        h->deferred.pending = false;
+    }
+    if (h->queued.active && h->queued.device && h->queued.deferred && !h->queued.packed) {
+        tsdf_handle::Queued& q = h->queued;
+        pick_pixel_layout(h, &q.su, &q.sv);
+        HIP_TRY(h, launch_pack(h->stream, pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, q.nb)));
+        q.packed = true;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return TSDF_OK;
