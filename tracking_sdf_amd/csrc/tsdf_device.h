@@ -117,6 +117,7 @@ hipError_t launch_pack(hipStream_t s, const PackArgs& a);
 // integrate_bookkeeping_words() unsigned, zero before the first launch; n_blocks: persistent grid size (CUs x
 // integrate_blocks_per_cu(), a multiple of 8).
 size_t integrate_worklist_entries(const Grid& g);
+size_t integrate_band_region_entries(const Grid& g);   // entries of the band regions in front of the overflow region
 size_t integrate_worklist_bytes(const Grid& g);      // 32-byte item descriptors: band regions + overflow region
 constexpr size_t kPixelRecordBytes = 32;             // per pixel: two float4 records (24 of them used when the volume has no colour)
 constexpr size_t kPixelBufferBytes = 40;             // what a frame's pixel buffer holds per pixel: the record + the f64 cosine (colour volumes)

@@ -188,7 +188,7 @@ __device__ __forceinline__ void clip_affine(double a, double b, double& lo, doub
 //   [kSetFirstOvf + b] smallest cursor value at which a group of band b did not fit its region any more (~0: all fitted)
 //   [kSetCap + b]     capacity of band b's region in the list          } prepared by the PREVIOUS launch's
 //   [kSetBase + b]    first list entry of band b's region (b = 0..kBins: [kBins] = end of the regions)  } integrate_kernel
-//   [kSetOvf]         items in the overflow region (list entries [ovf_base, ...), ovf_base = half of the list)
+//   [kSetOvf]         items in the overflow region (list entries [ovf_base, ...), ovf_base = integrate_band_region_entries())
 // One pass builds the band-sorted list (list_rows_kernel): the band regions are sized from the band counts of the
 // previous frame (+25 % + 128 entries) -- consecutive frames see nearly the same image -- and whatever does not fit goes
 // to the overflow region behind them, which is integrated like any other part of the list, only without the band's
@@ -1429,9 +1429,19 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 size_t integrate_worklist_entries(const Grid& g) {
     return (size_t)(g.xe - g.xs) * g.m * ((g.m + 63) / 64);
 }
-// band regions (at most `entries` in all) + an overflow region that can hold every item; zero-filled once at creation
-// (a wavefront without items reads entry 0)
-size_t integrate_worklist_bytes(const Grid& g) { return (2 * integrate_worklist_entries(g) + 8) * sizeof(ItemDesc); }
+// The band regions in front of the overflow region hold at most a quarter of all possible items (a frame lists a few
+// percent of them: 9 % at 512^3; whatever the bands' capacities cannot take goes to the overflow region, which is
+// integrated like the rest, only without the bands' locality) -- small volumes keep room for everything.
+size_t integrate_band_region_entries(const Grid& g) {
+    const size_t all = integrate_worklist_entries(g);
+    const size_t quarter = all / 4, floor_entries = (size_t)1 << 16;
+    return all <= floor_entries ? all : (quarter > floor_entries ? quarter : floor_entries);
+}
+// band regions + an overflow region that can hold every item; zero-filled once at creation (a wavefront without items
+// reads entry 0)
+size_t integrate_worklist_bytes(const Grid& g) {
+    return (integrate_band_region_entries(g) + integrate_worklist_entries(g) + 8) * sizeof(ItemDesc);
+}
 
 int integrate_blocks_per_cu(bool queue) {
     int n = 0;
@@ -1486,7 +1496,7 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     ItemDesc* const list = static_cast<ItemDesc*>(worklist);
     hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
-    const unsigned ovf_base = (unsigned)integrate_worklist_entries(p.g);       // band regions in the first half of the list
+    const unsigned ovf_base = (unsigned)integrate_band_region_entries(p.g);    // band regions in front of the overflow region
     // (pack: the frame's pixel records are still to be written -- workgroups behind the list's own do it, see the kernel)
     const PackArgs no_pack{};
     const unsigned ptiles = pack ? (unsigned)pack_tiles(*pack) : 0u;
