@@ -130,7 +130,8 @@ struct tsdf_handle {
         int nb = 0;
         int32_t su = 1, sv = 0;
         hipError_t err = hipSuccess;       // what the staging thread's HIP calls returned
-        int rc = 0;                        // tsdf_queue_depth_frame: what the pre-processing on the staging thread returned (message in the handle)
+        int rc = 0;                        // tsdf_queue_depth_frame: what the pre-processing on the staging thread returned
+        std::string msg;                   // ... and its message, handed to the handle by tsdf_next_frame
     } queued;
     hipEvent_t ev_queued = nullptr;        // the queued frame's records are packed
     std::thread qthread;                   // runs the pageable path's staging so that the caller can go on tracking
@@ -274,13 +275,18 @@ struct tsdf_handle {
 
 namespace {
 
+// Where fail() leaves its message when it runs on the queue's library thread (tsdf_queue_depth_frame): the handle's
+// own string belongs to the caller's thread, which may be failing a call of its own at that moment.
+thread_local std::string* t_err_sink = nullptr;
+
 int fail(tsdf_handle* h, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (h) h->err = buf;
+    if (h && t_err_sink) *t_err_sink = buf;
+    else if (h) h->err = buf;
     else { std::lock_guard<std::mutex> lk(g_err_mu); g_create_error = buf; }
     return code;
 }
@@ -1533,7 +1539,7 @@ int tsdf_next_frame(tsdf_handle* h) {
         std::unique_lock<std::mutex> g(h->qmu);
         h->qcv.wait(g, [&] { return !h->qbusy; });           // the staging thread is done with the caller's buffers
         if (h->sp.on) h->sp.next_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
-        if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; return r; }      // (the library thread left the message in the handle)
+        if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; h->err = q.msg; return r; }
         if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
     }
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
@@ -1750,7 +1756,9 @@ int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float*
         h->qbusy = true;
         h->qjob = [h, depth16, depthf, rgb, width, height, pp, pa] {
             bool direct = false;
+            t_err_sink = &h->queued.msg;
             int r = depth_frame_work(h, "tsdf_queue_depth_frame", depth16, depthf, rgb, width, height, pp, &direct);
+            t_err_sink = nullptr;
             hipError_t e = hipSuccess;
             if (r == TSDF_OK) e = launch_pack(h->fstream, pa);
             if (r == TSDF_OK && e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
