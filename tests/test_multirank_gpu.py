@@ -95,6 +95,28 @@ def test_config4_and_5_workloads_run_sharded(tmp_path, config, image):
     assert np.array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("config,m,image,ranks", [(4, 1024, [640, 480], (1, 2, 4)), (5, 2048, [1280, 960], (1, 2))])
+def test_configs_4_and_5_at_their_full_size_sharded_over_ranks_sharing_the_gpu(tmp_path, config, m, image, ranks):
+    """BASELINE configs 4 and 5 at the size they are named for -- 1024^3 with fr3 intrinsics at 640x480, 2048^3 at
+    1280x960, colour on (24 GiB / 192 GiB of volume) -- as x-slabs + halo over 2 (and 4) rank processes that share the
+    one MI355X, exchange step = the shared-memory fan-in: every sharded run must reproduce the single-rank trajectory
+    bit for bit.  (What this cannot show is RCCL over xGMI: one GPU.)"""
+    args = ["--config", str(config), "--voxels", str(m), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = []
+    for n in ranks:
+        traj = str(tmp_path / f"full{config}_n{n}.txt")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--trajectory-out", traj] + args
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert j["n_gpus"] == n and j["config"]["m"] == m and j["config"]["image"] == image and j["config"]["config"] == config
+        assert (j["config"]["halo"] > 0) == (n > 1)
+        out.append(np.loadtxt(traj))
+    for o in out[1:]:
+        assert np.array_equal(out[0], o)
+
+
 def test_in_library_rccl_code_path_with_two_ranks_over_a_mock_collective(tmp_path):
     """RCCL refuses two ranks on one device and this box has one, so the N > 1 run of the in-library RCCL path
     (communicator from a broadcast id, tracker result row -> collective on the library's stream -> publish kernel ->
