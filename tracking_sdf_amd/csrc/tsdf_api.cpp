@@ -1615,8 +1615,8 @@ void tsdf_default_preproc(tsdf_preproc_params* p) {
 
 namespace {
 // argument checks and buffers shared by tsdf_set_depth_frame / tsdf_queue_depth_frame (caller's thread)
-int depth_frame_prepare(tsdf_handle* h, const char* who, const uint16_t* depth16, const float* depthf, int32_t width, int32_t height,
-                        const tsdf_preproc_params* params, tsdf_preproc_params* pp_out) {
+int depth_frame_prepare(tsdf_handle* h, const char* who, bool queued, const uint16_t* depth16, const float* depthf, int32_t width,
+                        int32_t height, const tsdf_preproc_params* params, tsdf_preproc_params* pp_out) {
     if (!h || (!depth16 == !depthf) || width <= 0 || height <= 0)
         return h ? fail(h, TSDF_E_BADARG, "%s: exactly one of depth16 / depthf, positive size", who) : TSDF_E_BADARG;
     if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "%s needs the intrinsics for the back-projection", who);
@@ -1633,7 +1633,7 @@ int depth_frame_prepare(tsdf_handle* h, const char* who, const uint16_t* depth16
         return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", who);
     int rc = bind_device(h);
     if (rc) return rc;
-    if (h->have_frame && std::strcmp(who, "tsdf_queue_depth_frame") == 0 && (h->fw != width || h->fh != height))
+    if (queued && h->have_frame && (h->fw != width || h->fh != height))
         return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
     rc = ensure_frame_buffers(h, width, height, true);
     if (rc) return rc;
@@ -1717,7 +1717,7 @@ int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, c
 int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
                          int32_t width, int32_t height, const tsdf_preproc_params* params) {
     tsdf_preproc_params pp;
-    int rc = depth_frame_prepare(h, "tsdf_set_depth_frame", depth16, depthf, width, height, params, &pp);
+    int rc = depth_frame_prepare(h, "tsdf_set_depth_frame", false, depth16, depthf, width, height, params, &pp);
     if (rc) return rc;
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     bool direct = false;
@@ -1737,7 +1737,7 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
 int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
                            int32_t width, int32_t height, const tsdf_preproc_params* params) {
     tsdf_preproc_params pp;
-    int rc = depth_frame_prepare(h, "tsdf_queue_depth_frame", depth16, depthf, width, height, params, &pp);
+    int rc = depth_frame_prepare(h, "tsdf_queue_depth_frame", true, depth16, depthf, width, height, params, &pp);
     if (rc) return rc;
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = true; q.has_rgb = rgb != nullptr; q.direct = false; q.device = false; q.err = hipSuccess;
