@@ -167,3 +167,40 @@ def test_synchronize_ends_the_claim_on_the_planes(monkeypatch):
         poses.append((t.rot.copy(), t.trans.copy()))
         ab.append(t.accumulate())
     assert_same(want, finish(s, t, poses) + (ab,))
+
+
+@pytest.mark.parametrize("w,h,stride,color", [(203, 117, 3, True), (64, 48, 1, False), (161, 120, 4, True), (97, 33, 5, False)])
+def test_plane_sampling_for_odd_sizes_and_strides(w, h, stride, color, monkeypatch):
+    """the tracker's plane reads index pixel (col * stride, row * stride) of a `width`-wide image in the reference's visiting
+    order (columns outer); image sizes that are no multiples of the stride or of the packing tiles, with and without
+    colour records, against the host-plane loop bit for bit"""
+    import tracking_sdf_amd as ts
+    monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    n = 3
+    seq = synth.Sequence(n_frames=n, width=w, height=h, noise=True, holes=0.02, step=4)
+
+    def run(device):
+        s = ts.SDF(40, with_color=color, pixel_stride=stride)
+        t = ts.CameraTracking(sdf=s)
+        t.set_K(seq.K)
+        fr = frames_on_device(seq, n) if device else None
+        out = []
+        for k in range(n):
+            if device:
+                s.set_frame_device(fr[k][0].data_ptr(), fr[k][1].data_ptr(), fr[k][2].data_ptr() if color else 0, w, h, keep=fr[k])
+            else:
+                xyz, nrm, rgb = seq.frame(k)
+                s.set_frame(xyz, nrm, rgb if color else None)
+            if k > 0:
+                st = t.estimate_new_position()
+                out.append((t.rot.copy(), t.trans.copy(), st["iterations"]))
+            out.append(t.accumulate()[:2])
+            s.update()
+        D, Wt = s.download()
+        s.close()
+        return out, D, Wt
+    a, b = run(False), run(True)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for x, y in zip(a[0], b[0]):
+        for u, v in zip(x, y):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
