@@ -499,8 +499,9 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
 // A frame handed over in device memory is not packed when it is set: the tracker reads its samples from the xyz plane
 // (TrackParams::xyz_plane) and the pixel records are written inside the integrate launch, by workgroups appended to
 // list_rows_kernel (launch_integrate) -- the packing then hides under that kernel's latency chain instead of being 11 us
-// of its own in front of the first tracker pass.  The borrowing rule of tsdf_set_frame_device (valid until the next
-// set_frame* call) covers it.  TSDF_DEFER_PACK=0: pack at once, as rounds 1-3 did.
+// of its own in front of the first tracker pass.  The planes stay borrowed until that launch has run: tsdf.h asks for them
+// until the set_frame* call after the next one (or tsdf_synchronize, which packs what is pending).  TSDF_DEFER_PACK=0: pack
+// at once, as rounds 1-3 did.
 int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb) {
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;
