@@ -683,26 +683,41 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     if (host_fanin) {
         const int ns = track_num_shards(h->n_samples);
         const auto t0 = std::chrono::steady_clock::now();
+        // a shard's slot: 40 {value, word} pairs, each written by ONE 16-byte store (track_kernel).  A value is good when
+        // the word next to it is this pass's: read the word, then the value (loads stay in order on the host).
+        struct Pair { double v; unsigned long long w; };
+        const volatile Pair* pairs = reinterpret_cast<const volatile Pair*>(h->shard_host);
+        double rows[kTrackShards][kPartWidth];
         bool all = true;
         for (int sh = 0; sh < ns && all; ++sh) {
-            const volatile unsigned long long* word =
-                reinterpret_cast<const volatile unsigned long long*>(h->shard_host + (size_t)sh * kShardSlotDoubles + kPartWidth);
-            for (unsigned spins = 0;; ++spins) {
-                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
-                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { all = false; break; }
+            const volatile Pair* sp = pairs + (size_t)sh * (kShardSlotDoubles / 2);
+            for (int e = kPartWidth - 1; e >= 0 && all; --e) {
+                for (unsigned spins = 0;; ++spins) {
+                    if (__atomic_load_n(&sp[e].w, __ATOMIC_ACQUIRE) == seq) break;
+                    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { all = false; break; }
+                }
+                rows[sh][e] = sp[e].v;
             }
         }
-        if (!all) HIP_TRY(h, hipStreamSynchronize(h->stream));      // a shard row did not show up in time: synchronise for real
+        if (!all) {                                            // a shard row did not show up in time: synchronise for real
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            for (int sh = 0; sh < ns; ++sh)
+                for (int e = 0; e < kPartWidth; ++e) {
+                    const volatile Pair* sp = pairs + (size_t)sh * (kShardSlotDoubles / 2);
+                    if (sp[e].w != seq) return fail(h, TSDF_E_HIP, "tracker fan-in: shard %d of pass %llu never reached the host", sh, seq);
+                    rows[sh][e] = sp[e].v;
+                }
+        }
         if (h->track_profile) h->tp_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tp2).count();
         // shard order, as the device's last workgroup adds them: the same bits in every exchange mode
         double tot[kPartWidth];
         bool stale = false;
         for (int e = 0; e < kPartWidth; ++e) {
-            double v = h->shard_host[e];
-            for (int sh = 1; sh < ns; ++sh) v += h->shard_host[(size_t)sh * kShardSlotDoubles + e];
+            double v = rows[0][e];
+            for (int sh = 1; sh < ns; ++sh) v += rows[sh][e];
             tot[e] = v;
         }
-        for (int sh = 0; sh < ns; ++sh) stale |= h->shard_host[(size_t)sh * kShardSlotDoubles + kPartWidth - 1] != (double)(seq & 0xFFFFFFFFFFFFull);
+        for (int sh = 0; sh < ns; ++sh) stale |= rows[sh][kPartWidth - 1] != (double)(seq & 0xFFFFFFFFFFFFull);
         track_unpack_row(tot, h->red_host);
         if (stale) h->red_host[27] = std::nan("");
         arrived = true;
@@ -1029,8 +1044,9 @@ void tsdf_destroy(tsdf_handle* h) {
             const int nb = track_num_blocks(h->n_samples) < 4096 ? track_num_blocks(h->n_samples) : 4096;
             unsigned long long t0 = ~0ull;
             for (int b = 0; b < nb; ++b) if (st[8 * b] && st[8 * b] < t0) t0 = st[8 * b];
-            const char* names[7] = {"start", "window classified", "own sample", "look-ups done", "row written", "arrived", "shard row out"};
-            for (int k = 0; k < 7; ++k) {
+            const char* names[8] = {"start", "window classified", "own sample", "look-ups done", "row written", "arrived", "shard row out",
+                                    "shard word released"};
+            for (int k = 0; k < 8; ++k) {
                 double mn = 1e30, mx = 0, sum = 0; int n = 0;
                 for (int b = 0; b < nb; ++b) {
                     if (!st[8 * b + k] || st[8 * b + k] < t0) continue;

@@ -30,7 +30,8 @@ constexpr int kTrackBlock = TSDF_TRACK_BLOCK;    // threads per tracker workgrou
 #endif
 constexpr int kIntegrateBlock = TSDF_INTEGRATE_BLOCK;   // threads per integrate workgroup
 constexpr int kTrackShards = 8;                  // fan-in shards of the in-launch fold (blockIdx % 8: one per XCD)
-constexpr int kShardSlotDoubles = 48;            // pinned host slot of a shard row: 40 values + the pass word + pad
+constexpr int kShardSlotDoubles = 80;            // pinned host slot of a shard row: 40 {value, pass word} pairs of 16 bytes -- a value
+                                                 // and the word that validates it arrive in ONE store, so no fence separates them
 
 // partial row (kPartWidth) -> result row (kRedWidth): the mapping track_kernel's last workgroup applies, for the host
 // side of the fan-in
