@@ -118,9 +118,13 @@ def mixed(seq, steps):
     return out
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
-def test_every_route_of_a_frame_gives_the_same_bits(seed, monkeypatch):
-    monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+@pytest.mark.parametrize("seed,defer", [(1, None), (2, None), (3, None), (4, None), (5, None), (6, None), (7, None), (8, None),
+                                        (1, "0"), (2, "0"), (3, "2"), (4, "2")])
+def test_every_route_of_a_frame_gives_the_same_bits(seed, defer, monkeypatch):
+    if defer is None:
+        monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    else:
+        monkeypatch.setenv("TSDF_DEFER_PACK", defer)      # 0: device frames packed when they are set; 2: every pass reads the plane
     seq = synth.Sequence(n_frames=N, width=W, height=H, noise=True, holes=0.02, step=3)
     steps = plan(seed)
     want, got = reference(seq, steps), mixed(seq, steps)
