@@ -654,6 +654,9 @@ struct UpdateState {        // stage 2 done: volume reads requested
     u32x4 col;              // {Color_W, R, G, B} (fused colour; in flight until stage 3)
 };
 
+#ifndef TSDF_INTEGRATE_PRIO
+#define TSDF_INTEGRATE_PRIO 1       // bit 0: the record gathers of stage 1 are issued at raised wave priority (s_setprio 3)
+#endif
 #ifndef TSDF_INTEGRATE_DEPTH
 #define TSDF_INTEGRATE_DEPTH 1      // volume reads in flight per wavefront, in items (see the pipeline loop)
 #endif
@@ -810,6 +813,13 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         const unsigned roff = select_by_mask(okm, COLOR ? pixb << 5 : __umul24(pixb, (unsigned)kRec), dropped);
         const unsigned ra = (unsigned)__shfl((int)roff, lane >> 1) + half_off;
         const unsigned rb = (unsigned)__shfl((int)roff, 32 + (lane >> 1)) + half_off;
+        // The gathers go out at raised wave priority: they are the longest trip of an item (64 scattered records through
+        // L1 / L2), and a wavefront that has them ready should not queue behind the arithmetic of its four neighbours on
+        // the SIMD.  Measured on four boxes, alternating builds: integrate_kernel 2-7 % shorter on three of them (113.5 ->
+        // 105.7-110.4 us, 113.7 -> 110.2-111.0, 108.9 -> 106.4), either 106.3 or 110.5 against 108.7 on the fourth.
+#if TSDF_INTEGRATE_PRIO & 1
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if (COLOR) {
             g.A = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)ra, 0, 0);      // piece for LDS slot lane
             g.B = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)rb, 0, 0);      // piece for LDS slot 64 + lane
@@ -818,6 +828,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             const u32x3 b3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)rb, 0, 0);
             g.A = u32x4{a3.x, a3.y, a3.z, 0u}; g.B = u32x4{b3.x, b3.y, b3.z, 0u};
         }
+#if TSDF_INTEGRATE_PRIO & 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         g.live = okm;
         g.code = ds.code;
     };
