@@ -654,9 +654,12 @@ struct UpdateState {        // stage 2 done: volume reads requested
     u32x4 col;              // {Color_W, R, G, B} (fused colour; in flight until stage 3)
 };
 
-#ifndef TSDF_INTEGRATE_PRIO
-#define TSDF_INTEGRATE_PRIO 1       // bit 0: the record gathers of stage 1 are issued at raised wave priority (s_setprio 3)
+#ifndef TSDF_INTEGRATE_PRIO_LEVEL
+#define TSDF_INTEGRATE_PRIO_LEVEL 3
 #endif
+#ifndef TSDF_INTEGRATE_PRIO
+#define TSDF_INTEGRATE_PRIO 4       // raised wave priority (s_setprio): bit 2 = the whole of stage 1 (default), bit 0 = only around its two
+#endif                              // gather instructions, bit 1 = around the volume loads, bit 3 = the whole of stage 2 (measurement builds)
 #ifndef TSDF_INTEGRATE_DEPTH
 #define TSDF_INTEGRATE_DEPTH 1      // volume reads in flight per wavefront, in items (see the pipeline loop)
 #endif
@@ -790,6 +793,15 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         seg_delta = s_delta[sg];
     };
     auto stage1 = [&](int j, GatherState& g /*out: item j*/) {
+        // Stage 1 runs at raised wave priority: it ends in the gathers, the longest trip of an item (64 scattered records
+        // through L1 / L2), and a wavefront on its way to them should not queue behind the arithmetic of its four
+        // neighbours on the SIMD.  Measured on five boxes, alternating builds: with the priority only around the two gather
+        // instructions integrate_kernel is 2-7 % shorter on four of them (113.5 -> 105.7-110.4 us, 113.7 -> 110.2-111.0,
+        // 113.4 -> 110.4, 108.9 -> 106.4) and sits on two levels (106.3 / 110.5 against 108.7) on the fifth; the whole
+        // stage takes another 1.0-1.2 us (109.1-109.5); stage 2 or the volume loads at raised priority make it worse.
+#if TSDF_INTEGRATE_PRIO & 4
+        __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL);
+#endif
         const bool have = j < cnt;
         unsigned entry = 0u;                                    // (no item left: entry 0, masked below)
         if (have) {
@@ -813,12 +825,8 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         const unsigned roff = select_by_mask(okm, COLOR ? pixb << 5 : __umul24(pixb, (unsigned)kRec), dropped);
         const unsigned ra = (unsigned)__shfl((int)roff, lane >> 1) + half_off;
         const unsigned rb = (unsigned)__shfl((int)roff, 32 + (lane >> 1)) + half_off;
-        // The gathers go out at raised wave priority: they are the longest trip of an item (64 scattered records through
-        // L1 / L2), and a wavefront that has them ready should not queue behind the arithmetic of its four neighbours on
-        // the SIMD.  Measured on four boxes, alternating builds: integrate_kernel 2-7 % shorter on three of them (113.5 ->
-        // 105.7-110.4 us, 113.7 -> 110.2-111.0, 108.9 -> 106.4), either 106.3 or 110.5 against 108.7 on the fourth.
 #if TSDF_INTEGRATE_PRIO & 1
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL);
 #endif
         if (COLOR) {
             g.A = __builtin_amdgcn_raw_buffer_load_b128(pn_rsrc, (int)ra, 0, 0);      // piece for LDS slot lane
@@ -828,13 +836,16 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             const u32x3 b3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)rb, 0, 0);
             g.A = u32x4{a3.x, a3.y, a3.z, 0u}; g.B = u32x4{b3.x, b3.y, b3.z, 0u};
         }
-#if TSDF_INTEGRATE_PRIO & 1
+#if TSDF_INTEGRATE_PRIO & 5
         __builtin_amdgcn_s_setprio(0);
 #endif
         g.live = okm;
         g.code = ds.code;
     };
     auto stage2 = [&](const GatherState& gin /*item j-1, record arrived*/, UpdateState& u /*out: item j-1*/) {
+#if TSDF_INTEGRATE_PRIO & 8
+        __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL);
+#endif
         u32x4* stage = s_pieces[wv];
         if (COLOR) { stage[lane] = gin.A; stage[64 + lane] = gin.B; }
         else {
@@ -895,6 +906,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             const __amdgpu_buffer_rsrc_t seg_c = __builtin_amdgcn_make_buffer_rsrc(crgb + base2, 0, 64 * (int)sizeof(float4), kRsrcWord3);
             u.col = __builtin_amdgcn_raw_buffer_load_b128(seg_c, (int)(ld8 << 1), 0, 2);
         }
+#if TSDF_INTEGRATE_PRIO & 8
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto stage3 = [&](const UpdateState& uin /*item j-1-DEPTH, volume data arrived*/) {
         const unsigned code3 = uin.code;
