@@ -1188,6 +1188,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     set_window(0u);
 
     auto stage1 = [&](int j, Gather& g /*out: item j*/) {
+#if TSDF_INTEGRATE_PRIO & 4
+        __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL);   // as in integrate_kernel
+#endif
         const bool have = j < cnt;
         unsigned entry = 0u;                                    // (no item left: entry 0, masked below)
         if (have) {
@@ -1214,6 +1217,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             const u32x3 b3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)rb, 0, 0);
             g.A = u32x4{a3.x, a3.y, a3.z, 0u}; g.B = u32x4{b3.x, b3.y, b3.z, 0u};
         }
+#if TSDF_INTEGRATE_PRIO & 4
+        __builtin_amdgcn_s_setprio(0);
+#endif
         g.live = okm;
         g.code = ds.code;
         g.pixb = pixb;
