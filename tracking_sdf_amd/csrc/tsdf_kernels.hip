@@ -657,9 +657,13 @@ struct UpdateState {        // stage 2 done: volume reads requested
 #ifndef TSDF_INTEGRATE_PRIO_LEVEL
 #define TSDF_INTEGRATE_PRIO_LEVEL 3
 #endif
+#ifndef TSDF_INTEGRATE_PRIO_LEVEL_S2
+#define TSDF_INTEGRATE_PRIO_LEVEL_S2 1
+#endif
 #ifndef TSDF_INTEGRATE_PRIO
-#define TSDF_INTEGRATE_PRIO 4       // raised wave priority (s_setprio): bit 2 = the whole of stage 1 (default), bit 0 = only around its two
-#endif                              // gather instructions, bit 1 = around the volume loads, bit 3 = the whole of stage 2 (measurement builds)
+#define TSDF_INTEGRATE_PRIO 12      // graded wave priorities (s_setprio): bit 2 = the whole of stage 1 at TSDF_INTEGRATE_PRIO_LEVEL, bit 3 = the
+#endif                              // whole of stage 2 at ..._LEVEL_S2 (default: 3 / 1, stage 3 at 0); bit 0 = only around stage 1's two gather
+                                    // instructions, bit 1 = around the volume loads (measurement builds)
 #ifndef TSDF_INTEGRATE_DEPTH
 #define TSDF_INTEGRATE_DEPTH 1      // volume reads in flight per wavefront, in items (see the pipeline loop)
 #endif
@@ -798,7 +802,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         // neighbours on the SIMD.  Measured on five boxes, alternating builds: with the priority only around the two gather
         // instructions integrate_kernel is 2-7 % shorter on four of them (113.5 -> 105.7-110.4 us, 113.7 -> 110.2-111.0,
         // 113.4 -> 110.4, 108.9 -> 106.4) and sits on two levels (106.3 / 110.5 against 108.7) on the fifth; the whole
-        // stage takes another 1.0-1.2 us (109.1-109.5); stage 2 or the volume loads at raised priority make it worse.
+        // stage takes another 1.0-1.2 us (109.1-109.5); stage 2 at the SAME priority makes it worse, stage 2 one step above
+        // stage 3 (3 / 1 / 0) another ~3 us (109.3 -> 106.4 in 5 of 5 alternations on one box; 105.0 -> 101.2-102.1 in two
+        // of three on another, 106.1 in the third).
 #if TSDF_INTEGRATE_PRIO & 4
         __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL);
 #endif
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     };
     auto stage2 = [&](const GatherState& gin /*item j-1, record arrived*/, UpdateState& u /*out: item j-1*/) {
 #if TSDF_INTEGRATE_PRIO & 8
-        __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL);
+        __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL_S2);
 #endif
         u32x4* stage = s_pieces[wv];
         if (COLOR) { stage[lane] = gin.A; stage[64 + lane] = gin.B; }
