@@ -654,6 +654,9 @@ struct UpdateState {        // stage 2 done: volume reads requested
     u32x4 col;              // {Color_W, R, G, B} (fused colour; in flight until stage 3)
 };
 
+#ifndef TSDF_INTEGRATE_DESC_AHEAD
+#define TSDF_INTEGRATE_DESC_AHEAD 1 // the item descriptor of item j+1 is requested at the end of item j's stage 1
+#endif
 #ifndef TSDF_INTEGRATE_PRIO_LEVEL
 #define TSDF_INTEGRATE_PRIO_LEVEL 3
 #endif
@@ -796,6 +799,21 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         seg_end = __builtin_amdgcn_readfirstlane(s_vstart[sg + 1]);
         seg_delta = s_delta[sg];
     };
+    // One item's descriptor: wave-uniform, one scalar 32-byte load (no item left: entry 0, masked by the caller).
+    auto fetch_desc = [&](int j) {
+        unsigned entry = 0u;
+        if (j < cnt) {
+            const unsigned v = wg_first + (unsigned)wv + NW * (unsigned)j;
+            if (__builtin_expect(v >= seg_end, 0)) locate(v);
+            entry = v + seg_delta;
+        }
+        return list[__builtin_amdgcn_readfirstlane(entry)];
+    };
+#if TSDF_INTEGRATE_DESC_AHEAD
+    // ... requested one item ahead: stage 1 used to open with the load and an s_waitcnt lgkmcnt(0) right behind it -- a
+    // trip to L2 at the stage's raised priority in front of every item
+    ItemDesc dnext = fetch_desc(0);
+#endif
     auto stage1 = [&](int j, GatherState& g /*out: item j*/) {
         // Stage 1 runs at raised wave priority: it ends in the gathers, the longest trip of an item (64 scattered records
         // through L1 / L2), and a wavefront on its way to them should not queue behind the arithmetic of its four
@@ -809,13 +827,11 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL);
 #endif
         const bool have = j < cnt;
-        unsigned entry = 0u;                                    // (no item left: entry 0, masked below)
-        if (have) {
-            const unsigned v = wg_first + (unsigned)wv + NW * (unsigned)j;
-            if (__builtin_expect(v >= seg_end, 0)) locate(v);
-            entry = v + seg_delta;
-        }
-        const ItemDesc ds = list[__builtin_amdgcn_readfirstlane(entry)];    // wave-uniform: one scalar 32-byte load
+#if TSDF_INTEGRATE_DESC_AHEAD
+        const ItemDesc ds = dnext;                              // requested at the end of the previous item's stage 1
+#else
+        const ItemDesc ds = fetch_desc(j);
+#endif
         unsigned long long okm;
         unsigned pixb;
         project_item<KSTD, KTAB>(pc, ds, s_tab, lane, g.pcx, g.pcy, g.pcz, okm, pixb);
@@ -842,6 +858,9 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             const u32x3 b3 = __builtin_amdgcn_raw_buffer_load_b96(pn_rsrc, (int)rb, 0, 0);
             g.A = u32x4{a3.x, a3.y, a3.z, 0u}; g.B = u32x4{b3.x, b3.y, b3.z, 0u};
         }
+#if TSDF_INTEGRATE_DESC_AHEAD
+        dnext = fetch_desc(j + 1);
+#endif
 #if TSDF_INTEGRATE_PRIO & 5
         __builtin_amdgcn_s_setprio(0);
 #endif
