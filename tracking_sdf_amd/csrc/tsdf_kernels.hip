@@ -682,6 +682,14 @@ __device__ __forceinline__ float band_weight(float d, float eps) {
     return EXPPOLY ? (float)exp_taylor8(xarg) : (float)exp(xarg);
 }
 
+// floor(n * i / per) for the workgroup's share of its XCD's part of the list (n < 2^26 items, i <= per < 2^12): one f64
+// division instead of the 64-bit integer division's ~150 instructions in every wavefront's preamble.  Exact: n * i < 2^38
+// is a double, and a quotient that is not an integer lies at least 1 / per away from one -- far outside the division's
+// rounding.  Every workgroup uses the same expression, so neighbouring shares meet.
+__device__ __forceinline__ unsigned share_split(unsigned n, unsigned i, unsigned per) {
+    return (unsigned)(((double)n * (double)i) / (double)per);
+}
+
 // The list as list_rows_kernel left it: band b's items in [base[b], base[b] + fill[b]), then the overflow region.
 // Segment table (kBins + 1 segments): first VIRTUAL index of each segment (the list without its holes) and what to
 // add to a virtual index to get the list entry.  Workgroup 0 also prepares the bookkeeping set of the NEXT launch.
@@ -765,8 +773,8 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     const unsigned x_hi = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd + 1])) >> 24);
     // The workgroup's contiguous share of the work list, dealt to its wavefronts ITEM BY ITEM: at any moment the NW
     // wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring voxel rows.
-    const unsigned wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * in_xcd) / per_xcd)));
-    const unsigned wg_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * (in_xcd + 1)) / per_xcd)));
+    const unsigned wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + share_split(x_hi - x_lo, in_xcd, per_xcd)));
+    const unsigned wg_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + share_split(x_hi - x_lo, in_xcd + 1u, per_xcd)));
     const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
     unsigned n_own = 0, n_halo = 0;
     const unsigned long long loop_t0 = __builtin_amdgcn_s_memrealtime();      // for the XCD shares of the next launch
@@ -1139,8 +1147,8 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     const unsigned xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const unsigned x_lo = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd])) >> 24);
     const unsigned x_hi = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd + 1])) >> 24);
-    const unsigned wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * in_xcd) / per_xcd)));
-    const unsigned wg_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + (unsigned)(((unsigned long long)(x_hi - x_lo) * (in_xcd + 1)) / per_xcd)));
+    const unsigned wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + share_split(x_hi - x_lo, in_xcd, per_xcd)));
+    const unsigned wg_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + share_split(x_hi - x_lo, in_xcd + 1u, per_xcd)));
     const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
     unsigned n_own = 0, n_halo = 0;
     const unsigned long long loop_t0 = __builtin_amdgcn_s_memrealtime();      // for the XCD shares of the next launch
