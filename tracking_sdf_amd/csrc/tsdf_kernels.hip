@@ -157,7 +157,7 @@ hipError_t launch_pack(hipStream_t s, const PackArgs& a) {
 #endif
 constexpr int kClipBlock = TSDF_CLIP_BLOCK;      // rows (threads) per workgroup of list_rows_kernel
 #ifndef TSDF_INTEGRATE_MIN_WAVES
-#define TSDF_INTEGRATE_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
+#define TSDF_INTEGRATE_MIN_WAVES 5   // waves per SIMD the register allocator must leave room for (<= 96 VGPRs; the peeled pipeline took 108 at 4)
 #endif
 
 struct IntegrateTiling {
@@ -654,6 +654,9 @@ struct UpdateState {        // stage 2 done: volume reads requested
     u32x4 col;              // {Color_W, R, G, B} (fused colour; in flight until stage 3)
 };
 
+#ifndef TSDF_INTEGRATE_PEEL
+#define TSDF_INTEGRATE_PEEL 1       // the software pipeline's fill and drain written out (see the pipeline loop)
+#endif
 #ifndef TSDF_INTEGRATE_DESC_AHEAD
 #define TSDF_INTEGRATE_DESC_AHEAD 1 // the item descriptor of item j+1 is requested at the end of item j's stage 1
 #endif
@@ -1027,6 +1030,31 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     unsigned long long rt0 = 0, ct0 = 0;
     if (stamp) { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) : : "memory"); ct0 = clock_now(); }
 #endif
+#if TSDF_INTEGRATE_PEEL && !TSDF_INTEGRATE_DEBUG
+    // The pipeline's fill and drain, peeled: the rolled loop below runs cnt + 2 (or 3) steps of three stages each, i.e.
+    // 2-3 steps' worth of stages on items that do not exist -- with ~38 items per wavefront that is 6 % of all issued
+    // instructions.  While the kernel's stages queued behind each other's arithmetic that changed nothing (measured in
+    // the round's first half); with the graded priorities the kernel sits within ~10 % of its issue floor and the peeled
+    // form is worth 0.8 us (105.3 -> 104.5 us, 4 of 4 alternations).  The steady part is the same two-step rotation.
+    static_assert(TSDF_INTEGRATE_DEPTH == 1, "the peeled pipeline is written for two rotating update states");
+    if (cnt >= 2) {
+        stage1(0, G[0]);
+        stage1(1, G[1]); stage2(G[0], U[1]);
+        int j = 2;
+        for (; j + 1 < cnt; j += 2) {
+            stage1(j, G[0]);     stage2(G[1], U[0]); stage3(U[1]);
+            stage1(j + 1, G[1]); stage2(G[0], U[1]); stage3(U[0]);
+        }
+        if (j < cnt) {           // an odd item count: one more full step, then the drain
+            stage1(j, G[0]); stage2(G[1], U[0]); stage3(U[1]);
+            stage2(G[0], U[1]); stage3(U[0]);
+            stage3(U[1]);
+        } else {
+            stage2(G[1], U[0]); stage3(U[1]);
+            stage3(U[0]);
+        }
+    } else
+#endif
     for (int j = 0; j < cnt + 1 + TSDF_INTEGRATE_DEPTH; j += PERIOD) {
 #pragma unroll
         for (int q = 0; q < PERIOD; ++q) {
@@ -1122,7 +1150,7 @@ template <bool COLOR> struct QueueEntry { typedef u32x4 T; };     // {voxel, d b
 template <> struct QueueEntry<false> { typedef u32x2 T; };        // {voxel, d bits}
 
 template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
-__global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_queue_kernel(
+__global__ __launch_bounds__(kIntegrateBlock, 4) void integrate_queue_kernel(
     IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ set,
     unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
     float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
