@@ -654,6 +654,9 @@ struct UpdateState {        // stage 2 done: volume reads requested
     u32x4 col;              // {Color_W, R, G, B} (fused colour; in flight until stage 3)
 };
 
+#ifndef TSDF_INTEGRATE_SKIP_S2
+#define TSDF_INTEGRATE_SKIP_S2 1    // stage 2's un-shuffle and arithmetic only for items with a projected lane (the volume loads stay unconditional)
+#endif
 #ifndef TSDF_INTEGRATE_PEEL
 #define TSDF_INTEGRATE_PEEL 1       // the software pipeline's fill and drain written out (see the pipeline loop)
 #endif
@@ -882,6 +885,17 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 #if TSDF_INTEGRATE_PRIO & 8
         __builtin_amdgcn_s_setprio(TSDF_INTEGRATE_PRIO_LEVEL_S2);
 #endif
+        float d = 0.f, wn = 1.0f, wc = 0.f;
+        unsigned rgbv = 0u;
+        unsigned long long okm = 0ull;
+        // An item none of whose lanes projects into the image skips the un-shuffle and the distances; like stage 3's skip
+        // this leaves the vector-memory operations of a step where they are.  Putting the volume loads or the stores of
+        // items that update nothing behind the same kind of branch costs 3-10 us: hipcc then waits for the smallest
+        // outstanding count at every use (r04_integrate_fixed_costs.json).
+#if TSDF_INTEGRATE_SKIP_S2
+        if (gin.live != 0ull)
+#endif
+        {
         u32x4* stage = s_pieces[wv];
         if (COLOR) { stage[lane] = gin.A; stage[64 + lane] = gin.B; }
         else {
@@ -909,22 +923,24 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         // projectivePointToPlaneDistance, sdf.h:177-181 (Eigen dot: a0*b0 + (a1*b1 + a2*b2))
         const double dx = (double)Px - gin.pcx, dy = (double)Py - gin.pcy, dz = (double)Pz - gin.pcz;
         const double p2p = dx * (double)Nx + (dy * (double)Ny + dz * (double)Nz);
-        float d = (float)p2p;                                               // sdf.cpp:274
-        unsigned long long okm = gin.live & ~nanm & ~lanes(d > delta);      // sdf.cpp:280-283
+        d = (float)p2p;                                               // sdf.cpp:274
+        okm = gin.live & ~nanm & ~lanes(d > delta);      // sdf.cpp:280-283
         const unsigned long long bandm = okm & lanes(d >= eps);             // sdf.cpp:277-279 (d <= delta holds in okm)
 #if TSDF_INTEGRATE_DEBUG
         if (p.debug & 2) okm = 0ull;                                        // timing experiment only: no volume RMW
 #endif
         // sdf.cpp:294-299: wc = (float)(w_new * cosine).  For w_new == 1 that is the pre-rounded cosine of the record;
         // a wavefront with lanes in the exp() band recomputes the f64 cosine from the normal for those lanes.
-        float wn = 1.0f, wc = COLOR ? __uint_as_float(N.w) : 0.f;
+        wc = COLOR ? __uint_as_float(N.w) : 0.f;
         if (bandm != 0ull) {
             wn = __uint_as_float(select_by_mask(bandm, __float_as_uint(band_weight<EXPPOLY>(d, eps)), 0x3f800000u));
             if (COLOR)
                 wc = __uint_as_float(select_by_mask(bandm, __float_as_uint((float)((double)wn * pixel_cosine(Nx, Ny, Nz))),
                                                     __float_as_uint(wc)));
         }
-        if (COLOR) { u.rgb = P.w; u.wc = wc; }
+        rgbv = P.w;
+        }
+        if (COLOR) { u.rgb = rgbv; u.wc = wc; }
         d = d < neg_delta ? neg_delta : d;                                  // sdf.cpp:285-287
         u.d_new = d; u.w_new = wn;
         u.live = okm;
