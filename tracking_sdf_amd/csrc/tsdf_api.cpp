@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -807,6 +808,33 @@ int fetch_counters(tsdf_handle* h) {
             for (size_t w = 0; w < 4 * (size_t)h->integrate_blocks; ++w)
                 for (int q = 0; q < 6; ++q) t[q] += h->wg_counts_host[nw + 6 * w + q];
             std::fprintf(stderr, "LIVEHIST items by updated lanes: 0: %llu  1-16: %llu  17-32: %llu  33-48: %llu  49-63: %llu  64: %llu\n", t[0], t[1], t[2], t[3], t[4], t[5]);
+        }
+    }
+    {   // TSDF_WG_FINISH=1 with a -DTSDF_WG_FINISH build: when the wavefronts of the LAST integrate launch ended their item loops
+        static const bool wg_finish = [] { const char* e = std::getenv("TSDF_WG_FINISH"); return e && std::atoi(e) != 0; }();
+        if (wg_finish) {
+            const size_t nwv = 4 * (size_t)h->integrate_blocks;
+            unsigned long long t0 = ~0ull;
+            for (size_t w = 0; w < nwv; ++w) if (h->wg_counts_host[nw + 6 * w]) t0 = std::min(t0, h->wg_counts_host[nw + 6 * w]);
+            std::vector<double> end, start;
+            double by_gen[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t n_gen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t w = 0; w < nwv; ++w) {
+                if (!h->wg_counts_host[nw + 6 * w]) continue;
+                const double e = 0.01 * (double)(h->wg_counts_host[nw + 6 * w + 1] - t0);
+                end.push_back(e); start.push_back(0.01 * (double)(h->wg_counts_host[nw + 6 * w] - t0));
+                const size_t gen = std::min<size_t>(7, ((w / 4) >> 3) / 32);
+                by_gen[gen] += e; n_gen[gen] += 1;
+            }
+            std::sort(end.begin(), end.end()); std::sort(start.begin(), start.end());
+            if (!end.empty()) {
+                double mean = 0; for (double e : end) mean += e; mean /= (double)end.size();
+                auto q = [&](const std::vector<double>& v, double f) { return v[std::min(v.size() - 1, (size_t)(f * (double)v.size()))]; };
+                std::fprintf(stderr, "WGFINISH wavefronts %zu: loop start p50 %.1f max %.1f us; loop end mean %.1f min %.1f p10 %.1f p25 %.1f p50 %.1f p75 %.1f p90 %.1f max %.1f us;",
+                             end.size(), q(start, 0.5), start.back(), mean, end.front(), q(end, 0.1), q(end, 0.25), q(end, 0.5), q(end, 0.75), q(end, 0.9), end.back());
+                std::fprintf(stderr, " by workgroup generation (index in the XCD / 32):");
+                for (int g = 0; g < 8; ++g) if (n_gen[g]) std::fprintf(stderr, " %.1f", by_gen[g] / (double)n_gen[g]);
+                std::fprintf(stderr, "\n");
+            }
         }
     }
     unsigned long long own = 0, halo = 0;

@@ -657,6 +657,9 @@ struct UpdateState {        // stage 2 done: volume reads requested
 #ifndef TSDF_INTEGRATE_SKIP_S2
 #define TSDF_INTEGRATE_SKIP_S2 1    // stage 2's un-shuffle and arithmetic only for items with a projected lane (the volume loads stay unconditional)
 #endif
+#ifndef TSDF_INTEGRATE_INTERLEAVE
+#define TSDF_INTEGRATE_INTERLEAVE 1  // the workgroups of an XCD walk its part of the list together (0: one stretch per workgroup)
+#endif
 #ifndef TSDF_INTEGRATE_PEEL
 #define TSDF_INTEGRATE_PEEL 1       // the software pipeline's fill and drain written out (see the pipeline loop)
 #endif
@@ -777,11 +780,26 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     // table's loads changes nothing: measured.)
     const unsigned x_lo = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd])) >> 24);
     const unsigned x_hi = (unsigned)(((unsigned long long)n_items * (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_fb[xcd + 1])) >> 24);
-    // The workgroup's contiguous share of the work list, dealt to its wavefronts ITEM BY ITEM: at any moment the NW
-    // wavefronts of a workgroup work on NW consecutive items, i.e. on neighbouring voxel rows.
+    // Items are dealt to the wavefronts of a workgroup ITEM BY ITEM: at any moment its NW wavefronts work on NW consecutive
+    // items, i.e. on neighbouring voxel rows.
+#if TSDF_INTEGRATE_INTERLEAVE
+    // The XCD's workgroups walk its part of the list TOGETHER: workgroup w takes the items [x_lo + (j * per_xcd + w) * NW,
+    // + NW) for j = 0, 1, ...  Neighbouring items cost alike (12 % of the items update nothing, a quarter touches 1-16
+    // voxels, and they come in runs), so with one contiguous stretch per workgroup (rounds 1-3) stretches of equal length
+    // differed in cost: the wavefronts' item loops ended 101 us into the launch at the latest and after 82 on average
+    // (tools/wg_finish_probe.py).  Every workgroup now gets an even sample of the band -- 95 us at the latest -- and the
+    // XCD's 160 workgroups touch the same part of the image at the same time.  -2 % at 512^3, -2.5 % at 1024^3, both
+    // scenes, with and without colour (r04_integrate_fixed_costs.json; what did NOT work there: item pools with atomic
+    // cursors, shares per workgroup generation, shares per workgroup by feedback).
+    const unsigned v_stride = per_xcd * NW, v_first = x_lo + in_xcd * NW + (unsigned)wv, v_lim = x_hi;
+    const int cnt = __builtin_amdgcn_readfirstlane(v_first < x_hi ? (int)share_split(x_hi - v_first + v_stride - 1u, 1u, v_stride) : 0);
+#else
+    // one contiguous stretch of the XCD's part per workgroup
     const unsigned wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + share_split(x_hi - x_lo, in_xcd, per_xcd)));
     const unsigned wg_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_lo + share_split(x_hi - x_lo, in_xcd + 1u, per_xcd)));
-    const int cnt = wg_last > wg_first + (unsigned)wv ? (int)((wg_last - wg_first - (unsigned)wv + NW - 1u) / NW) : 0;
+    const unsigned v_stride = NW, v_first = wg_first + (unsigned)wv, v_lim = wg_last;
+    const int cnt = wg_last > v_first ? (int)((wg_last - v_first + NW - 1u) / NW) : 0;
+#endif
     unsigned n_own = 0, n_halo = 0;
     const unsigned long long loop_t0 = __builtin_amdgcn_s_memrealtime();      // for the XCD shares of the next launch
 
@@ -814,19 +832,19 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         seg_delta = s_delta[sg];
     };
     // One item's descriptor: wave-uniform, one scalar 32-byte load (no item left: entry 0, masked by the caller).
-    auto fetch_desc = [&](int j) {
+    auto fetch_desc = [&](unsigned v) {
         unsigned entry = 0u;
-        if (j < cnt) {
-            const unsigned v = wg_first + (unsigned)wv + NW * (unsigned)j;
+        if (v < v_lim) {
             if (__builtin_expect(v >= seg_end, 0)) locate(v);
             entry = v + seg_delta;
         }
         return list[__builtin_amdgcn_readfirstlane(entry)];
     };
+    auto item_v = [&](int j) { return v_first + v_stride * (unsigned)j; };           // virtual index of this wavefront's item j
 #if TSDF_INTEGRATE_DESC_AHEAD
     // ... requested one item ahead: stage 1 used to open with the load and an s_waitcnt lgkmcnt(0) right behind it -- a
     // trip to L2 at the stage's raised priority in front of every item
-    ItemDesc dnext = fetch_desc(0);
+    ItemDesc dnext = fetch_desc(item_v(0));
 #endif
     auto stage1 = [&](int j, GatherState& g /*out: item j*/) {
         // Stage 1 runs at raised wave priority: it ends in the gathers, the longest trip of an item (64 scattered records
@@ -844,7 +862,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
 #if TSDF_INTEGRATE_DESC_AHEAD
         const ItemDesc ds = dnext;                              // requested at the end of the previous item's stage 1
 #else
-        const ItemDesc ds = fetch_desc(j);
+        const ItemDesc ds = fetch_desc(item_v(j));
 #endif
         unsigned long long okm;
         unsigned pixb;
@@ -873,7 +891,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
             g.A = u32x4{a3.x, a3.y, a3.z, 0u}; g.B = u32x4{b3.x, b3.y, b3.z, 0u};
         }
 #if TSDF_INTEGRATE_DESC_AHEAD
-        dnext = fetch_desc(j + 1);
+        dnext = fetch_desc(item_v(j + 1));
 #endif
 #if TSDF_INTEGRATE_PRIO & 5
         __builtin_amdgcn_s_setprio(0);
@@ -1116,6 +1134,12 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     }
 #endif
 
+#ifdef TSDF_WG_FINISH
+    if (lane == 0) {     // measurement build: when this wavefront's item loop began and ended (100 MHz ticks), last launch
+        unsigned long long* w = counters + 2 * (size_t)gridDim.x + 6 * ((size_t)blockIdx.x * NW + (size_t)wv);
+        w[0] = loop_t0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = (unsigned long long)cnt;
+    }
+#endif
     if (wv == 0 && lane == 0)
         atomicAdd(reinterpret_cast<unsigned long long*>(xcd_fb + kFbTicksWord) + xcd, __builtin_amdgcn_s_memrealtime() - loop_t0 + 1ull);
     // Update counts (wave-uniform already): LDS across the waves, then the workgroup adds to ITS OWN pair of cumulative
