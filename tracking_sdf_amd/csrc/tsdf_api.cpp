@@ -833,6 +833,15 @@ int fetch_counters(tsdf_handle* h) {
                              end.size(), q(start, 0.5), start.back(), mean, end.front(), q(end, 0.1), q(end, 0.25), q(end, 0.5), q(end, 0.75), q(end, 0.9), end.back());
                 std::fprintf(stderr, " by workgroup generation (index in the XCD / 32):");
                 for (int g = 0; g < 8; ++g) if (n_gen[g]) std::fprintf(stderr, " %.1f", by_gen[g] / (double)n_gen[g]);
+                double x_max[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t x_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t w = 0; w < nwv; ++w) {
+                    if (!h->wg_counts_host[nw + 6 * w]) continue;
+                    const double e = 0.01 * (double)(h->wg_counts_host[nw + 6 * w + 1] - t0);
+                    const size_t x = (w / 4) & 7;
+                    x_max[x] = std::max(x_max[x], e); x_sum[x] += e; x_n[x] += 1;
+                }
+                std::fprintf(stderr, "; by XCD mean/max:");
+                for (int x = 0; x < 8; ++x) if (x_n[x]) std::fprintf(stderr, " %.1f/%.1f", x_sum[x] / (double)x_n[x], x_max[x]);
                 std::fprintf(stderr, "\n");
             }
         }
