@@ -144,7 +144,7 @@ hipError_t launch_pack(hipStream_t s, const PackArgs& a) {
 //                      its 64-voxel chunks go to the work list, into the region of the image band the row
 //                      projects to.  Every listed voxel still runs the reference's exact tests, so the
 //                      cull never changes a result.
-//   integrate_kernel   persistent workgroups take contiguous shares of the list; one item = 64 consecutive k of
+//   integrate_kernel   every XCD takes a contiguous part of the list, its persistent workgroups walk it together; one item = 64 consecutive k of
 //                      one row = one 512-byte {D,W} segment (+1 KiB colour): perfectly coalesced RMW.
 //                      The row's share of rot_inv * g (its first two terms, identical for all k) travels in the
 //                      item descriptor (one scalar 32-byte load per item), the third term comes from a table of
@@ -772,8 +772,8 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     make_proj_const(p, tl, lane, pc);
     // Workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD one contiguous eighth of the
     // list = one band of the image, so the pixel records it gathers stay in its own L2.
-    // The XCD's part of the list [x_lo, x_hi) follows the shares of update_xcd_shares(); its gridDim.x / 8 workgroups
-    // split it evenly.
+    // The XCD's part of the list [x_lo, x_hi) follows the shares of update_xcd_shares(); how its gridDim.x / 8 workgroups
+    // share it: below.
     const unsigned xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     // (readfirstlane: xcd_fb is written at the end of this kernel, so the compiler may fetch the shares with a vector
     // load and then takes everything derived from them for per-lane values.  Requesting them in front of the segment
