@@ -739,3 +739,42 @@ def test_work_list_regions_follow_the_previous_frame_and_overflow_when_it_lies()
         counts.append(n_or)
     assert max(counts) > 20 * (min(counts) + 1), counts          # the launches really differ
     assert_volume_equal(go, oo, m)
+
+
+def test_unnormalised_normals_in_the_exp_band():
+    """sdf.cpp:294 divides by n.norm(): the input normals need not be unit vectors.  Their length enters the distance
+    (d = (P - voxel) . n), so a normal far from 1 moves its pixel's voxels out of the exp() band -- lengths within a
+    factor of a few keep some in it.  The band's colour weight (float)(w * |n_z| / |n|) is computed by the bare
+    square-root / division cores for normals of ordinary size and by sqrt() and '/' otherwise: both against the
+    oracle's libm, three frames, lengths from 2^-4 to 2^4 with a sprinkling of 2^+-30, 2^+-120, zero vectors and
+    infinite components."""
+    m = 48
+    seq, fr = frames(3, noise=True, holes=0.01)
+    rng = np.random.default_rng(11)
+    oo, ot = make_oracle(m, seq.K)
+    go, gt = make_gpu(m, seq.K)
+    for xyz, nrm, rgb in fr:
+        scale = np.exp2(rng.uniform(-4.0, 4.0, size=nrm.shape[:2])).astype(np.float32)
+        odd = rng.random(nrm.shape[:2])
+        scale[odd < 0.02] = np.float32(2.0 ** 30)
+        scale[(odd >= 0.02) & (odd < 0.04)] = np.float32(2.0 ** -30)
+        scale[(odd >= 0.04) & (odd < 0.05)] = np.float32(2.0 ** 120)
+        scale[(odd >= 0.05) & (odd < 0.06)] = np.float32(2.0 ** -120)
+        n2 = (nrm * scale[..., None]).astype(np.float32)
+        n2[(odd >= 0.06) & (odd < 0.07)] = 0.0
+        n2[(odd >= 0.07) & (odd < 0.08), 2] = np.inf
+        n2[(odd >= 0.08) & (odd < 0.09), 0] = -np.inf
+        with np.errstate(all="ignore"):
+            n_or = oo.update(ot, orc.Cloud(xyz, n2, rgb), with_color=True)
+        st = go.update(gt, xyz, n2, rgb)
+        assert st["n_updated"] == n_or
+    D, W = go.download()
+    uW = ulp_diff(W, oo.W)
+    assert uW.max() <= 1 and ulp_diff(D, oo.D)[uW == 0].max() == 0
+    cw, r, g, b = go.download_color()
+    same = uW == 0
+    for got, want in ((cw, oo.Color_W), (r, oo.R), (g, oo.G), (b, oo.B)):
+        a, w = got[same], want[same]
+        assert np.array_equal(np.isnan(a), np.isnan(w))
+        ok = ~np.isnan(w)
+        assert np.array_equal(a[ok].view(np.uint32), w[ok].view(np.uint32))

@@ -44,6 +44,34 @@ __device__ __forceinline__ double pixel_cosine(float nx, float ny, float nz) {
     return fabs(0.0 * x + (0.0 * y + 1.0 * z)) / sqrt(x * x + (y * y + z * z));
 }
 
+// The same value for normals of ordinary size, without the wrappers hipcc puts around sqrt() and '/': its correctly
+// rounded cores as they stand in this build's ISA (v_rsq_f64 + the coupled iteration with two residual corrections;
+// v_rcp_f64 + two Newton steps, quotient, one residual correction), minus the range scaling (v_div_scale / v_ldexp),
+// which only acts outside 2^+-767 / 2^+-1022, and minus the special-case selects (v_div_fixup, the 0 / inf pass-through).
+// With x, y finite, fabs(0*x + (0*y + z)) is |z|.  Valid for 2^-200 <= n2 <= 2^200 (the caller tests n2, which also
+// rules out NaN and infinite components); bit-identical to pixel_cosine() there -- the fuzz and parity tests compare
+// the colour weights of band voxels with the oracle's libm sqrt and division.
+__device__ __forceinline__ double pixel_cosine_core(double z, double n2) {
+    const double y = __builtin_amdgcn_rsq(n2);
+    double g = n2 * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, n2);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, n2);
+    g = __builtin_fma(d, h, g);                               // sqrt(n2)
+    const double a = __builtin_fabs(z);
+    double q = __builtin_amdgcn_rcp(g);
+    double e = __builtin_fma(-g, q, 1.0);
+    q = __builtin_fma(q, e, q);
+    e = __builtin_fma(-g, q, 1.0);
+    q = __builtin_fma(q, e, q);
+    const double t = a * q;
+    const double res = __builtin_fma(-g, t, a);
+    return __builtin_fma(res, q, t);
+}
+
 // ------------------------------------------------------------------------------------------------
 // volume fill: D = width+height+depth, W = 0, Color_W = 0, R = G = B = 0.4f   (sdf.cpp:28-34)
 
@@ -657,6 +685,9 @@ struct UpdateState {        // stage 2 done: volume reads requested
 #ifndef TSDF_INTEGRATE_SKIP_S2
 #define TSDF_INTEGRATE_SKIP_S2 1    // stage 2's un-shuffle and arithmetic only for items with a projected lane (the volume loads stay unconditional)
 #endif
+#ifndef TSDF_INTEGRATE_COSINE_CORE
+#define TSDF_INTEGRATE_COSINE_CORE 1 // the exp() band's f64 cosine by the bare sqrt / division cores when the normal is of ordinary size
+#endif
 #ifndef TSDF_INTEGRATE_INTERLEAVE
 #define TSDF_INTEGRATE_INTERLEAVE 1  // the workgroups of an XCD walk its part of the list together (0: one stretch per workgroup)
 #endif
@@ -952,9 +983,19 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
         wc = COLOR ? __uint_as_float(N.w) : 0.f;
         if (bandm != 0ull) {
             wn = __uint_as_float(select_by_mask(bandm, __float_as_uint(band_weight<EXPPOLY>(d, eps)), 0x3f800000u));
-            if (COLOR)
-                wc = __uint_as_float(select_by_mask(bandm, __float_as_uint((float)((double)wn * pixel_cosine(Nx, Ny, Nz))),
-                                                    __float_as_uint(wc)));
+            if (COLOR) {
+#if TSDF_INTEGRATE_COSINE_CORE
+                const double nxd = (double)Nx, nyd = (double)Ny, nzd = (double)Nz;
+                const double n2 = nxd * nxd + (nyd * nyd + nzd * nzd);
+                const unsigned long long plain = lanes(n2 >= 0x1p-200) & lanes(n2 <= 0x1p200);
+                double cosine;
+                if (__builtin_expect((bandm & ~plain) == 0ull, 1)) cosine = pixel_cosine_core(nzd, n2);
+                else cosine = pixel_cosine(Nx, Ny, Nz);
+#else
+                const double cosine = pixel_cosine(Nx, Ny, Nz);
+#endif
+                wc = __uint_as_float(select_by_mask(bandm, __float_as_uint((float)((double)wn * cosine)), __float_as_uint(wc)));
+            }
         }
         rgbv = P.w;
         }
