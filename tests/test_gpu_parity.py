@@ -778,3 +778,26 @@ def test_unnormalised_normals_in_the_exp_band():
         assert np.array_equal(np.isnan(a), np.isnan(w))
         ok = ~np.isnan(w)
         assert np.array_equal(a[ok].view(np.uint32), w[ok].view(np.uint32))
+
+
+@pytest.mark.parametrize("per_cu,m", [(1, 40), (3, 64), (7, 64), (2, 96)])
+def test_the_volume_does_not_depend_on_the_integrate_grid(per_cu, m, monkeypatch):
+    """The workgroups of an XCD walk its part of the work list together (workgroup w takes the items
+    [(j * per_xcd + w) * 4, +4)), the XCD shares follow the last launch's timers: every voxel belongs to exactly one
+    item, so the volume must not depend on how many workgroups there are -- 1, 2, 3 or 7 per CU instead of 5, over
+    four frames (the feedback has moved the shares by then), against the default grid bit for bit."""
+    seq, fr = frames(4, noise=True, holes=0.02)
+
+    def run():
+        go, gt = make_gpu(m, seq.K)
+        n = [go.update(gt, *f)["n_updated"] for f in fr]
+        out = (n, go.download(), go.download_color())
+        go.close()
+        return out
+    monkeypatch.delenv("TSDF_INTEGRATE_BLOCKS_PER_CU", raising=False)
+    want = run()
+    monkeypatch.setenv("TSDF_INTEGRATE_BLOCKS_PER_CU", str(per_cu))
+    got = run()
+    assert want[0] == got[0]
+    for a, b in zip(want[1] + want[2], got[1] + got[2]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
