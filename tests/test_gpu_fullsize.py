@@ -1,7 +1,15 @@
-"""Full-size (BASELINE.json) configurations checked through size-independent properties -- the oracle would
-take minutes per frame here, so nothing in this file calls it.
+"""Full-size (BASELINE.json) configurations.
 
-Properties of SDF::update (sdf.cpp:289-292) that hold bit-exactly in float arithmetic:
+(1) HIP path against the CPU oracle AT the configurations' sizes (configs 2, 3, 4 and config 5's image size at the
+largest volume the oracle fits in host memory): the regimes that exist only at size -- 8 chunks per voxel row, ~195 k work
+items over 64 band regions + overflow, 1280 persistent workgroups with XCD feedback, 714 tracker workgroups over 8 shards,
+640x480 / 1280x960 pixel-record layouts -- are checked bit for bit against sdf.cpp:224-315 / camera_tracking.cpp:66-363
+as restated in oracle/tsdf_oracle.c (the oracle needs 61 ms per update and 11 ms per tracker call at 512^3 on the
+box's 16 host threads).
+
+(2) Size-independent properties where no oracle fits (2048^3: 206 GB of host arrays, and the reference's own int
+voxel count wraps at m >= 1291, sdf.cpp:9).  Properties of SDF::update (sdf.cpp:289-292) that hold bit-exactly in float
+arithmetic:
   * integrating the SAME frame at the SAME pose twice doubles W exactly and leaves D unchanged
     ((W d + w d')/(W + w) with identical terms is exact: x + x and 2x/2 never round);
   * the set of updated voxels is a function of pose and image only (counter identical both times);
@@ -14,6 +22,7 @@ import numpy as np
 import pytest
 
 from tracking_sdf_amd import synth
+from util import assert_volume_equal_at_size, sym_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -154,6 +163,83 @@ def test_config5_shapes_1280x960_at_1024():
 
 
 FR3_K = np.array([[535.4, 0.0, 320.1], [0.0, 539.2, 247.6], [0.0, 0.0, 1.0]])
+
+
+def mem_available_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+# (config of BASELINE.json, m, image, intrinsics, host GB the oracle + the downloads need)
+ORACLE_AT_SIZE = [
+    pytest.param(256, 640, 480, None, 2, id="config2-256-640x480"),
+    pytest.param(512, 640, 480, None, 12, id="config3-512-640x480"),
+    pytest.param(1024, 640, 480, FR3_K, 60, id="config4-1024-640x480-fr3"),
+    pytest.param(1024, 1280, 960, None, 60, id="config5-image-1280x960-at-1024"),
+]
+CARRY_THREADS = 4
+
+
+@pytest.mark.parametrize("m,w,h,K,need_gb", ORACLE_AT_SIZE)
+def test_hip_path_equals_the_oracle_at_baseline_size(m, w, h, K, need_gb):
+    """SDF::update (sdf.cpp:224-315) and estimate_new_position (camera_tracking.cpp:66-245) at the sizes BASELINE.json
+    names, HIP against the oracle on the same inputs: three noisy frames with 2 % holes fused at ground-truth poses (the
+    third with the camera rolled by 35 degrees: row-major pixel records, other image bands), n_updated equal per frame,
+    D / W / Color_W / R / G / B bit-exact (exp() band <= 1 ulp of W); then, on the oracle's volume, one
+    Gauss-Newton pass (counts equal, A, b <= 1e-11) and one whole tracker call (same iterations and stop flag, pose
+    <= 1e-9) at the reference's thread-local carry state for CARRY_THREADS OpenMP threads."""
+    import oracle as orc
+    import tracking_sdf_amd as ts
+    if mem_available_gb() < need_gb:
+        pytest.skip(f"{need_gb} GB of host memory needed for the oracle's {m}^3 arrays next to the downloaded volume "
+                    f"({mem_available_gb():.0f} GB available): BASELINE config {m}^3 {w}x{h} not oracle-checked on this host")
+    seq = synth.Sequence(n_frames=4, width=w, height=h, noise=True, holes=0.02, step=4, K=K)
+    a = np.deg2rad(35.0)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    fused = [(seq.R[0], seq.t[0], seq.frame(0)), (seq.R[1], seq.t[1], seq.frame(1)),
+             (seq.R[2] @ Rz, seq.t[2], synth.render_frame(seq.R[2] @ Rz, seq.t[2], seq.K, w, h, noise=True, holes=0.02,
+                                                          rng=np.random.default_rng(5)))]
+    oo = orc.SDF(m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025, with_global_coords=(m <= 512))
+    ot = orc.CameraTracking(oo)
+    ot.set_K(seq.K)
+    go = ts.SDF(m, with_color=True, carry_threads=CARRY_THREADS)
+    gt = ts.CameraTracking(sdf=go)
+    gt.set_K(seq.K)
+    for R, t, (xyz, nrm, rgb) in fused:
+        ot.set_camera_transformation(R, t)
+        gt.set_camera_transformation(R, t)
+        n_or = oo.update(ot, orc.Cloud(xyz, nrm, rgb))
+        st = go.update(gt, xyz, nrm, rgb)
+        assert st["n_updated"] == n_or and st["n_voxels"] == m ** 3 and n_or > 0.02 * m ** 3
+    n_exp = assert_volume_equal_at_size(go, oo, color=True)
+    # the tracker on IDENTICAL volumes (the <= 1-ulp exp() voxels would otherwise show up in A at 1e-9)
+    if n_exp:
+        go.upload(oo.D, oo.W)
+    xyz = seq.frame(3)[0]
+    cloud = orc.Cloud(xyz)
+    ot.set_camera_transformation(seq.R[2], seq.t[2])
+    gt.set_camera_transformation(seq.R[2], seq.t[2])
+    A_o, b_o, st_o = ot.accumulate(oo, cloud, threads=CARRY_THREADS, stale_carry=True)
+    go.set_frame(xyz)
+    A_g, b_g, st_g = gt.accumulate()
+    assert st_g["n_samples"] == st_o["n_samples"] == -(-w // 3) * -(-h // 3)
+    for key in ("n_nan", "n_oog", "n_ok", "n_terms"):
+        assert st_g[key] == st_o[key], key
+    assert st_o["n_ok"] > 0.6 * st_o["n_samples"]
+    assert sym_rel_err(A_g, A_o) < 1e-11 and sym_rel_err(b_g, b_o) < 1e-11
+    so = ot.estimate_new_position(oo, cloud, threads=CARRY_THREADS, stale_carry=True)
+    sg = gt.estimate_new_position(go, xyz)
+    assert sg["iterations"] == so["iterations"] and bool(sg["stopped"]) == so["stopped"] and not so["nonfinite"]
+    assert sg["n_terms_last"] == so["n_terms_last"]
+    assert np.max(np.abs(gt.trans - ot.trans)) < 1e-9 and np.max(np.abs(gt.rot - ot.rot)) < 1e-9
+    assert np.linalg.norm(gt.trans - seq.t[3]) < np.linalg.norm(seq.t[2] - seq.t[3])       # and it moved the right way
+    go.close()
 
 
 def test_config4_workload_1024_cubed_with_colour_and_fr3_intrinsics():

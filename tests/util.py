@@ -45,3 +45,44 @@ def sym_rel_err(A, B):
     A = np.asarray(A, dtype=np.float64)
     B = np.asarray(B, dtype=np.float64)
     return float(np.max(np.abs(A - B)) / max(np.max(np.abs(B)), 1e-300))
+
+
+def volume_mismatch(got, want, chunk=1 << 24):
+    """(max ulp distance, number of differing elements) between two float32 arrays of any size, without whole-array
+    int64 temporaries: bit patterns are compared chunk by chunk and ulp distances are formed for the differing
+    elements only (512^3 = 134 M voxels per array, 1024^3 = 1.07 G)."""
+    got = np.asarray(got).reshape(-1)
+    want = np.asarray(want).reshape(-1)
+    assert got.dtype == np.float32 and want.dtype == np.float32 and got.size == want.size
+    worst, count = 0, 0
+    where = []
+    for a in range(0, got.size, chunk):
+        g, w = got[a:a + chunk], want[a:a + chunk]
+        ne = np.flatnonzero(g.view(np.uint32) != w.view(np.uint32))
+        if ne.size:
+            u = ulp_diff(g[ne], w[ne])
+            nz = u > 0                                     # +0 / -0 and NaN payloads are not differences
+            if nz.any():
+                worst = max(worst, int(u.max()))
+                count += int(nz.sum())
+                where.append(ne[nz] + a)
+    return worst, count, (np.concatenate(where) if where else np.zeros(0, dtype=np.int64))
+
+
+def assert_volume_equal_at_size(go, oo, color=True, max_exp_ulp=1, max_frac=1e-4):
+    """test_gpu_parity.assert_volume_equal's bar for volumes of BASELINE size: W bit-exact except
+    the rare voxels whose weight went through exp() (<= 1 ulp), D and the colour lanes identical wherever W is."""
+    D, W = go.download()
+    n = W.size
+    uW, nW, iW = volume_mismatch(W, oo.W)
+    assert uW <= max_exp_ulp, f"W differs by {uW} ulp"
+    assert nW / n < max_frac, f"{nW} of {n} voxels differ in W (expected only rare exp() last-bit cases)"
+    uD, nD, iD = volume_mismatch(D, oo.D)
+    assert uD <= 4 and np.isin(iD, iW).all(), f"D differs in {nD} voxels (max {uD} ulp), W in {nW}"
+    del D, W
+    if color:
+        got = go.download_color()
+        for g, want in zip(got, (oo.Color_W, oo.R, oo.G, oo.B)):
+            u, k, i = volume_mismatch(g, want)
+            assert u <= 4 and np.isin(i, iW).all(), f"a colour lane differs in {k} voxels (max {u} ulp), W in {nW}"
+    return nW
