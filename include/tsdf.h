@@ -45,8 +45,12 @@ extern "C" {
 #endif
 
 /* 2: tsdf_config.carry_threads, tsdf_preproc_params.grid_filter (the struct layouts changed: a caller built against
- * version 1 must be rebuilt; tsdf_abi_version() lets a loader refuse a mismatched library) */
-#define TSDF_ABI_VERSION 2
+ * version 1 must be rebuilt; tsdf_abi_version() lets a loader refuse a mismatched library)
+ * 3: BEHAVIOURAL: planes handed to tsdf_set_frame_device / tsdf_queue_frame_device stay borrowed past the next
+ * set_frame* call (their packing runs asynchronously inside the frame's integrate launch); tsdf_device_frame_released()
+ * says when they are free.  Version 2 promised "until the next set_frame* call": a caller that alternated two device
+ * buffers by that rule must ask tsdf_device_frame_released() (or keep three buffers) -- see tsdf_set_frame_device. */
+#define TSDF_ABI_VERSION 3
 
 typedef enum tsdf_status {
     TSDF_OK = 0,
@@ -138,9 +142,17 @@ int tsdf_get_pose(const tsdf_handle *h, double rot[9], double trans[3],
  * (tracking needs xyz only; integration needs nrm; rgb is needed only when with_color = 1).
  * tsdf_set_frame_device borrows DEVICE pointers (same layouts) whose contents must be complete when the call is made.
  * Nothing is launched by the call: the tracker's first pass reads its samples from the xyz plane and the pixel records
- * are packed inside the frame's integrate launch (workgroups appended to its first kernel, asynchronous), so the
- * buffers must stay valid and unchanged until the set_frame* call AFTER the next one, tsdf_synchronize or destroy
- * (TSDF_DEFER_PACK=0 in the environment of tsdf_create: packed by a launch of its own when the frame is set).
+ * are packed inside the frame's integrate launch (workgroups appended to its first kernel, asynchronous).
+ * BORROWING RULE (ABI version 3): the planes of the frame with serial s (tsdf_frame_serial() right after the call) must
+ * stay valid and unchanged until tsdf_device_frame_released() >= s, or tsdf_synchronize / tsdf_destroy.  In the loop
+ * set_frame_device(k) -> track -> integrate(k) -> set_frame_device(k+1) -> ... frame k becomes free a few microseconds
+ * into integrate(k)'s launch -- i.e. usually AFTER set_frame_device(k+1) has returned, and certainly by the time the
+ * first tsdf_track of frame k+1 has returned.  A producer that refills buffers on its own stream needs a ring of THREE
+ * device buffers to never wait (frame k+2 is written while frame k may still be read and frame k+1 is current), or two
+ * buffers and a poll of tsdf_device_frame_released() before each refill.  The reference's own contract for comparison:
+ * clouds are borrowed for the duration of estimate_new_position / update only (sdf.h:161-163).
+ * (TSDF_DEFER_PACK=0 in the environment of tsdf_create: packed by a launch of its own when the frame is set; the rule
+ * and tsdf_device_frame_released() are the same.)
  * The frame-side work of tsdf_set_frame / tsdf_set_depth_frame (staging copies, pre-processing, the packing
  * kernel) runs on an internal second stream, so setting frame k+1 right after tsdf_integrate(k) overlaps it
  * with that integration; the hot calls wait for it on the device. */
@@ -148,6 +160,13 @@ int tsdf_set_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uin
                    int32_t width, int32_t height);
 int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb,
                           int32_t width, int32_t height);
+/* Serial (as tsdf_frame_serial counts; a queued frame has the serial it will get from tsdf_next_frame) of the newest
+ * frame such that the library no longer reads the DEVICE planes of that frame or of any device frame before it.  Host
+ * frames are borrowed for their call only and never hold the value back.  Non-blocking, launches nothing: the launch
+ * that packs a device frame stores a ticket in pinned host memory when the planes have been read, and this call
+ * compares.  -1 for a NULL handle.  Monotonic; equals tsdf_frame_serial() (+1 with a packed queued device frame) once
+ * everything handed over has been read, e.g. after tsdf_synchronize. */
+int64_t tsdf_device_frame_released(const tsdf_handle *h);
 /* Two-deep frame queue: upload and pack the NEXT frame while the current one is still being tracked and integrated
  * (the reference's callback has the next cloud in its subscriber queue while it works on the current one,
  * sdf_reconstruction.cpp:89: queue size 1).  tsdf_queue_frame / tsdf_queue_frame_aos return at once: page-locked
@@ -160,8 +179,9 @@ int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm
  * tsdf_queue_frame_aos needs the points (it has no 'normals only' form). */
 int tsdf_queue_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uint8_t *rgb, int32_t width, int32_t height);
 /* The same for a frame that is already in device memory (tsdf_set_frame_device's layouts and borrowing rule: the
- * buffers must be complete when the call is made and stay valid and unchanged until the frame AFTER this one has been
- * made current, or tsdf_synchronize).  Only the packing is left to hide: the integrate launch of the CURRENT frame
+ * buffers must be complete when the call is made and stay valid and unchanged until tsdf_device_frame_released()
+ * reaches the serial the frame gets from tsdf_next_frame -- normally a few microseconds into the CURRENT frame's
+ * integrate launch, which packs it -- or tsdf_synchronize).  Only the packing is left to hide: the integrate launch of the CURRENT frame
  * does it, sample list included, in workgroups appended to its first kernel; a queued frame that no integrate launch
  * came by is taken over unpacked by tsdf_next_frame, exactly like a frame of tsdf_set_frame_device. */
 int tsdf_queue_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm, const uint8_t *d_rgb, int32_t width, int32_t height);

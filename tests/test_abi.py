@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound():
     for name in syms:
         assert hasattr(L, name), f"{name} declared in include/tsdf.h but not exported by libtsdf_hip.so"
     assert sorted(ts.ABI_SYMBOLS) == syms, "python binding and header disagree"
-    assert L.tsdf_abi_version() == 2
+    assert L.tsdf_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

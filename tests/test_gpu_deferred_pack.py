@@ -204,3 +204,115 @@ def test_plane_sampling_for_odd_sizes_and_strides(w, h, stride, color, monkeypat
     for x, y in zip(a[0], b[0]):
         for u, v in zip(x, y):
             assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
+@pytest.mark.parametrize("ring,mode", [(3, None), (2, None), (1, None), (2, "0"), (1, "0"), (3, "queue"), (2, "queue")])
+def test_ring_of_device_buffers_refilled_as_soon_as_they_are_reported_free(ring, mode, monkeypatch):
+    """The borrowing rule of ABI version 3 (tsdf.h, tsdf_set_frame_device): a frame's device planes are the library's until
+    tsdf_device_frame_released() reaches its serial.  A producer with a ring of `ring` device buffers overwrites a buffer
+    with NaN THE MOMENT the call reports it free -- on torch's stream, which is not ordered against the library's, so a
+    report that came too early would put NaN into the pixel records -- and refills it with a later frame only then.  With
+    three buffers the loop never has to wait; with ONE buffer it polls behind every integrate launch (the report comes a few
+    microseconds into the launch that packs the frame, while integrate_kernel is still running): either way 40 frames give the trajectory and the volume of the host-plane loop, bit
+    for bit.  mode "0": TSDF_DEFER_PACK=0 (packed by a launch of its own when set); "queue": through
+    tsdf_queue_frame_device (packed inside the PREVIOUS frame's integrate launch)."""
+    import time
+    import torch
+    import tracking_sdf_amd as ts
+    if mode == "0":
+        monkeypatch.setenv("TSDF_DEFER_PACK", "0")
+    else:
+        monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    n = 40
+    want = host_loop(n=n)[:4]
+    seq = synth.Sequence(n_frames=n, width=W, height=H, noise=True, holes=0.02, step=4)
+    src = frames_on_device(seq, n)                     # the producer's source; the library only ever sees the ring
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    bufs = [[torch.empty_like(a) for a in src[0]] for _ in range(ring)]
+    holds = [None] * ring                              # serial of the frame a buffer holds (None: free)
+    last_rel = [s.device_frame_released()]
+    waits = 0
+
+    def reclaim():
+        rel = s.device_frame_released()
+        assert rel >= last_rel[0] and rel <= s.frame_serial() + 1         # monotonic, never ahead of what was handed over
+        last_rel[0] = rel
+        for b in range(ring):
+            if holds[b] is not None and holds[b] <= rel:
+                bufs[b][0].fill_(float("nan")); bufs[b][1].fill_(float("nan")); bufs[b][2].zero_()   # torch's stream: at once
+                holds[b] = None
+        return rel
+
+    def produce(k, serial):
+        nonlocal waits
+        t0 = time.perf_counter()
+        while True:
+            reclaim()
+            free = [b for b in range(ring) if holds[b] is None]
+            if free:
+                break
+            waits += 1
+            assert time.perf_counter() - t0 < 5.0, "no buffer was ever reported free"
+        b = free[0]
+        for dst, a in zip(bufs[b], src[k]):
+            dst.copy_(a)
+        torch.cuda.synchronize()                       # "contents must be complete when the call is made"
+        holds[b] = serial
+        return bufs[b]
+
+    poses = []
+    if mode == "queue":
+        buf = produce(0, 1)
+        s.queue_frame_device(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), W, H)
+    for k in range(n):
+        if mode == "queue":
+            s.next_frame()
+            assert s.frame_serial() == k + 1
+            if k + 1 < n:
+                buf = produce(k + 1, k + 2)
+                s.queue_frame_device(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), W, H)
+        else:
+            buf = produce(k, k + 1)
+            s.set_frame_device(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), W, H)
+            assert s.frame_serial() == k + 1
+        if k > 0:
+            t.estimate_new_position()
+        s.update(want_stats=False)
+        reclaim()                                      # right behind the integrate launch: the frame may or may not be free yet
+        poses.append((t.rot.copy(), t.trans.copy()))
+    s.synchronize()
+    assert s.device_frame_released() == s.frame_serial() == n
+    reclaim()
+    assert all(x is None for x in holds)
+    got = finish(s, t, poses)
+    assert_same(want, got)
+    if ring == 3 and mode is None:
+        assert waits == 0                              # three buffers never wait in the plain loop
+
+
+def test_a_frame_that_is_replaced_unpacked_is_free_at_once(monkeypatch):
+    """set_frame_device(A), track, set_frame_device(B) without integrating A: nothing will ever pack A (its tracker passes
+    were host-synchronous), so A is reported free as soon as B is set; B stays borrowed until its integrate launch has run."""
+    import time
+    import tracking_sdf_amd as ts
+    monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    seq = synth.Sequence(n_frames=3, width=W, height=H, noise=True, holes=0.02, step=4)
+    fr = frames_on_device(seq, 3)
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    assert s.device_frame_released() == 0
+    s.set_frame_device(fr[0][0].data_ptr(), fr[0][1].data_ptr(), fr[0][2].data_ptr(), W, H)
+    assert s.device_frame_released() == 0              # handed over, not packed
+    s.update()                                         # with statistics: synchronous
+    assert s.device_frame_released() == 1
+    s.set_frame_device(fr[1][0].data_ptr(), fr[1][1].data_ptr(), fr[1][2].data_ptr(), W, H)
+    t.estimate_new_position()
+    assert s.device_frame_released() == 1              # frame 2 only tracked so far
+    s.set_frame_device(fr[2][0].data_ptr(), fr[2][1].data_ptr(), fr[2][2].data_ptr(), W, H)
+    assert s.device_frame_released() == 2              # frame 2 was replaced unpacked: free
+    s.set_frame(*seq.frame(2))                         # a host frame replaces device frame 3 (serial 4): 3 is free, 4 never was borrowed
+    assert s.device_frame_released() == 4 == s.frame_serial()
+    s.close()

@@ -182,6 +182,9 @@ ORACLE_AT_SIZE = [
     pytest.param(512, 640, 480, None, 12, id="config3-512-640x480"),
     pytest.param(1024, 640, 480, FR3_K, 60, id="config4-1024-640x480-fr3"),
     pytest.param(1024, 1280, 960, None, 60, id="config5-image-1280x960-at-1024"),
+    # config 5 itself: 206 GB of oracle arrays + 206 GB of downloaded volume (the GPU box has 3 TB of host memory).  The
+    # reference cannot run this size (its int voxel count wraps at m >= 1291, sdf.cpp:9): the oracle is its 64-bit reading
+    pytest.param(2048, 1280, 960, None, 500, id="config5-2048-1280x960"),
 ]
 CARRY_THREADS = 4
 

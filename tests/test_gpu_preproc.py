@@ -152,6 +152,9 @@ def test_queued_depth_frames_give_the_same_trajectory_and_volume(pinned):
                     s.queue_depth_frame(*frames[k + 1], depth_scale=1.0 / 5000.0, **params)
                     with pytest.raises(ts.TsdfError):
                         s.set_depth_frame(*frames[k], depth_scale=1.0 / 5000.0, **params)      # a frame is queued
+                    with pytest.raises(ts.TsdfError) as ei:
+                        s.get_preprocessed()       # the staging planes are being filled with frame k+1: not frame k's any more
+                    assert ei.value.code == ts.E_NO_FRAME
             else:
                 s.set_depth_frame(*frames[k], depth_scale=1.0 / 5000.0, **params)
             if k > 0:

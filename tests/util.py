@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests: build the oracle and the HIP path on identical inputs."""
+import os
+
 import numpy as np
 
 import oracle as orc
@@ -48,25 +50,34 @@ def sym_rel_err(A, B):
 
 
 def volume_mismatch(got, want, chunk=1 << 24):
-    """(max ulp distance, number of differing elements) between two float32 arrays of any size, without whole-array
-    int64 temporaries: bit patterns are compared chunk by chunk and ulp distances are formed for the differing
-    elements only (512^3 = 134 M voxels per array, 1024^3 = 1.07 G)."""
+    """(max ulp distance, number of differing elements, their indices) between two float32 arrays of any size, without
+    whole-array int64 temporaries: bit patterns are compared chunk by chunk (a few threads: NumPy releases the GIL in the
+    comparison) and ulp distances are formed for the differing elements only (512^3 = 134 M voxels per array,
+    1024^3 = 1.07 G, 2048^3 = 8.6 G)."""
+    from concurrent.futures import ThreadPoolExecutor
     got = np.asarray(got).reshape(-1)
     want = np.asarray(want).reshape(-1)
     assert got.dtype == np.float32 and want.dtype == np.float32 and got.size == want.size
-    worst, count = 0, 0
-    where = []
-    for a in range(0, got.size, chunk):
+
+    def one(a):
         g, w = got[a:a + chunk], want[a:a + chunk]
         ne = np.flatnonzero(g.view(np.uint32) != w.view(np.uint32))
-        if ne.size:
-            u = ulp_diff(g[ne], w[ne])
-            nz = u > 0                                     # +0 / -0 and NaN payloads are not differences
-            if nz.any():
-                worst = max(worst, int(u.max()))
-                count += int(nz.sum())
-                where.append(ne[nz] + a)
-    return worst, count, (np.concatenate(where) if where else np.zeros(0, dtype=np.int64))
+        if not ne.size:
+            return 0, None
+        u = ulp_diff(g[ne], w[ne])
+        nz = u > 0                                         # +0 / -0 and NaN payloads are not differences
+        return (int(u.max()), ne[nz] + a) if nz.any() else (0, None)
+
+    starts = range(0, got.size, chunk)
+    if got.size > 4 * chunk:
+        with ThreadPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as ex:
+            res = list(ex.map(one, starts))
+    else:
+        res = [one(a) for a in starts]
+    where = [i for _, i in res if i is not None]
+    worst = max([u for u, _ in res], default=0)
+    idx = np.concatenate(where) if where else np.zeros(0, dtype=np.int64)
+    return worst, int(idx.size), idx
 
 
 def assert_volume_equal_at_size(go, oo, color=True, max_exp_ulp=1, max_frac=1e-4):

@@ -76,7 +76,7 @@ def main():
     ms = tm["integrate_ms"] / tm["integrate_launches"]
     upd = cn["n_updated"] / tm["integrate_launches"]
     out = {"m": args.m, "integrate_ms": ms, "updated_per_launch": upd,
-           "integrate_GBs": (bpv * upd + args.width * args.height * 32) / (ms * 1e-3) / 1e9,
+           "integrate_GBs": (bpv * upd + args.width * args.height * 27) / (ms * 1e-3) / 1e9,
            "pack_ms": tm["pack_ms"] / max(1, tm["pack_launches"]),
            "items_per_launch": cn["integrate_items"] / tm["integrate_launches"]}
     # tracker passes at a perturbed pose (not applied: accumulate only)

@@ -25,7 +25,7 @@ OK, E_BADARG, E_NO_DEVICE, E_HIP, E_NO_INTRINSICS, E_NO_FRAME, E_SINGULAR, E_NO_
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 RED_WIDTH = 34
 RED_ALLREDUCE = 30
-ABI_VERSION = 2          # TSDF_ABI_VERSION of include/tsdf.h this module mirrors (struct layouts)
+ABI_VERSION = 3          # TSDF_ABI_VERSION of include/tsdf.h this module mirrors (struct layouts)
 
 
 class TsdfError(RuntimeError):
@@ -104,7 +104,7 @@ ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_set_tracker_params", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_frame_serial", "tsdf_queue_frame", "tsdf_queue_frame_device", "tsdf_queue_frame_aos", "tsdf_next_frame",
-    "tsdf_set_frame_device", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_queue_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
+    "tsdf_set_frame_device", "tsdf_device_frame_released", "tsdf_set_frame_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_queue_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
     "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
@@ -153,6 +153,7 @@ def lib():
         "tsdf_set_camera_transformation": (C.c_int, [H, dp, dp]),
         "tsdf_set_tracker_params": (C.c_int, [H, C.c_int32, C.c_float, C.c_float, C.c_float]),
         "tsdf_frame_serial": (C.c_int64, [H]),
+        "tsdf_device_frame_released": (C.c_int64, [H]),
         "tsdf_queue_frame": (C.c_int, [H, fp, fp, u8p, C.c_int32, C.c_int32]),
         "tsdf_queue_frame_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32]),
         "tsdf_next_frame": (C.c_int, [H]),
@@ -466,6 +467,15 @@ class SDF:
         self._keep = getattr(self, "_keep", [])[-1:] + [keep]
         self._check(lib().tsdf_set_frame_device(self._h, C.c_void_p(d_xyz), C.c_void_p(d_normals or 0),
                                                 C.c_void_p(d_rgb or 0), int(width), int(height)))
+
+    def frame_serial(self):
+        """tsdf_frame_serial: frames made current so far."""
+        return int(lib().tsdf_frame_serial(self._h))
+
+    def device_frame_released(self):
+        """tsdf_device_frame_released: the library no longer reads the device planes of any frame with a serial up to
+        this one (non-blocking)."""
+        return int(lib().tsdf_device_frame_released(self._h))
 
     def queue_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
         """tsdf_queue_frame_device: queue a frame that is already in HBM (device pointers as ints); the current frame's

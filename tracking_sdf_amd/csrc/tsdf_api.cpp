@@ -4,7 +4,9 @@
 // across the boundary, no CPU fallback.
 #include "../../include/tsdf.h"
 
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 #include <sched.h>
 #include <hip/hip_runtime_api.h>
 
@@ -22,6 +24,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <ctime>
 #include <cstring>
 #include <functional>
@@ -183,6 +186,17 @@ struct tsdf_handle {
         bool pending = false, samples_listed = false;      // samples_listed: a tracker pass has written the sample list
         const float* xyz = nullptr; const float* nrm = nullptr; const uint8_t* rgb = nullptr;
     } deferred;
+    // tsdf_device_frame_released: frames handed over in DEVICE memory whose planes the library may still read, oldest
+    // first.  A frame is free once the launch that packs it has run: that launch stores its ticket into release_host[s]
+    // (pinned; s = 0 main stream, 1 frame stream -- tickets grow per stream) and the entry says which ticket to wait for.
+    struct BorrowedFrame {
+        int64_t serial;                        // tsdf_frame_serial() the frame has (or will have, while it is still queued)
+        int stream;                            // -1: not packed yet (and not abandoned): still borrowed, whatever the words say
+        unsigned long long ticket;
+    };
+    std::deque<BorrowedFrame> borrowed;
+    unsigned long long* release_host = nullptr;    // pinned: two words
+    unsigned long long release_ticket[2] = {0ull, 0ull};
     bool deferred_list_samples = true;         // TSDF_DEFER_PACK=2 (diagnosis): every pass reads the plane
     bool defer_device_pack = true;             // TSDF_DEFER_PACK=0: pack when the frame is set
     float4* pn_buf[2] = {nullptr, nullptr};
@@ -468,10 +482,41 @@ PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, con
     return a;
 }
 
+// ---- borrowed device planes (tsdf_device_frame_released) ---------------------------------------------------------
+// a device frame with this serial has been handed over; nothing has packed it yet
+void borrow_device_frame(tsdf_handle* h, int64_t serial) { h->borrowed.push_back({serial, -1, 0ull}); }
+// the launch that packs frame `serial` is about to be issued on stream index s: the ticket it will publish
+ReleaseWord release_for(tsdf_handle* h, int64_t serial, int s) {
+    ReleaseWord r;
+    r.word = h->release_host + s;
+    r.ticket = ++h->release_ticket[s];
+    for (auto& b : h->borrowed)
+        if (b.serial == serial) { b.stream = s; b.ticket = r.ticket; }
+    return r;
+}
+// frame `serial` will never be packed (replaced while its packing was still deferred; the tracker passes that read its
+// xyz plane are host-synchronous and over): free as soon as the frames before it are
+void abandon_device_frame(tsdf_handle* h, int64_t serial) {
+    for (auto& b : h->borrowed)
+        if (b.serial == serial && b.stream < 0) { b.stream = 0; b.ticket = 0ull; }
+}
+// newest serial S such that no device frame with serial <= S is still read by the library
+int64_t released_serial(tsdf_handle* h) {
+    while (!h->borrowed.empty()) {
+        const tsdf_handle::BorrowedFrame& b = h->borrowed.front();
+        if (b.stream < 0) break;
+        if (b.ticket && __atomic_load_n(h->release_host + b.stream, __ATOMIC_ACQUIRE) < b.ticket) break;
+        h->borrowed.pop_front();
+    }
+    if (h->borrowed.empty()) return h->frame_serial + ((h->queued.active && h->queued.device) ? 1 : 0);
+    return h->borrowed.front().serial - 1;
+}
+
 // st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
 // overlaps the running integration like they do.  Device-resident inputs pack on the main stream: measured, a
 // pack_kernel squeezed in beside the persistent integrate_kernel slows that one down by as much as it takes.
-int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st) {
+int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st, bool borrowed_planes = false) {
+    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
     const bool side = st != h->stream;
@@ -482,6 +527,10 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     int rc = timed_begin(h, 1, &ep, st);
     if (rc) return rc;
     HIP_TRY(h, launch_pack(st, pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb)));
+    if (borrowed_planes) {
+        borrow_device_frame(h, h->frame_serial + 1);
+        HIP_TRY(h, launch_release(st, release_for(h, h->frame_serial + 1, side ? 1 : 0)));
+    }
     rc = timed_end(h, ep, st);
     if (rc) return rc;
     if (side) {
@@ -503,7 +552,9 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
 // of its own in front of the first tracker pass.  The planes stay borrowed until that launch has run: tsdf.h asks for them
 // until the set_frame* call after the next one (or tsdf_synchronize, which packs what is pending).  TSDF_DEFER_PACK=0: pack
 // at once, as rounds 1-3 did.
-int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb) {
+int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false) {
+    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
+    if (!already_borrowed) borrow_device_frame(h, h->frame_serial + 1);
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;
     h->frame_side = false;
@@ -693,11 +744,14 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         for (int sh = 0; sh < ns && all; ++sh) {
             const volatile Pair* sp = pairs + (size_t)sh * (kShardSlotDoubles / 2);
             for (int e = kPartWidth - 1; e >= 0 && all; --e) {
+                // (value, word) may be read in two pieces here and -- not architecturally excluded -- written in two pieces
+                // on the way: whichever half is stale, the pair does not validate and is read again
                 for (unsigned spins = 0;; ++spins) {
-                    if (__atomic_load_n(&sp[e].w, __ATOMIC_ACQUIRE) == seq) break;
+                    const unsigned long long w = __atomic_load_n(&sp[e].w, __ATOMIC_ACQUIRE);
+                    const unsigned long long vb = __atomic_load_n(reinterpret_cast<const volatile unsigned long long*>(&sp[e].v), __ATOMIC_ACQUIRE);
+                    if (w == shard_pair_word(vb, seq)) { std::memcpy(&rows[sh][e], &vb, sizeof vb); break; }
                     if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { all = false; break; }
                 }
-                rows[sh][e] = sp[e].v;
             }
         }
         if (!all) {                                            // a shard row did not show up in time: synchronise for real
@@ -705,8 +759,10 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
             for (int sh = 0; sh < ns; ++sh)
                 for (int e = 0; e < kPartWidth; ++e) {
                     const volatile Pair* sp = pairs + (size_t)sh * (kShardSlotDoubles / 2);
-                    if (sp[e].w != seq) return fail(h, TSDF_E_HIP, "tracker fan-in: shard %d of pass %llu never reached the host", sh, seq);
-                    rows[sh][e] = sp[e].v;
+                    unsigned long long vb;
+                    { const double v = sp[e].v; std::memcpy(&vb, &v, sizeof vb); }
+                    if (sp[e].w != shard_pair_word(vb, seq)) return fail(h, TSDF_E_HIP, "tracker fan-in: shard %d of pass %llu never reached the host", sh, seq);
+                    std::memcpy(&rows[sh][e], &vb, sizeof vb);
                 }
         }
         if (h->track_profile) h->tp_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tp2).count();
@@ -1046,6 +1102,8 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMalloc((void**)&h->red_dev, kRedWidth * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->red_host, (kRedWidth + 2) * sizeof(double), hipHostMallocDefault));
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
+    CREATE_TRY(hipHostMalloc((void**)&h->release_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    h->release_host[0] = h->release_host[1] = 0ull;
     { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
     { const char* ev = std::getenv("TSDF_DEFER_PACK"); h->defer_device_pack = !(ev && std::atoi(ev) == 0); h->deferred_list_samples = !(ev && std::atoi(ev) == 2); }
     { const char* ev = std::getenv("TSDF_HOST_FOLD"); h->host_fold = !(ev && std::atoi(ev) == 0); }
@@ -1054,8 +1112,8 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     { const char* ev = std::getenv("TSDF_HOST_FANIN"); h->host_fanin = !(ev && std::atoi(ev) == 0); }
     { const char* ev = std::getenv("TSDF_TRACK_STAMPS");      // diagnosis: where inside the launch does a tracker pass spend its time?
       if (ev && std::atoi(ev) != 0) {
-          CREATE_TRY(hipMalloc((void**)&h->track_stamps, 8 * 4096 * sizeof(unsigned long long)));
-          CREATE_TRY(hipMemsetAsync(h->track_stamps, 0, 8 * 4096 * sizeof(unsigned long long), h->stream));
+          CREATE_TRY(hipMalloc((void**)&h->track_stamps, 8 * (size_t)kTrackStampBlocks * sizeof(unsigned long long)));
+          CREATE_TRY(hipMemsetAsync(h->track_stamps, 0, 8 * (size_t)kTrackStampBlocks * sizeof(unsigned long long), h->stream));
       } }
     { const char* ev = std::getenv("TSDF_TRACK_PROFILE"); h->track_profile = ev && std::atoi(ev) != 0; }
     { const char* ev = std::getenv("TSDF_STAGE_PROFILE"); h->sp.on = ev && std::atoi(ev) != 0; }
@@ -1075,10 +1133,10 @@ void tsdf_destroy(tsdf_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->track_stamps) {
         // phase stamps of the LAST tracker pass: per workgroup, microseconds after the earliest workgroup's start
-        std::vector<unsigned long long> st(8 * 4096);
+        std::vector<unsigned long long> st(8 * (size_t)kTrackStampBlocks);
         (void)hipDeviceSynchronize();
         if (hipMemcpy(st.data(), h->track_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            const int nb = track_num_blocks(h->n_samples) < 4096 ? track_num_blocks(h->n_samples) : 4096;
+            const int nb = track_num_blocks(h->n_samples) < kTrackStampBlocks ? track_num_blocks(h->n_samples) : kTrackStampBlocks;
             unsigned long long t0 = ~0ull;
             for (int b = 0; b < nb; ++b) if (st[8 * b] && st[8 * b] < t0) t0 = st[8 * b];
             const char* names[8] = {"start", "window classified", "own sample", "look-ups done", "row written", "arrived", "shard row out",
@@ -1134,6 +1192,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);
     if (h->red_host) (void)hipHostFree(h->red_host);
+    if (h->release_host) (void)hipHostFree(h->release_host);
     if (h->fold_ctr) (void)hipFree(h->fold_ctr);
     if (h->shard_host) (void)hipHostFree(h->shard_host);
     if (h->counters) (void)hipFree(h->counters);
@@ -1242,6 +1301,7 @@ inline void repack_triples(const char* src /* first triple */, size_t stride, bo
                            float* dst /* plane */, size_t i0, size_t i1) {
     size_t i = i0;
     const char* p = src + i0 * stride;
+#if defined(__SSE2__)
     if (wide) {
         for (; i < i1 && (i & 3u); ++i, p += stride) std::memcpy(dst + 3 * i, p, 12);      // up to a 16-byte boundary of the plane
         for (; i + 4 <= i1; i += 4, p += 4 * stride) {
@@ -1257,6 +1317,9 @@ inline void repack_triples(const char* src /* first triple */, size_t stride, bo
             _mm_stream_ps(o + 8, _mm_shuffle_ps(t2, d, _MM_SHUFFLE(2, 1, 2, 0)));           // cz dx dy dz
         }
     }
+#else
+    (void)wide;                                              // hosts without SSE2: the per-point copy below does all of it
+#endif
     for (; i < i1; ++i, p += stride) std::memcpy(dst + 3 * i, p, 12);
 }
 inline void repack_aos(const tsdf_aos_layout& lay, const void* points, const void* normals, bool color,
@@ -1275,7 +1338,9 @@ inline void repack_aos(const tsdf_aos_layout& lay, const void* points, const voi
         const bool wide = lay.normal_offset + 16 <= lay.normal_stride && (reinterpret_cast<uintptr_t>(pnm) & 15u) == 0;
         repack_triples((const char*)normals + lay.normal_offset, (size_t)lay.normal_stride, wide, pnm, i0, i1);
     }
+#if defined(__SSE2__)
     _mm_sfence();                                           // the streaming stores are globally visible before the chunk is handed to the DMA
+#endif
 }
 
 // cores this process may run on (the affinity mask: hardware_concurrency() reports the whole machine in a container)
@@ -1547,6 +1612,7 @@ int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_n
         // list_rows_kernel (tsdf_integrate), on the main stream, i.e. behind the last reader of the record buffer
         q.deferred = true; q.d_xyz = d_xyz; q.d_nrm = d_nrm; q.d_rgb = d_rgb;
         q.active = true;
+        borrow_device_frame(h, h->frame_serial + 1);
         return TSDF_OK;
     }
     pick_pixel_layout(h, &q.su, &q.sv);
@@ -1555,6 +1621,8 @@ int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_n
     rc = wait_buffer_free(h, q.nb, h->fstream);
     if (rc) return rc;
     HIP_TRY(h, launch_pack(h->fstream, pack_args(h, d_xyz, d_nrm, d_rgb, q.su, q.sv, q.nb)));
+    borrow_device_frame(h, h->frame_serial + 1);
+    HIP_TRY(h, launch_release(h->fstream, release_for(h, h->frame_serial + 1, 1)));
     HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
     q.active = true;
     return TSDF_OK;
@@ -1572,8 +1640,9 @@ int tsdf_next_frame(tsdf_handle* h) {
     if (from_device && q.deferred) {
         q.deferred = false;
         h->staged_xyz = false;
-        if (!q.packed) return defer_pack(h, q.d_xyz, q.d_nrm, q.d_rgb);      // no integrate launch came by: as tsdf_set_frame_device
+        if (!q.packed) return defer_pack(h, q.d_xyz, q.d_nrm, q.d_rgb, true);      // no integrate launch came by: as tsdf_set_frame_device
         // packed inside the previous frame's integrate launch, on the main stream: nothing to wait for
+        if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);
         h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
         h->deferred = tsdf_handle::DeferredPack();
         h->pix_su = q.su; h->pix_sv = q.sv;
@@ -1597,6 +1666,7 @@ int tsdf_next_frame(tsdf_handle* h) {
         if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
     }
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
+    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);     // the frame this one replaces was never packed
     h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
     h->deferred = tsdf_handle::DeferredPack();
     h->pix_su = q.su; h->pix_sv = q.sv;
@@ -1618,7 +1688,7 @@ int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm
     if (rc) return rc;
     h->staged_xyz = false;
     if (h->defer_device_pack) return defer_pack(h, d_xyz, d_nrm, d_rgb);
-    return run_pack(h, d_xyz, d_nrm, d_rgb, h->stream);
+    return run_pack(h, d_xyz, d_nrm, d_rgb, h->stream, true);
 }
 
 int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L,
@@ -1831,6 +1901,11 @@ int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {
     int rc = check_ready(h, true);
     if (rc) return rc;
     if (!h->in_xyz || h->in_cap < (size_t)h->fw * h->fh) return fail(h, TSDF_E_NO_FRAME, "no pre-processed frame held");
+    // the staging planes hold the CURRENT frame only until the next frame is queued (tsdf_queue_frame / _aos /
+    // tsdf_queue_depth_frame fill them with frame k+1, on the library thread and the frame stream, while frame k is current)
+    if (!h->staged_xyz)
+        return fail(h, TSDF_E_NO_FRAME, "tsdf_get_preprocessed: the planes of the current frame are no longer held (a frame is queued behind "
+                                        "it, or the frame came from device memory): read them before queueing the next frame");
     const size_t bytes = (size_t)h->fw * h->fh * 3 * sizeof(float);
     if (xyz) HIP_TRY(h, hipMemcpyAsync(xyz, h->in_xyz, bytes, hipMemcpyDeviceToHost, h->fstream));
     if (nrm) HIP_TRY(h, hipMemcpyAsync(nrm, h->in_nrm, bytes, hipMemcpyDeviceToHost, h->fstream));
@@ -1870,10 +1945,12 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     // A queued device frame goes first -- that is the packing of the NEXT frame, sample list included, hidden under this
     // frame's list kernel; the current frame's own records then need a launch in front (the first frame of a stream only).
     PackArgs pa;
-    bool fused = false;
+    bool fused = false, fused_queued = false;
+    ReleaseWord rel;                         // tells the host when the borrowed planes packed by this launch have been read
     tsdf_handle::Queued& q = h->queued;
     if (q.active && q.device && q.deferred && !q.packed) {
-        if (h->deferred.pending) {
+        const bool own_too = h->deferred.pending;
+        if (own_too) {
             PackArgs own = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
             if (h->deferred.samples_listed) own.samples = nullptr;
             HIP_TRY(h, launch_pack(h->stream, own));
@@ -1881,16 +1958,28 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
         }
         q.su = h->pix_su; q.sv = h->pix_sv;      // laid out for this frame's pose: the next one's is close to it
         pa = pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, q.nb);
-        q.packed = true;
-        fused = true;
+        rel = release_for(h, h->frame_serial + 1, 0);
+        if (own_too)                             // the launch in front, same stream: read by the time the ticket appears
+            for (auto& b : h->borrowed) if (b.serial == h->frame_serial) { b.stream = 0; b.ticket = rel.ticket; }
+        fused = fused_queued = true;
     } else if (h->deferred.pending) {
         pa = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
         if (h->deferred.samples_listed) pa.samples = nullptr;     // a tracker pass has written them already
+        rel = release_for(h, h->frame_serial, 0);
         fused = true;
     }
-    HIP_TRY(h, launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                                h->integrate_blocks, h->integrate_launches++, h->wg_counts, h->integrate_queue,
-                                fused ? &pa : nullptr));
+    {
+        const hipError_t le = launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
+                                               h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue,
+                                               fused ? &pa : nullptr, fused ? &rel : nullptr);
+        if (le != hipSuccess) {
+            // nothing was packed: the frames stay borrowed and unpacked (a later launch, or tsdf_synchronize, packs them)
+            if (fused) for (auto& b : h->borrowed) if (b.stream == 0 && b.ticket == rel.ticket && b.serial >= h->frame_serial + (fused_queued ? 1 : 0)) b.stream = -1;
+            return fail(h, TSDF_E_HIP, "launch_integrate failed: %s (%s:%d)", hipGetErrorString(le), __FILE__, __LINE__);
+        }
+    }
+    h->integrate_launches++;
+    if (fused_queued) q.packed = true;       // only now: a failed launch must not leave an unpacked record buffer marked as packed
     h->deferred.pending = false;             // records and sample list of the current frame are complete from here on
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
@@ -2710,7 +2799,15 @@ int tsdf_synchronize(tsdf_handle* h) {
     }
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->borrowed.clear();                     // nothing launched so far reads a borrowed plane any more
     return TSDF_OK;
+}
+
+// Serial (as tsdf_frame_serial counts) of the newest frame such that the library no longer reads the DEVICE planes of
+// that frame or of any frame before it.  Never blocks, launches nothing.
+int64_t tsdf_device_frame_released(const tsdf_handle* h) {
+    if (!h) return -1;
+    return released_serial(const_cast<tsdf_handle*>(h));      // (drops the entries that have become free: bookkeeping only)
 }
 
 void* tsdf_stream(tsdf_handle* h) { return h ? (void*)h->stream : nullptr; }

@@ -30,8 +30,19 @@ constexpr int kTrackBlock = TSDF_TRACK_BLOCK;    // threads per tracker workgrou
 #endif
 constexpr int kIntegrateBlock = TSDF_INTEGRATE_BLOCK;   // threads per integrate workgroup
 constexpr int kTrackShards = 8;                  // fan-in shards of the in-launch fold (blockIdx % 8: one per XCD)
+constexpr int kTrackStampBlocks = 4096;          // TSDF_TRACK_STAMPS: workgroups that have a slot in the stamp buffer (the others write none)
 constexpr int kShardSlotDoubles = 80;            // pinned host slot of a shard row: 40 {value, pass word} pairs of 16 bytes -- a value
                                                  // and the word that validates it arrive in ONE store, so no fence separates them
+
+// What travels next to a shard-row value in its 16-byte {value, word} pair (host side of the tracker fan-in): the pass
+// word mixed with the value's own bits.  The host accepts a value when shard_pair_word(value bits, pass) equals the word
+// it reads next to it, so a pair torn anywhere between the store instruction and host memory cannot pass a stale value.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline unsigned long long shard_pair_word(unsigned long long value_bits, unsigned long long pass_word) {
+    return pass_word ^ (value_bits * 0x9E3779B97F4A7C15ull);
+}
 
 // partial row (kPartWidth) -> result row (kRedWidth): the mapping track_kernel's last workgroup applies, for the host
 // side of the fan-in
@@ -112,6 +123,10 @@ struct MeshParams {
 // cumulative device counters (unsigned long long each)
 enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntItems = 2, kCntOverflowItems = 3, kNumCounters = 4 };
 
+// pinned host word + the value a launch stores there once the caller's device planes have been read (tsdf_device_frame_released)
+struct ReleaseWord { unsigned long long* word = nullptr; unsigned long long ticket = 0; };
+hipError_t launch_release(hipStream_t s, const ReleaseWord& rel);   // behind a launch_pack of borrowed device planes
+
 hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0);
 hipError_t launch_pack(hipStream_t s, const PackArgs& a);
 // worklist: integrate_worklist_bytes(g) bytes, zero before the first launch; work_count:
@@ -130,7 +145,8 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
                             const float4* pn, unsigned long long* counters,
                             void* worklist, unsigned* work_count, int n_blocks,
                             unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */, bool queue,
-                            const PackArgs* pack = nullptr /* the frame's records are still to be packed: done inside this launch */);
+                            const PackArgs* pack = nullptr /* the frame's records are still to be packed: done inside this launch */,
+                            const ReleaseWord* release = nullptr /* with pack of borrowed planes: told to the host once they are read */);
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit

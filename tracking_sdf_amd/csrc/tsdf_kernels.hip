@@ -780,13 +780,28 @@ __device__ __forceinline__ void build_segment_table(const unsigned* __restrict__
     }
 }
 
+// tsdf_device_frame_released: the launch that packs a frame handed over in device memory tells the host, through a word
+// in pinned memory, that the caller's planes have been read -- the first workgroup of the kernel BEHIND the packing
+// (integrate_kernel behind list_rows_kernel's appended workgroups; release_kernel behind a pack_kernel launch) stores
+// the launch's ticket.  Tickets of one stream grow, the host compares with >=.
+__device__ __forceinline__ void publish_release(const ReleaseWord& rel, int tid) {
+    if (rel.word && blockIdx.x == 0 && tid == 0)
+        __hip_atomic_store(rel.word, rel.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void release_kernel(ReleaseWord rel) { publish_release(rel, (int)threadIdx.x); }
+hipError_t launch_release(hipStream_t s, const ReleaseWord& rel) {
+    if (!rel.word) return hipSuccess;
+    release_kernel<<<dim3(1), dim3(64), 0, s>>>(rel);
+    return hipGetLastError();
+}
+
 template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
 __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ set,
     unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
     float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
     unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */,
-    unsigned* __restrict__ xcd_fb) {
+    unsigned* __restrict__ xcd_fb, ReleaseWord rel) {
     constexpr int kRec = COLOR ? 32 : 24, kHalf = kRec / 2;        // bytes of a pixel record / of the piece a lane fetches
     extern __shared__ double s_tab[];
     const int m = p.g.m;
@@ -795,6 +810,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
     constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
     __shared__ unsigned s_vstart[kBins + 2], s_delta[kBins + 1];
+    publish_release(rel, tid);      // list_rows_kernel -- and the packing of a device frame in its appended workgroups -- is complete
     build_segment_table(set, next_set, ovf_base, totals, s_vstart, s_delta, tid);
     if (KTAB) build_k_table(p, s_tab, tid, kIntegrateBlock);
     else __syncthreads();
@@ -1241,8 +1257,9 @@ __global__ __launch_bounds__(kIntegrateBlock, 4) void integrate_queue_kernel(
     unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
     float2* __restrict__ dw, float4* __restrict__ crgb, const char* __restrict__ pn,
     unsigned long long* __restrict__ counters /* per workgroup: {owned, halo} updated, cumulative */,
-    unsigned* __restrict__ xcd_fb) {
+    unsigned* __restrict__ xcd_fb, ReleaseWord rel) {
     typedef typename QueueEntry<COLOR>::T Entry;
+    publish_release(rel, (int)threadIdx.x);
     constexpr int kRec = COLOR ? 32 : 24, kHalf = kRec / 2;        // bytes of a pixel record / of the piece a lane fetches
     extern __shared__ double s_tab[];
     const int m = p.g.m;
@@ -1662,7 +1679,8 @@ static bool use_exp_poly(const IntegrateParams& p) {
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             void* worklist, unsigned* work_count, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts, bool queue, const PackArgs* pack) {
+                            unsigned launch_parity, unsigned long long* wg_counts, bool queue, const PackArgs* pack,
+                            const ReleaseWord* release) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
@@ -1688,10 +1706,11 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     const bool ktab = m <= 1024;                                       // 24 bytes of LDS per k
     const size_t lds = ktab ? (size_t)m * 24 : 0;
     const char* planes = reinterpret_cast<const char*>(pn);
+    const ReleaseWord rel = release ? *release : ReleaseWord{};
     if (queue && !integrate_queue_fits(p.g)) return hipErrorInvalidValue;
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) do { \
-    if (queue) integrate_queue_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb); \
-    else integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb); } while (0)
+    if (queue) integrate_queue_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb, rel); \
+    else integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb, rel); } while (0)
 #define TSDF_LAUNCH_INTEGRATE3(C, KS, EP) do { if (ktab) TSDF_LAUNCH_INTEGRATE(C, KS, EP, true); else TSDF_LAUNCH_INTEGRATE(C, KS, EP, false); } while (0)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE3(C, KS, true); else TSDF_LAUNCH_INTEGRATE3(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }
@@ -2030,7 +2049,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int base = blockIdx.x * kSamplesPerBlock;        // first of this workgroup's own samples
-    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    if (fold.stamps && tid == 0 && blockIdx.x < (unsigned)kTrackStampBlocks) fold.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // p.rpm[9*q] with a per-lane q is a vector load from the kernel-argument segment: a memory round trip in
     // front of the look-ups.  Stage the matrices in LDS while the samples are being classified.
     if (tid < 54) s_rpm[tid] = p.rpm[tid];
@@ -2059,7 +2078,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     }
     __syncthreads();
 
-    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (fold.stamps && tid == 0 && blockIdx.x < (unsigned)kTrackStampBlocks) fold.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     // ---- phase B: this thread's own sample (group g; no second trip to memory, no second classification) and
     // its look-ups (q and q + 7)
     const int g = tid >> 3, q = tid & 7;
@@ -2126,7 +2145,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         }
     }
 
-    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (fold.stamps && tid == 0 && blockIdx.x < (unsigned)kTrackStampBlocks) fold.stamps[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- the look-ups of this lane (camera_tracking.cpp:269-361): slot A = look-up q (centre, +x -x +y -y +z -z)
     // on lanes 0..6, slot B = look-up 7 + q (r1p r1m r2p r2m r3p r3m) on lanes 0..5
     const bool owned = (cls == kClsIn) && (sg.vx >= (double)p.g.own_x0) && (sg.vx < (double)p.g.own_x1);
@@ -2162,7 +2181,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
     const unsigned long long violmask = __ballot(viol != 0u);
     const bool any_viol = ((violmask >> gl) & 0xFFull) != 0ull;
 
-    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (fold.stamps && tid == 0 && blockIdx.x < (unsigned)kTrackStampBlocks) fold.stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     // ---- J[q] on lanes 0..5 of the group, from the +/- partners (float quotient widened, :286,331)
     const float r0 = __shfl(valA, gl);
     const int qa = q < 6 ? q : 0;
@@ -2230,7 +2249,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         if (slot >= 0) store_sc1(&partials[(long long)blockIdx.x * kPartWidth + slot], v);
     }
 
-    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    if (fold.stamps && tid == 0 && blockIdx.x < (unsigned)kTrackStampBlocks) fold.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     // ---- in-launch fan-in (no second launch, no host-side fold): every workgroup has written its row write-through;
     // one lane arrives on the counter of its shard (blockIdx % 8: workgroups b and b + 8 share an XCD, so a shard's
     // arrivals stay on one L2 -- speed only, nothing depends on the placement); the workgroup whose arrival completes a
@@ -2253,7 +2272,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         }
     }
     __syncthreads();
-    if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    if (fold.stamps && tid == 0 && blockIdx.x < (unsigned)kTrackStampBlocks) fold.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     if (s_role == 0) return;
 
     constexpr int RG = kTrackBlock / kPartWidth;                      // row groups of kPartWidth columns
@@ -2309,11 +2328,14 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
             typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
             u64x2* slot = reinterpret_cast<u64x2*>(fold.host_shards + (size_t)shard * kShardSlotDoubles);
             if (tid < kPartWidth) {
-                u64x2 pr; pr.x = (unsigned long long)__double_as_longlong(shard_v); pr.y = fold.word;
+                // The word is mixed with the value's own bits (shard_pair_word): should the 16 bytes ever reach host memory in
+                // two pieces -- neither the single global_store_dwordx4 nor an undivided PCIe write is architecturally
+                // promised -- an old value next to a new word (or the reverse) does not validate and the host keeps waiting.
+                u64x2 pr; pr.x = (unsigned long long)__double_as_longlong(shard_v); pr.y = shard_pair_word(pr.x, fold.word);
                 __builtin_nontemporal_store(pr, &slot[tid]);
             }
             if (tid == 0) __hip_atomic_store(&fold.ctr[32 * shard], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next pass
-            if (fold.stamps && tid == 0) fold.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+            if (fold.stamps && tid == 0 && blockIdx.x < (unsigned)kTrackStampBlocks) fold.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         }
         return;
     }
