@@ -412,8 +412,11 @@ def run(args):
         def first_frame(self, fr, mode=MAIN_MODE, host=None, depth16=None):
             """frame 1: integrate only at the reference's initial pose (sdf_reconstruction.cpp:69)"""
             self.est = []
-            self.feed(0, fr, mode, host, depth16)
-            self.sdf.update(want_stats=False)
+            if mode in ("ref_calls", "ref_calls_r4"):
+                self.sdf.update_aos(*host[0]) if mode == "ref_calls" else (self.sdf.set_frame_aos(*host[0]), self.sdf.update(want_stats=False))
+            else:
+                self.feed(0, fr, mode, host, depth16)
+                self.sdf.update(want_stats=False)
             self.est.append(self.trk.trans.copy())
 
         def feed(self, k, fr, mode, host, depth16):
@@ -458,6 +461,21 @@ def run(args):
                 self.sdf.set_depth_frame(depth16[k], host[k][2])
 
         def step(self, k, fr, mode=MAIN_MODE, host=None, depth16=None, timed=False):
+            if mode in ("ref_calls", "ref_calls_r4"):
+                # exactly what kinect_callback does (sdf_reconstruction.cpp:70,74), synchronously, on pageable PCL-layout
+                # clouds: estimate_new_position(sdf, cloud) then update(tracker, cloud, normals)
+                pts, nn = host[k]
+                if mode == "ref_calls":
+                    self.sdf.track_aos(pts)                        # samples first, the cloud staged under the passes
+                    self.sdf.update_aos(pts, nn)                   # normals; the cloud is compared, not uploaded again
+                else:                                              # round 4's shim: two uploads, a host wait for the frame stream
+                    self.sdf.set_frame_aos(pts, None)
+                    self.sdf._check(L.tsdf_track(self.sdf._h, None))
+                    self.sdf.set_frame_aos(None, nn)
+                    self.sdf._check(L.tsdf_integrate(self.sdf._h, None))
+                f_pose(self.sdf._h, None, self.pose_ptr, None, None)
+                self.est.append(self.pose_t.copy())
+                return
             self.feed(k, fr, mode, host, depth16)
             tq = perf()
             rc = f_step(self.sdf._h, 1, None, None)        # estimate_new_position + update, sdf_reconstruction.cpp:70,74
@@ -698,6 +716,16 @@ def run(args):
             nn = np.zeros(x.shape[:2], dtype=ts.PCL_NORMAL)
             nn["normal_x"], nn["normal_y"], nn["normal_z"] = n[..., 0], n[..., 1], n[..., 2]
             aos.append((pts, nn))
+        # the rate through the reference's own two entry points, called the way kinect_callback calls them
+        extras["value_reference_entry_points"] = args.steps / best_of_two("ref_calls", aos)
+        extras["value_reference_entry_points_round4_sequence"] = args.steps / best_of_two("ref_calls_r4", aos)
+        extras["reference_entry_points_note"] = (
+            "estimate_new_position(sdf, cloud) then update(tracker, cloud, normals), synchronously, one frame at a time, clouds as arrays of "
+            "PCL's 32-byte structs in pageable memory (sdf_reconstruction.cpp:33-49,70,74) = tsdf_track_aos + tsdf_integrate_aos, which the "
+            "exact-type shim forwards to: the tracker's 34 240 samples are copied first, the cloud is staged under the Gauss-Newton passes, "
+            "update adds the normals and compares the cloud instead of uploading it again.  _round4_sequence: what the shim issued until "
+            "round 4 (tsdf_set_frame_aos(points) -> tsdf_track -> tsdf_set_frame_aos(normals only) -> tsdf_integrate).  The normals are only "
+            "handed over by update, so their repack and copy (3.7 MB) sit between a frame's last pass and its integration whatever the library does")
         e4 = best_of_two("aos", aos)
         extras["value_pcl_clouds_inclusive"] = args.steps / e4
         extras["pcl_clouds_note"] = ("frames handed over as arrays of PCL's 32-byte point / normal structs in pageable memory "

@@ -379,30 +379,14 @@ public:
         impl_.set_camera_transformation(to_rows(r), Vec3{{t(0), t(1), t(2)}});
         pull();
     }
-    // camera_tracking.h:101
+    // camera_tracking.h:101.  tsdf_track_aos: the tracker's 34 240 samples go up first and the Gauss-Newton passes run
+    // while the library threads stage the rest of the cloud; the cloud is the caller's again when this returns.
     void estimate_new_position(const SDF* sdf, const pcl::PointCloud<pcl::PointXYZRGB>::Ptr& point_cloud) {
         push(sdf);
-        token_ = FrameToken();
-        sdf->check(tsdf_set_frame_aos(sdf->handle(), point_cloud->points.data(), nullptr, &pcl_layout(),
-                                      (int32_t)point_cloud->width, (int32_t)point_cloud->height), "tsdf_set_frame_aos");
-        token_ = FrameToken(*point_cloud, tsdf_frame_serial(sdf->handle()));
-        try { impl_.estimate_new_position(sdf); } catch (...) { pull(); throw; }
+        const int rc = tsdf_track_aos(sdf->handle(), point_cloud->points.data(), &pcl_layout(), (int32_t)point_cloud->width,
+                                      (int32_t)point_cloud->height, nullptr);
         pull();
-    }
-    // The reference hands the cloud it has just tracked to SDF::update (sdf_reconstruction.cpp:70,74): its points are
-    // in HBM already, update() then uploads the normals only -- when the frame in the library is still that upload
-    // (tsdf_frame_serial) and the cloud is still that cloud: same array, same size and the same bytes in a sample of
-    // its points (a cloud changed in place, or another one allocated at the same address, does not pass for it).
-    // One-shot: true once per tracked cloud.  TSDF_SHIM_NO_CLOUD_REUSE switches the reuse off altogether.
-    bool take_tracked(const SDF* sdf, const pcl::PointCloud<pcl::PointXYZRGB>& c) {
-#ifdef TSDF_SHIM_NO_CLOUD_REUSE
-        (void)sdf; (void)c;
-        return false;
-#else
-        const bool same = token_.valid && token_ == FrameToken(c, tsdf_frame_serial(sdf->handle()));
-        token_ = FrameToken();
-        return same;
-#endif
+        sdf->check(rc, "tsdf_track_aos");
     }
     // camera_tracking.cpp:40-47: ij = K * camera_point, (u, v) = ij.xy / ij.z   (fixed-size product, Eigen 3.2 order)
     void project_camera_to_image_plane(Eigen::Vector3d& camera_point, Eigen::Vector2d& image_point) {
@@ -511,36 +495,21 @@ public:
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 
 private:
-    struct FrameToken {                    // identifies "the cloud estimate_new_position uploaded"
-        bool valid;
-        const void* points; uint32_t w, h; int64_t serial; uint64_t sum;
-        FrameToken() : valid(false), points(nullptr), w(0), h(0), serial(-1), sum(0) {}
-        FrameToken(const pcl::PointCloud<pcl::PointXYZRGB>& c, int64_t serial_)
-            : valid(true), points(c.points.data()), w(c.width), h(c.height), serial(serial_), sum(0) {
-            const size_t n = c.points.size();
-            const unsigned char* b = reinterpret_cast<const unsigned char*>(c.points.data());
-            for (int k = 0; k < 32 && n; ++k) {            // 32 points spread over the array: FNV-1a over their 16 payload bytes
-                const size_t i = (n - 1) * (size_t)k / 31;
-                for (size_t q = 0; q < 16; ++q) sum = (sum ^ b[i * sizeof(pcl::PointXYZRGB) + q]) * 1099511628211ull;
-            }
-        }
-        bool operator==(const FrameToken& o) const {
-            return valid && o.valid && points == o.points && w == o.w && h == o.h && serial == o.serial && sum == o.sum;
-        }
-    };
     tsdf_shim::CameraTracking impl_;
-    FrameToken token_;
     Eigen::Matrix3d seen_rot_, seen_rot_inv_, seen_K_;
     Eigen::Vector3d seen_trans_, seen_rot_inv_trans_;
 };
 
+// sdf.h:161-163.  The reference hands the cloud it has just tracked to SDF::update (sdf_reconstruction.cpp:70,74): its
+// points are in HBM already and tsdf_integrate_aos uploads the normals only -- after the LIBRARY has checked, on its
+// staging threads and under the normals' copy, that the cloud still holds the bytes that were tracked (every point: a
+// cloud filtered in place between the two calls, or another one at the same address, is uploaded again and integrated as
+// it is now, as sdf.cpp:258-259 would read it).
 inline void SDF::update(CameraTracking* camera_tracking, pcl::PointCloud<pcl::PointXYZRGB>::Ptr cloud_filtered,
                         pcl::PointCloud<pcl::Normal>::Ptr normals) {
     if (camera_tracking) camera_tracking->push(this);
-    const bool reuse = camera_tracking && camera_tracking->take_tracked(this, *cloud_filtered);
-    check(tsdf_set_frame_aos(handle(), reuse ? nullptr : cloud_filtered->points.data(), normals->points.data(), &pcl_layout(),
-                             (int32_t)cloud_filtered->width, (int32_t)cloud_filtered->height), "tsdf_set_frame_aos");
-    tsdf_shim::SDF::update(camera_tracking ? camera_tracking->impl() : nullptr);
+    check(tsdf_integrate_aos(handle(), cloud_filtered->points.data(), normals->points.data(), &pcl_layout(),
+                             (int32_t)cloud_filtered->width, (int32_t)cloud_filtered->height, nullptr), "tsdf_integrate_aos");
 }
 
 }  // namespace ref_types

@@ -209,6 +209,25 @@ int tsdf_set_frame_aos(tsdf_handle *h, const void *points, const void *normals, 
 int tsdf_queue_frame_aos(tsdf_handle *h, const void *points, const void *normals, const tsdf_aos_layout *layout,
                          int32_t width, int32_t height);   /* see tsdf_queue_frame */
 
+/* The reference's two hot calls on its own clouds, as kinect_callback issues them (sdf_reconstruction.cpp:70,74):
+ *   tsdf_track_aos      = CameraTracking::estimate_new_position(sdf, cloud)        camera_tracking.h:101
+ *   tsdf_integrate_aos  = SDF::update(tracker, cloud, normals)                     sdf.h:161-163
+ * tsdf_track_aos makes `points` the current frame and tracks it: the tracker's samples (every pixel_stride-th point of
+ * every pixel_stride-th row, 0.5 MB at 640x480) are gathered and copied first and the Gauss-Newton passes run on them while
+ * the library's threads repack the whole cloud and the frame stream copies it -- the 4.6 MB of a 640x480 cloud travel
+ * UNDER the passes instead of in front of them.  The cloud is borrowed for the call only.  Pose / error behaviour as
+ * tsdf_track.  The frame has no normals yet: tsdf_integrate needs tsdf_integrate_aos (or tsdf_set_frame_aos) first.
+ * tsdf_integrate_aos completes the frame with `normals` and integrates it.  `points` may be NULL (= the tracked cloud)
+ * or the cloud itself, as SDF::update receives it: the library then compares it, every point, with what it staged when
+ * the cloud was tracked (on its threads, under the copy of the normals) and uploads it again only when it is another
+ * cloud or was changed in place -- SDF::update integrates the cloud as it is when update is called (sdf.cpp:258-259).
+ * Without a cloud tracked by tsdf_track_aos (frame 1 of a sequence, sdf_reconstruction.cpp:69) it is
+ * tsdf_set_frame_aos(points, normals) + tsdf_integrate.  Buffers are borrowed for the call only. */
+int tsdf_track_aos(tsdf_handle *h, const void *points, const tsdf_aos_layout *layout, int32_t width, int32_t height,
+                   tsdf_track_stats *stats);
+int tsdf_integrate_aos(tsdf_handle *h, const void *points, const void *normals, const tsdf_aos_layout *layout,
+                       int32_t width, int32_t height, tsdf_integrate_stats *stats);
+
 /* ---- optional: depth pre-processing on the GPU.  Replaces, for callers that have a raw
  * depth image instead of PCL clouds, the host-side steps of sdf_reconstruction.cpp:29-49 (cloud conversion,
  * pcl::FastBilateralFilter, pcl::IntegralImageNormalEstimation).  PCL is not available here, so this is the

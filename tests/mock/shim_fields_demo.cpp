@@ -89,7 +89,11 @@ int main(int argc, char** argv) {
         td.estimate_new_position(&d, clouds[1]);
         Matrix3d Rc = tc.rot; Vector3d tcv = tc.trans;
         td.set_camera_transformation(Rc, tcv);                  // (same pose anyway; keeps the two bit-identical)
-        for (size_t i = 0; i < clouds[1]->points.size(); ++i) clouds[1]->points[i].z += 0.05f;     // in place, same array
+        {   // in place, same array, ONE point (and not one a sampled token would look at): every point is compared
+            size_t i = clouds[1]->points.size() / 2 + 37;
+            while (!(clouds[1]->points[i].z == clouds[1]->points[i].z)) ++i;
+            clouds[1]->points[i].z += 0.05f;
+        }
         c.update(&tc, clouds[1], nrms[1]);                      // must notice and upload the points again
         CloudPtr fresh(new pcl::PointCloud<pcl::PointXYZRGB>(*clouds[1]));                         // another array: no reuse possible
         d.update(&td, fresh, nrms[1]);

@@ -74,7 +74,34 @@ def aos_tight(s, t, k, xyz, nrm, rgb):
     s.update()
 
 
-@pytest.mark.parametrize("feed", [aos_reference_order, aos_tight])
+def aos_entry_points(s, t, k, xyz, nrm, rgb):
+    """tsdf_track_aos / tsdf_integrate_aos: the reference's two calls, the cloud handed to both (sdf_reconstruction.cpp:70,74)"""
+    pts, nn = clouds(xyz, nrm, rgb)
+    if k > 0:
+        s.track_aos(pts)                      # estimate_new_position(sdf, cloud_filtered): samples first
+    s.update_aos(pts, nn)                     # update(tracker, cloud_filtered, normals); k == 0: nothing was tracked
+
+
+def aos_entry_points_no_cloud(s, t, k, xyz, nrm, rgb):
+    pts, nn = clouds(xyz, nrm, rgb)
+    if k > 0:
+        s.track_aos(pts)
+        s.update_aos(None, nn)                # "the tracked cloud"
+    else:
+        s.update_aos(pts, nn)
+
+
+def aos_entry_points_tight(s, t, k, xyz, nrm, rgb):
+    pd = np.dtype({"names": ["r", "g", "b", "x", "y", "z"], "formats": ["u1", "u1", "u1", "<f4", "<f4", "<f4"],
+                   "offsets": [0, 1, 2, 4, 8, 12], "itemsize": 16})
+    nd = np.dtype([("normal_x", "<f4"), ("normal_y", "<f4"), ("normal_z", "<f4")])
+    pts, nn = clouds(xyz, nrm, rgb, pd, nd)
+    if k > 0:
+        s.track_aos(pts)
+    s.update_aos(pts, nn)
+
+
+@pytest.mark.parametrize("feed", [aos_reference_order, aos_tight, aos_entry_points, aos_entry_points_no_cloud, aos_entry_points_tight])
 def test_aos_frames_give_the_planar_result(feed):
     want = run_sequence(planar)
     got = run_sequence(feed)
@@ -212,3 +239,85 @@ def test_queued_frames_give_the_same_trajectory_and_volume(kind):
     assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2])
     for a, b in zip(want[3], got[3]):
         assert np.array_equal(a, b)
+
+
+def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
+    """sdf.cpp:258-259 reads the cloud at update time.  Between estimate_new_position and update the caller may (a) change
+    ONE point of the tracked cloud in place -- the 32-point token of round 4's shim would not have seen it -- or (b) hand
+    over another cloud altogether, or (c) call update twice: each time the volume must be what the planar path gives for
+    the points update received, and the tracked pose what tracking the ORIGINAL cloud gives."""
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=3, width=W, height=H, noise=True, holes=0.02, step=4)
+    fr = [seq.frame(k) for k in range(3)]
+
+    def run(entry_points, variant):
+        s = ts.SDF(M, with_color=True)
+        t = ts.CameraTracking(sdf=s)
+        t.set_K(seq.K)
+        s.set_frame(*fr[0]); s.update()
+        xyz, nrm, rgb = (a.copy() for a in fr[1])
+        pts, nn = clouds(xyz, nrm, rgb)
+        if entry_points:
+            st = s.track_aos(pts)
+        else:
+            s.set_frame(xyz, None, rgb)
+            st = t.estimate_new_position()
+        pose = (t.rot.copy(), t.trans.copy(), st["iterations"])
+        if variant == "one point":
+            r, c = np.argwhere(np.isfinite(xyz[..., 2]))[1234]
+            xyz[r, c, 2] += 0.05; pts["z"][r, c] = xyz[r, c, 2]
+            rgb[r, c, 1] ^= 0x40; pts["g"][r, c] = rgb[r, c, 1]
+        elif variant == "other cloud":
+            xyz, nrm, rgb = (a.copy() for a in fr[2])
+            pts, nn = clouds(xyz, nrm, rgb)
+        if entry_points:
+            s.update_aos(pts, nn)
+            if variant == "twice":
+                s.update_aos(pts, nn)
+        else:
+            s.set_frame(xyz, nrm, rgb); s.update()
+            if variant == "twice":
+                s.update()
+        out = (pose, s.download(), s.download_color())
+        s.close()
+        return out
+    for variant in ("same", "one point", "other cloud", "twice"):
+        want, got = run(False, variant), run(True, variant)
+        assert np.array_equal(want[0][0], got[0][0]) and np.array_equal(want[0][1], got[0][1]) and want[0][2] == got[0][2], variant
+        for a, b in zip(want[1] + want[2], got[1] + got[2]):
+            assert np.array_equal(a, b), variant
+    # and the one changed point really changes the volume (the test would notice a skipped upload)
+    a, b = run(True, "same"), run(True, "one point")
+    assert not np.array_equal(a[1][0], b[1][0])
+
+
+def test_track_aos_state_and_argument_checks():
+    import ctypes as C
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=2, width=W, height=H, noise=True, holes=0.02, step=4)
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    pts0, nn0 = clouds(*seq.frame(0))
+    pts1, nn1 = clouds(*seq.frame(1))
+    s.update_aos(pts0, nn0)
+    serial = s.frame_serial()
+    s.track_aos(pts1)
+    assert s.frame_serial() == serial + 1
+    with pytest.raises(ts.TsdfError) as ei:
+        s.update()                                   # the tracked frame has no normals yet
+    assert ei.value.code == ts.E_NO_FRAME
+    rot, trans = t.rot.copy(), t.trans.copy()
+    s.update_aos(None, nn1)
+    assert s.frame_serial() == serial + 1            # the same frame, completed
+    lay = ts.AosLayout(8, 0, -1, -1, -1, 12, 0)      # 8-byte stride cannot hold three floats
+    assert ts.lib().tsdf_track_aos(s._h, C.c_void_p(pts1.ctypes.data), C.byref(lay), W, H, None) == ts.E_BADARG
+    assert ts.lib().tsdf_integrate_aos(s._h, None, None, C.byref(lay), W, H, None) == ts.E_BADARG
+    # a failing tracker call (no valid sample) leaves the pose alone and the handle usable
+    nanpts = pts1.copy(); nanpts["x"] = np.nan
+    with pytest.raises(ts.TsdfError) as ei:
+        s.track_aos(nanpts)
+    assert ei.value.code == ts.E_NO_SAMPLES and np.array_equal(t.rot, rot) and np.array_equal(t.trans, trans)
+    s.track_aos(pts1)
+    s.update_aos(pts1, nn1)
+    s.close()

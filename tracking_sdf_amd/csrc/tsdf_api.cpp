@@ -157,6 +157,14 @@ struct tsdf_handle {
     // second staging set of the frame queue's pageable path: frame k+1 is filled into one set while the DMA engine still
     // reads frame k from the other (with one set the caller's thread waited for those copies before every queue call)
     float* alt_xyz = nullptr; float* alt_nrm = nullptr; uint8_t* alt_rgb = nullptr; size_t alt_cap = 0;
+    // tsdf_track_aos / tsdf_integrate_aos (the reference's two calls on its own clouds): the tracker's samples go up first,
+    // through their own pinned list; the cloud estimate_new_position was called with, for SDF::update's "same cloud?" check
+    float4* pin_samples[2] = {nullptr, nullptr}; size_t pin_samples_cap = 0;
+    struct TrackedCloud {
+        bool valid = false, color = false;
+        const void* points = nullptr; int32_t w = 0, h = 0; int64_t serial = -1;
+        tsdf_aos_layout lay{};
+    } tracked;
     hipEvent_t ev_stage_done[2] = {nullptr, nullptr};   // [0]: the copies out of the set in use have been issued up to here; [1]: the other set's
     bool stage_recorded[2] = {false, false};
     size_t in_cap = 0;             // pixels the staging buffers hold
@@ -342,6 +350,9 @@ void free_frame(tsdf_handle* h) {
     if (h->in_xyz) (void)hipFree(h->in_xyz);
     if (h->pin_xyz) (void)hipHostFree(h->pin_xyz);
     if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
+    for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
+    h->pin_samples_cap = 0;
+    h->tracked = tsdf_handle::TrackedCloud();
     h->in_xyz = h->in_nrm = nullptr; h->in_rgb = nullptr;
     h->pin_xyz = h->pin_nrm = nullptr; h->pin_rgb = nullptr;
     h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
@@ -1488,6 +1499,22 @@ void queue_thread_main(tsdf_handle* h) {
     }
 }
 
+// the second set of pinned staging planes (the frame queue and tsdf_track_aos alternate between two sets)
+int ensure_second_staging_set(tsdf_handle* h, size_t npix) {
+    if (h->alt_cap >= npix) return TSDF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
+    h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
+    // the same block layout as the first set and the device block: sized like them (in_cap pixels)
+    const size_t plane = plane_stride_bytes(h->in_cap);
+    char* pin = nullptr;
+    HIP_TRY(h, hipHostMalloc((void**)&pin, frame_block_bytes(h->in_cap), hipHostMallocDefault));
+    h->alt_xyz = reinterpret_cast<float*>(pin); h->alt_nrm = reinterpret_cast<float*>(pin + plane); h->alt_rgb = reinterpret_cast<uint8_t*>(pin + 2 * plane);
+    h->alt_cap = h->in_cap;
+    h->stage_recorded[0] = h->stage_recorded[1] = false;
+    return TSDF_OK;
+}
+
 // what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
 int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
                        bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
@@ -1519,18 +1546,8 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     // pageable buffers: a library thread fills pinned staging planes (with the staging pool) and issues copies and pack
     // while the caller goes on.  Two sets of staging planes alternate: the one that is filled now last fed the copies of
     // the frame before the current one, and the library thread, not the caller, waits for those if it has to.
-    if (h->alt_cap < npix) {
-        HIP_TRY(h, hipStreamSynchronize(h->fstream));
-        if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
-        h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
-        // the same block layout as the first set and the device block: sized like them (in_cap pixels)
-        const size_t plane = plane_stride_bytes(h->in_cap);
-        char* pin = nullptr;
-        HIP_TRY(h, hipHostMalloc((void**)&pin, frame_block_bytes(h->in_cap), hipHostMallocDefault));
-        h->alt_xyz = reinterpret_cast<float*>(pin); h->alt_nrm = reinterpret_cast<float*>(pin + plane); h->alt_rgb = reinterpret_cast<uint8_t*>(pin + 2 * plane);
-        h->alt_cap = h->in_cap;
-        h->stage_recorded[0] = h->stage_recorded[1] = false;
-    }
+    rc = ensure_second_staging_set(h, npix);
+    if (rc) return rc;
     {   // TSDF_STAGE_SETS=1 (diagnosis): wait here, on the caller's thread, as the single staging set of round 3 made it do
         static const bool one_set = [] { const char* e = std::getenv("TSDF_STAGE_SETS"); return e && std::atoi(e) == 1; }();
         if (one_set) HIP_TRY(h, hipStreamSynchronize(h->fstream));
@@ -2031,9 +2048,18 @@ int tsdf_gn_update(tsdf_handle* h, const double A[36], const double b[6], double
     return TSDF_OK;
 }
 
+namespace {
+int track_loop(tsdf_handle* h, tsdf_track_stats* stats);
+}
 int tsdf_track(tsdf_handle* h, tsdf_track_stats* stats) {
     int rc = check_ready(h, true);
     if (rc) return rc;
+    return track_loop(h, stats);
+}
+namespace {
+// camera_tracking.cpp:79-239: the Gauss-Newton loop on the current frame's sample list
+int track_loop(tsdf_handle* h, tsdf_track_stats* stats) {
+    int rc = TSDF_OK;
     bool stop = false;
     int g = 0;
     double A[36], b[6], twist[6] = {0, 0, 0, 0, 0, 0};
@@ -2070,6 +2096,7 @@ int tsdf_track(tsdf_handle* h, tsdf_track_stats* stats) {
     }
     return TSDF_OK;
 }
+}  // namespace
 
 int tsdf_track_and_integrate(tsdf_handle* h, int32_t do_track, tsdf_track_stats* track_stats, tsdf_integrate_stats* integrate_stats) {
     if (do_track) {
@@ -2077,6 +2104,219 @@ int tsdf_track_and_integrate(tsdf_handle* h, int32_t do_track, tsdf_track_stats*
         if (rc) return rc;
     }
     return tsdf_integrate(h, integrate_stats);
+}
+
+// ---- the reference's two hot calls on its own clouds (sdf_reconstruction.cpp:70,74) -------------------------------------
+// kinect_callback calls estimate_new_position(sdf, cloud) and then update(tracker, cloud, normals), synchronously, with the
+// clouds in pageable memory.  Through tsdf_set_frame_aos that was: upload ALL points (repack 9.8 MB, copy 4.6 MB, pack) ->
+// track -> wait for the frame stream on the host, upload the normals, pack again -> integrate.  The tracker needs 34 240 of
+// the 307 200 points: tsdf_track_aos gathers those into a pinned list (0.5 MB), copies it, and starts the Gauss-Newton
+// passes; the whole cloud is repacked by the library threads and copied on the frame stream UNDER the passes.  The cloud
+// is the caller's again when the call returns (the repack is over; the copy reads the library's pinned planes).
+// tsdf_integrate_aos adds the normals (repack, one copy), checks -- under that copy -- that `points` still is the cloud
+// that was tracked, byte for byte, and only uploads it again when it is not.
+namespace {
+int check_point_layout(tsdf_handle* h, const char* who, const tsdf_aos_layout* L, bool* color) {
+    *color = L->r_offset >= 0 && L->g_offset >= 0 && L->b_offset >= 0;
+    if (L->point_stride < 12 || L->xyz_offset < 0 || L->xyz_offset + 12 > L->point_stride ||
+        (*color && (L->r_offset >= L->point_stride || L->g_offset >= L->point_stride || L->b_offset >= L->point_stride)))
+        return fail(h, TSDF_E_BADARG, "%s: point layout (stride %d, xyz at %d) does not hold three floats and the colour bytes", who,
+                    L->point_stride, L->xyz_offset);
+    return TSDF_OK;
+}
+int check_normal_layout(tsdf_handle* h, const char* who, const tsdf_aos_layout* L) {
+    if (L->normal_stride < 12 || L->normal_offset < 0 || L->normal_offset + 12 > L->normal_stride)
+        return fail(h, TSDF_E_BADARG, "%s: normal layout (stride %d, normal at %d) does not hold three floats", who,
+                    L->normal_stride, L->normal_offset);
+    return TSDF_OK;
+}
+// do the points [i0, i1) of an array-of-structs cloud still hold the bytes that were repacked into the planes?
+bool points_equal_planes(const tsdf_aos_layout& lay, const void* points, bool color, const float* px, const uint8_t* pc, size_t i0, size_t i1) {
+    const char* p = (const char*)points + i0 * (size_t)lay.point_stride;
+    unsigned diff = 0u;
+    for (size_t i = i0; i < i1; ++i, p += lay.point_stride) {
+        diff |= (unsigned)(std::memcmp(px + 3 * i, p + lay.xyz_offset, 12) != 0);
+        if (color) diff |= (unsigned)((uint8_t)p[lay.r_offset] ^ pc[3 * i]) | (unsigned)((uint8_t)p[lay.g_offset] ^ pc[3 * i + 1]) | (unsigned)((uint8_t)p[lay.b_offset] ^ pc[3 * i + 2]);
+    }
+    return diff == 0u;
+}
+}  // namespace
+
+int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L, int32_t width, int32_t height, tsdf_track_stats* stats) {
+    if (!h || !L || !points || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_track_aos: bad argument") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_track_aos");
+    bool color = false;
+    int rc = check_point_layout(h, "tsdf_track_aos", L, &color);
+    if (rc) return rc;
+    rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    rc = ensure_second_staging_set(h, npix);
+    if (rc) return rc;
+    const size_t ns = (size_t)h->n_samples;
+    if (ns > h->pin_samples_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
+        h->pin_samples_cap = 0;
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipHostMalloc((void**)&h->pin_samples[b], ns * sizeof(float4), hipHostMallocDefault));
+        h->pin_samples_cap = ns;
+    }
+    if (!h->qthread.joinable()) {
+        try { h->qthread = std::thread(queue_thread_main, h); }
+        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_track_aos: cannot start the staging thread"); }
+    }
+    // the other set of pinned planes: the copies out of it were those of the frame before the last one
+    std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
+    std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
+    if (h->stage_recorded[0]) HIP_TRY(h, hipEventSynchronize(h->ev_stage_done[0]));
+    h->staged_xyz = false;
+    h->tracked = tsdf_handle::TrackedCloud();
+    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
+    h->deferred = tsdf_handle::DeferredPack();
+    // 1. the tracker's samples, in the reference's visiting order (columns outer, rows inner, camera_tracking.cpp:162-163),
+    //    straight from the cloud: sample (ci, rj) = point (ci * stride, rj * stride).  Sample rows are shared out over the
+    //    library threads (each reads along image rows).
+    const int nb = h->fidx ^ 1;
+    {
+        float4* const ps = h->pin_samples[nb];
+        const int32_t st = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows;
+        const tsdf_aos_layout lay = *L;
+        const std::function<void(int, int)> gather = [&](int part, int parts) {
+            const int r0 = (int)((long long)nrows * part / parts), r1 = (int)((long long)nrows * (part + 1) / parts);
+            for (int rj = r0; rj < r1; ++rj) {
+                const char* rowp = (const char*)points + ((size_t)rj * st * width) * (size_t)lay.point_stride + lay.xyz_offset;
+                for (int ci = 0; ci < ncols; ++ci) {
+                    float4 v;
+                    std::memcpy(&v, rowp + (size_t)ci * st * (size_t)lay.point_stride, 12);
+                    v.w = 0.0f;
+                    ps[(size_t)ci * nrows + rj] = v;
+                }
+            }
+        };
+        HostPool* const pool = host_pool(h);
+        if (pool) pool->run(gather); else gather(0, 1);
+        HIP_TRY(h, hipMemcpyAsync(h->samples_buf[nb], ps, ns * sizeof(float4), hipMemcpyHostToDevice, h->fstream));
+        HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
+    }
+    choose_pixel_layout(h);
+    h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
+    h->have_frame = true;
+    h->frame_serial++;
+    h->frame_has_nrm = false;                // the pixel records are written when the normals arrive (tsdf_integrate_aos)
+    h->frame_has_rgb = color;
+    h->frame_side = true;
+    // 2. the whole cloud -> pinned planes -> in_xyz / in_rgb, on the library threads and the frame stream, under the passes
+    {
+        const tsdf_aos_layout lay = *L;
+        std::lock_guard<std::mutex> g(h->qmu);
+        h->qbusy = true;
+        h->queued.err = hipSuccess;
+        h->qjob = [h, npix, points, lay, color] {
+            float* const px = h->pin_xyz; uint8_t* const pc = h->pin_rgb;
+            h->queued.err = stage_and_upload(h, npix, true, false, color, [&](size_t i0, size_t i1) {
+                repack_aos(lay, points, nullptr, color, px, nullptr, pc, i0, i1);
+            });
+        };
+    }
+    h->qcv.notify_all();
+    // 3. estimate_new_position on the list
+    const int rc_track = track_loop(h, stats);
+    // 4. the cloud is the caller's again when this call returns
+    {
+        std::unique_lock<std::mutex> g(h->qmu);
+        h->qcv.wait(g, [&] { return !h->qbusy; });
+    }
+    if (h->queued.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_track_aos: staging the cloud failed: %s", hipGetErrorString(h->queued.err));
+    HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));      // the copies out of this set of planes, so far
+    h->stage_recorded[0] = true;
+    h->staged_xyz = true;
+    h->tracked.valid = true; h->tracked.color = color; h->tracked.points = points; h->tracked.w = width; h->tracked.h = height;
+    h->tracked.serial = h->frame_serial; h->tracked.lay = *L;
+    return rc_track;
+}
+
+int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height,
+                       tsdf_integrate_stats* stats) {
+    if (!h || !L || !normals || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_integrate_aos: bad argument (the normals are required)") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_integrate_aos");
+    bool color = false;
+    int rc = points ? check_point_layout(h, "tsdf_integrate_aos", L, &color) : TSDF_OK;
+    if (rc) return rc;
+    rc = check_normal_layout(h, "tsdf_integrate_aos", L);
+    if (rc) return rc;
+    const tsdf_handle::TrackedCloud& tc = h->tracked;
+    // is the frame in the library the cloud estimate_new_position was given?  Identity first (cheap), contents below.
+    const bool candidate = tc.valid && h->have_frame && h->staged_xyz && tc.serial == h->frame_serial && tc.w == width && tc.h == height &&
+                           (!points || (points == tc.points && color == tc.color && L->point_stride == tc.lay.point_stride && L->xyz_offset == tc.lay.xyz_offset &&
+                                        L->r_offset == tc.lay.r_offset && L->g_offset == tc.lay.g_offset && L->b_offset == tc.lay.b_offset));
+    if (!candidate) {
+        // not the tracked cloud (or nothing was tracked through tsdf_track_aos): the whole frame goes up
+        rc = tsdf_set_frame_aos(h, points, normals, L, width, height);
+        if (rc) return rc;
+        return tsdf_integrate(h, stats);
+    }
+    rc = bind_device(h);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    const tsdf_aos_layout lay = *L;
+    HostPool* const pool = host_pool(h);
+    float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
+    auto split = [npix](int part, int parts, size_t* i0, size_t* i1) {
+        // multiples of four points, so that the 16-byte stores of the repack stay aligned in every part
+        *i0 = (npix * (size_t)part / (size_t)parts) & ~(size_t)3; *i1 = part + 1 == parts ? npix : (npix * (size_t)(part + 1) / (size_t)parts) & ~(size_t)3;
+    };
+    // 1. the normals: repack into the pinned plane of the set that holds the cloud, one copy
+    {
+        const std::function<void(int, int)> fill = [&](int part, int parts) {
+            size_t i0, i1; split(part, parts, &i0, &i1);
+            repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
+        };
+        if (pool) pool->run(fill); else fill(0, 1);
+        HIP_TRY(h, hipMemcpyAsync(h->in_nrm, pnm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    }
+    // 2. under that copy: is `points` still, byte for byte, what was repacked when it was tracked?  (A cloud filtered in
+    //    place between the two calls must be integrated as it is NOW: sdf.cpp:258-259 reads it at update time.)
+    bool same = true;
+    if (points) {
+        std::atomic<int> differs{0};
+        const std::function<void(int, int)> verify = [&](int part, int parts) {
+            size_t i0, i1; split(part, parts, &i0, &i1);
+            if (!points_equal_planes(lay, points, color, px, pc, i0, i1)) differs.store(1, std::memory_order_relaxed);
+        };
+        if (pool) pool->run(verify); else verify(0, 1);
+        same = differs.load() == 0;
+    }
+    if (!same) {
+        h->tracked.valid = false;
+        HIP_TRY(h, stage_and_upload(h, npix, true, false, color, [&](size_t i0, size_t i1) {
+            repack_aos(lay, points, nullptr, color, px, nullptr, pc, i0, i1);
+        }));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));
+    h->stage_recorded[0] = true;
+    // 3. the pixel records (and, for a changed cloud, its sample list), then SDF::update
+    choose_pixel_layout(h);
+    rc = wait_buffer_free(h, h->fidx, h->fstream);
+    if (rc) return rc;
+    {
+        PackArgs pa = pack_args(h, h->in_xyz, h->in_nrm, h->frame_has_rgb ? h->in_rgb : nullptr, h->pix_su, h->pix_sv, h->fidx);
+        if (same) pa.samples = nullptr;          // uploaded by tsdf_track_aos
+        EventPair* ep;
+        rc = timed_begin(h, 1, &ep, h->fstream);
+        if (rc) return rc;
+        HIP_TRY(h, launch_pack(h->fstream, pa));
+        rc = timed_end(h, ep, h->fstream);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
+    h->frame_has_nrm = true;
+    h->frame_side = true;
+    h->tracked.valid = false;                // one-shot: a second update of the same cloud uploads it
+    return tsdf_integrate(h, stats);
 }
 
 int tsdf_sample(tsdf_handle* h, const double* vox, int32_t n, float* val, int32_t* ok) {
