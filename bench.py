@@ -726,6 +726,32 @@ def run(args):
             "update adds the normals and compares the cloud instead of uploading it again.  _round4_sequence: what the shim issued until "
             "round 4 (tsdf_set_frame_aos(points) -> tsdf_track -> tsdf_set_frame_aos(normals only) -> tsdf_integrate).  The normals are only "
             "handed over by update, so their repack and copy (3.7 MB) sit between a frame's last pass and its integration whatever the library does")
+        # ... and the same loop in C++ through the reference's exact signatures (tests/mock/refcall_demo.cpp, built against the
+        # mock Eigen / PCL headers: test infrastructure; the library underneath is the product), on the same frames
+        try:
+            import struct
+            import tempfile
+            subprocess.check_call(["make", "-C", ROOT, "-s", "refcall_demo"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with tempfile.TemporaryDirectory(prefix="tsdf_refcall_", dir="/tmp") as td:
+                fb = os.path.join(td, "frames.bin")
+                with open(fb, "wb") as f:
+                    f.write(struct.pack("<3i", len(host_frames), width, height))
+                    f.write(np.ascontiguousarray(seq.K, dtype="<f8").tobytes())
+                    for k, (x, n_, c) in enumerate(host_frames):
+                        f.write(struct.pack("<d", float(seq.stamps[k])))
+                        f.write(np.ascontiguousarray(x, dtype="<f4").tobytes()); f.write(np.ascontiguousarray(n_, dtype="<f4").tobytes())
+                        f.write(np.ascontiguousarray(c, dtype=np.uint8).tobytes())
+                best = 0.0
+                for _ in range(2):
+                    pr = subprocess.run([os.path.join(ROOT, "build", "refcall_demo"), fb, str(m), os.path.join(td, "traj.txt")],
+                                        capture_output=True, text=True, timeout=300)
+                    for line in pr.stderr.splitlines():
+                        if line.startswith("RATE "):
+                            best = max(best, float(line.split()[1]))
+                extras["value_reference_entry_points_cpp"] = best if best > 0 else None
+        except Exception as e:      # noqa: BLE001
+            extras["value_reference_entry_points_cpp"] = None
+            extras["reference_entry_points_cpp_error"] = f"{type(e).__name__}: {e}"
         e4 = best_of_two("aos", aos)
         extras["value_pcl_clouds_inclusive"] = args.steps / e4
         extras["pcl_clouds_note"] = ("frames handed over as arrays of PCL's 32-byte point / normal structs in pageable memory "

@@ -243,7 +243,7 @@ def test_queued_frames_give_the_same_trajectory_and_volume(kind):
 
 def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
     """sdf.cpp:258-259 reads the cloud at update time.  Between estimate_new_position and update the caller may (a) change
-    ONE point of the tracked cloud in place -- the 32-point token of round 4's shim would not have seen it -- or (b) hand
+    a handful of points of the tracked cloud in place -- the 32-point token of round 4's shim would not have seen them -- or (b) hand
     over another cloud altogether, or (c) call update twice: each time the volume must be what the planar path gives for
     the points update received, and the tracked pose what tracking the ORIGINAL cloud gives."""
     import tracking_sdf_amd as ts
@@ -263,10 +263,11 @@ def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
             s.set_frame(xyz, None, rgb)
             st = t.estimate_new_position()
         pose = (t.rot.copy(), t.trans.copy(), st["iterations"])
-        if variant == "one point":
-            r, c = np.argwhere(np.isfinite(xyz[..., 2]))[1234]
-            xyz[r, c, 2] += 0.05; pts["z"][r, c] = xyz[r, c, 2]
-            rgb[r, c, 1] ^= 0x40; pts["g"][r, c] = rgb[r, c, 1]
+        if variant == "one point":              # "a handful": 8 of the 19 200 points (a pixel without a voxel in reach changes nothing)
+            valid = np.argwhere(np.isfinite(xyz[..., 2]) & np.isfinite(nrm[..., 2]))
+            for r, c in valid[np.linspace(500, len(valid) - 500, 8).astype(int)]:
+                xyz[r, c, 2] += 0.05; pts["z"][r, c] = xyz[r, c, 2]
+                rgb[r, c, 1] ^= 0x40; pts["g"][r, c] = rgb[r, c, 1]
         elif variant == "other cloud":
             xyz, nrm, rgb = (a.copy() for a in fr[2])
             pts, nn = clouds(xyz, nrm, rgb)
@@ -288,7 +289,7 @@ def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
             assert np.array_equal(a, b), variant
     # and the one changed point really changes the volume (the test would notice a skipped upload)
     a, b = run(True, "same"), run(True, "one point")
-    assert not np.array_equal(a[1][0], b[1][0])
+    assert not np.array_equal(a[1][0], b[1][0]) and not np.array_equal(a[2][2], b[2][2])
 
 
 def test_track_aos_state_and_argument_checks():

@@ -56,6 +56,7 @@ class HostPool {
 public:
     explicit HostPool(int workers) {
         // a thread that cannot be started (resource limits) only means fewer parts: nothing may throw across the C ABI
+        if (const char* e = std::getenv("TSDF_POOL_SPIN_US")) spin_ns_ = (long long)std::atoi(e) * 1000ll;
         try {
             threads_.reserve((size_t)workers);
             for (int i = 0; i < workers; ++i) threads_.emplace_back([this, i] { loop(i + 1); });
@@ -63,43 +64,78 @@ public:
         }
     }
     ~HostPool() {
-        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        { std::lock_guard<std::mutex> g(mu_); stop_.store(true, std::memory_order_release); }
         cv_.notify_all();
         for (auto& t : threads_) t.join();
     }
     int parts() const { return (int)threads_.size() + 1; }
     void run(const std::function<void(int, int)>& fn) {
         if (threads_.empty()) { fn(0, 1); return; }
-        { std::lock_guard<std::mutex> g(mu_); fn_ = &fn; pending_ = (int)threads_.size(); ++gen_; }
-        cv_.notify_all();
+        fn_ = &fn;
+        pending_.store((int)threads_.size(), std::memory_order_relaxed);
+        {   // the generation is published under the mutex so that a worker about to sleep cannot miss it
+            std::lock_guard<std::mutex> g(mu_);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
         fn(0, parts());
-        std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [this] { return pending_ == 0; });
+        // the workers are a few microseconds behind at most: spin, then sleep
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
+            cpu_relax();
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                std::unique_lock<std::mutex> g(mu_);
+                done_.wait(g, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+                break;
+            }
+        }
         fn_ = nullptr;
     }
 
 private:
+    static void cpu_relax() {
+#if defined(__SSE2__)
+        _mm_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    // A frame's host-side work comes as 2-4 short jobs in quick succession (gather the samples, repack the cloud, repack
+    // the normals, compare): waking a sleeping thread costs 20-50 us each time -- as much as the job.  A worker therefore
+    // keeps looking for the next job for spin_ns_ after the last one (TSDF_POOL_SPIN_US, default 150) before it sleeps;
+    // between frames of a live stream (33 ms) everybody sleeps.
     void loop(int part) {
         unsigned long long seen = 0;
         for (;;) {
-            const std::function<void(int, int)>* fn;
-            {
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_; fn = fn_;
+            bool got = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;; ++spins) {
+                if (stop_.load(std::memory_order_acquire)) return;
+                if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; }
+                if ((spins & 63u) == 63u && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns_) break;
+                cpu_relax();
             }
+            if (!got) {
+                std::unique_lock<std::mutex> g(mu_);
+                sleepers_.fetch_add(1, std::memory_order_release);
+                cv_.wait(g, [&] { return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_release);
+                if (stop_.load(std::memory_order_acquire)) return;
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            const std::function<void(int, int)>* fn = fn_;
             (*fn)(part, parts());
-            { std::lock_guard<std::mutex> g(mu_); if (--pending_ == 0) done_.notify_one(); }
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> g(mu_); done_.notify_one(); }
         }
     }
     std::vector<std::thread> threads_;
     std::mutex mu_;
     std::condition_variable cv_, done_;
     const std::function<void(int, int)>* fn_ = nullptr;
-    unsigned long long gen_ = 0;
-    int pending_ = 0;
-    bool stop_ = false;
+    std::atomic<unsigned long long> gen_{0};
+    std::atomic<int> pending_{0}, sleepers_{0};
+    std::atomic<bool> stop_{false};
+    long long spin_ns_ = 150000;
 };
 
 }  // namespace
@@ -222,6 +258,10 @@ struct tsdf_handle {
     double* shard_host = nullptr;  // pinned: kTrackShards slots of kShardSlotDoubles (host side of the fan-in)
     bool host_fanin = true;        // the second level of the tracker fan-in runs on the host (TSDF_HOST_FANIN=0: on the device)
     unsigned integrate_launches = 0;
+    // tsdf_integrate_aos issues the frame's list_rows_kernel as soon as it is called (the list needs the pose, not the
+    // normals): tsdf_integrate then launches integrate_kernel alone -- if pose and intrinsics are still the ones listed for
+    bool list_ahead = false;
+    IntegrateParams list_ahead_params{};
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
     unsigned long long* track_stamps = nullptr;   // TSDF_TRACK_STAMPS=1: 8 device words per tracker workgroup (phase stamps of the last pass)
     // TSDF_TRACK_PROFILE=1: host-side clock of a pass, printed by tsdf_destroy (ns sums: parameters, launch call, wait
@@ -239,6 +279,9 @@ struct tsdf_handle {
         double sync_before = 0;  // queue_frame: waiting for the previous frame's copies to leave the staging planes
         double next_wait = 0;    // tsdf_next_frame: waiting for the staging thread
         double handoff = 0;      // queue call -> the staging thread starts the job
+        // tsdf_track_aos / tsdf_integrate_aos (ns sums)
+        long long aos_frames = 0;
+        double a_prep = 0, a_gather = 0, a_issue = 0, a_loop = 0, a_wait = 0, b_normals = 0, b_verify = 0, b_issue = 0, b_integrate = 0;
     } sp;
 
     // comm
@@ -577,6 +620,18 @@ int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t
     h->deferred = tsdf_handle::DeferredPack();
     h->deferred.pending = true; h->deferred.xyz = xyz; h->deferred.nrm = nrm; h->deferred.rgb = rgb;
     return TSDF_OK;
+}
+
+void fill_integrate_params(const tsdf_handle* h, IntegrateParams& p) {
+    std::memset(&p, 0, sizeof p);            // (compared bytewise by tsdf_integrate: no stray padding)
+    p.g = h->grid;
+    std::memcpy(p.rot_inv, h->pose.rot_inv, sizeof p.rot_inv);
+    std::memcpy(p.rot_inv_trans, h->pose.rot_inv_trans, sizeof p.rot_inv_trans);
+    std::memcpy(p.K, h->K, sizeof p.K);
+    p.width = h->fw; p.height = h->fh;
+    p.pix_su = h->pix_su; p.pix_sv = h->pix_sv;
+    p.with_color = h->cfg.with_color;
+    p.debug = h->integrate_debug;
 }
 
 void fill_track_params(const tsdf_handle* h, TrackParams& p) {
@@ -1171,6 +1226,14 @@ void tsdf_destroy(tsdf_handle* h) {
                              "tsdf_next_frame waits %.1f  workers %d\n",
                      h->sp.frames, h->sp.total / f, h->sp.fill_max / f, h->sp.first_chunk / f, h->sp.upload_calls / f, h->sp.sync_before / f,
                      h->sp.handoff / f, h->sp.next_wait / f, h->pool ? h->pool->parts() - 1 : 0);
+    }
+    if (h->sp.on && h->sp.aos_frames) {
+        const double f = (double)h->sp.aos_frames * 1e3;
+        std::fprintf(stderr, "AOS_PROFILE frames %lld  us per frame: tsdf_track_aos: prepare %.1f  gather samples %.1f  issue copy + start staging %.1f  "
+                             "Gauss-Newton loop %.1f  wait for the staging %.1f | tsdf_integrate_aos: repack normals + issue copy %.1f  compare cloud %.1f  "
+                             "pack launch + events %.1f  tsdf_integrate call %.1f\n",
+                     h->sp.aos_frames, h->sp.a_prep / f, h->sp.a_gather / f, h->sp.a_issue / f, h->sp.a_loop / f, h->sp.a_wait / f,
+                     h->sp.b_normals / f, h->sp.b_verify / f, h->sp.b_issue / f, h->sp.b_integrate / f);
     }
     if (h->track_profile && h->tp_passes)
         std::fprintf(stderr, "TRACKPROFILE passes %lld  ns per pass: parameters %.0f  launch call %.0f  wait for the row %.0f  fold+solve+pose %.0f\n",
@@ -1939,16 +2002,15 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     if (!h->frame_has_nrm) return fail(h, TSDF_E_NO_FRAME, "tsdf_integrate needs normals in the current frame");
     if (h->cfg.with_color && !h->frame_has_rgb)
         return fail(h, TSDF_E_NO_FRAME, "with_color=1 needs rgb in the current frame");
-    IntegrateParams p;
-    p.g = h->grid;
-    std::memcpy(p.rot_inv, h->pose.rot_inv, sizeof p.rot_inv);
-    std::memcpy(p.rot_inv_trans, h->pose.rot_inv_trans, sizeof p.rot_inv_trans);
-    std::memcpy(p.K, h->K, sizeof p.K);
-    p.width = h->fw; p.height = h->fh;
     if (h->deferred.pending) choose_pixel_layout(h);      // the records are written in this launch: lay them out for the pose they are read at
-    p.pix_su = h->pix_su; p.pix_sv = h->pix_sv;
-    p.with_color = h->cfg.with_color;
-    p.debug = h->integrate_debug;
+    IntegrateParams p;
+    fill_integrate_params(h, p);
+    // a list launched ahead (tsdf_integrate_aos) is this frame's list if nothing it was built from has changed since
+    const bool list_done = h->list_ahead && std::memcmp(&p, &h->list_ahead_params, sizeof p) == 0 && !h->deferred.pending &&
+                           !(h->queued.active && h->queued.device && h->queued.deferred && !h->queued.packed);
+    if (h->list_ahead && !list_done)         // launched ahead for another pose / frame (an error path in between): forget it
+        HIP_TRY(h, launch_integrate_list_reset(h->stream, h->work_count, h->integrate_launches));
+    h->list_ahead = false;
     unsigned long long before[kNumCounters];
     if (stats) {
         rc = fetch_counters(h);
@@ -1986,9 +2048,12 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
         fused = true;
     }
     {
-        const hipError_t le = launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                                               h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue,
-                                               fused ? &pa : nullptr, fused ? &rel : nullptr);
+        const hipError_t le = list_done
+            ? launch_integrate_items(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
+                                     h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue, nullptr)
+            : launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
+                               h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue,
+                               fused ? &pa : nullptr, fused ? &rel : nullptr);
         if (le != hipSuccess) {
             // nothing was packed: the frames stay borrowed and unpacked (a later launch, or tsdf_synchronize, packs them)
             if (fused) for (auto& b : h->borrowed) if (b.stream == 0 && b.ticket == rel.ticket && b.serial >= h->frame_serial + (fused_queued ? 1 : 0)) b.stream = -1;
@@ -2148,6 +2213,15 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
     bool color = false;
     int rc = check_point_layout(h, "tsdf_track_aos", L, &color);
     if (rc) return rc;
+    using pclk = std::chrono::steady_clock;
+    const bool prof = h->sp.on;
+    auto lap = [prof](pclk::time_point& t, double& acc) { if (prof) { const pclk::time_point n = pclk::now(); acc += std::chrono::duration<double, std::nano>(n - t).count(); t = n; } };
+    pclk::time_point tp = prof ? pclk::now() : pclk::time_point();
+    static const bool plain = [] { const char* e = std::getenv("TSDF_TRACK_AOS"); return e && std::atoi(e) == 0; }();
+    if (plain) {                                 // TSDF_TRACK_AOS=0 (comparison): the whole cloud in front of the passes, as round 4's shim did
+        rc = tsdf_set_frame_aos(h, points, nullptr, L, width, height);
+        return rc ? rc : tsdf_track(h, stats);
+    }
     rc = bind_device(h);
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, true);
@@ -2196,7 +2270,9 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
             }
         };
         HostPool* const pool = host_pool(h);
+        lap(tp, h->sp.a_prep);
         if (pool) pool->run(gather); else gather(0, 1);
+        lap(tp, h->sp.a_gather);
         HIP_TRY(h, hipMemcpyAsync(h->samples_buf[nb], ps, ns * sizeof(float4), hipMemcpyHostToDevice, h->fstream));
         HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
@@ -2222,13 +2298,17 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
         };
     }
     h->qcv.notify_all();
+    lap(tp, h->sp.a_issue);
     // 3. estimate_new_position on the list
     const int rc_track = track_loop(h, stats);
+    lap(tp, h->sp.a_loop);
     // 4. the cloud is the caller's again when this call returns
     {
         std::unique_lock<std::mutex> g(h->qmu);
         h->qcv.wait(g, [&] { return !h->qbusy; });
     }
+    lap(tp, h->sp.a_wait);
+    if (prof) h->sp.aos_frames++;
     if (h->queued.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_track_aos: staging the cloud failed: %s", hipGetErrorString(h->queued.err));
     HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));      // the copies out of this set of planes, so far
     h->stage_recorded[0] = true;
@@ -2247,6 +2327,18 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
     if (rc) return rc;
     rc = check_normal_layout(h, "tsdf_integrate_aos", L);
     if (rc) return rc;
+    using pclk = std::chrono::steady_clock;
+    const bool prof = h->sp.on;
+    auto lap = [prof](pclk::time_point& t, double& acc) { if (prof) { const pclk::time_point n = pclk::now(); acc += std::chrono::duration<double, std::nano>(n - t).count(); t = n; } };
+    pclk::time_point tp = prof ? pclk::now() : pclk::time_point();
+    {
+        static const bool plain = [] { const char* e = std::getenv("TSDF_TRACK_AOS"); return e && std::atoi(e) == 0; }();
+        if (plain) {                             // TSDF_TRACK_AOS=0 (comparison): round 4's shim -- the normals alone when a host frame of this size is current
+            const bool keep = points && h->have_frame && h->staged_xyz && h->fw == width && h->fh == height && h->frame_serial > 1;
+            rc = tsdf_set_frame_aos(h, keep ? nullptr : points, normals, L, width, height);
+            return rc ? rc : tsdf_integrate(h, stats);
+        }
+    }
     const tsdf_handle::TrackedCloud& tc = h->tracked;
     // is the frame in the library the cloud estimate_new_position was given?  Identity first (cheap), contents below.
     const bool candidate = tc.valid && h->have_frame && h->staged_xyz && tc.serial == h->frame_serial && tc.w == width && tc.h == height &&
@@ -2260,6 +2352,19 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
     }
     rc = bind_device(h);
     if (rc) return rc;
+    if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "camera matrix not received (reference: sdf.cpp:227-230 exits)");
+    if (h->cfg.with_color && !h->frame_has_rgb) return fail(h, TSDF_E_NO_FRAME, "with_color=1 needs rgb in the current frame");
+    // 0. the work list of this integration depends on the pose and the image size, not on the normals: its kernel runs on
+    //    the main stream while the normals are repacked and copied
+    choose_pixel_layout(h);
+    {
+        static const bool ahead = [] { const char* e = std::getenv("TSDF_LIST_AHEAD"); return !(e && std::atoi(e) == 0); }();
+        if (ahead) {
+            fill_integrate_params(h, h->list_ahead_params);
+            HIP_TRY(h, launch_integrate_list(h->stream, h->list_ahead_params, h->worklist, h->work_count, h->integrate_launches, nullptr));
+            h->list_ahead = true;
+        }
+    }
     const size_t npix = (size_t)width * height;
     const tsdf_aos_layout lay = *L;
     HostPool* const pool = host_pool(h);
@@ -2277,6 +2382,7 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
         if (pool) pool->run(fill); else fill(0, 1);
         HIP_TRY(h, hipMemcpyAsync(h->in_nrm, pnm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     }
+    lap(tp, h->sp.b_normals);
     // 2. under that copy: is `points` still, byte for byte, what was repacked when it was tracked?  (A cloud filtered in
     //    place between the two calls must be integrated as it is NOW: sdf.cpp:258-259 reads it at update time.)
     bool same = true;
@@ -2289,6 +2395,7 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
         if (pool) pool->run(verify); else verify(0, 1);
         same = differs.load() == 0;
     }
+    lap(tp, h->sp.b_verify);
     if (!same) {
         h->tracked.valid = false;
         HIP_TRY(h, stage_and_upload(h, npix, true, false, color, [&](size_t i0, size_t i1) {
@@ -2298,7 +2405,6 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
     HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));
     h->stage_recorded[0] = true;
     // 3. the pixel records (and, for a changed cloud, its sample list), then SDF::update
-    choose_pixel_layout(h);
     rc = wait_buffer_free(h, h->fidx, h->fstream);
     if (rc) return rc;
     {
@@ -2316,7 +2422,10 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
     h->frame_has_nrm = true;
     h->frame_side = true;
     h->tracked.valid = false;                // one-shot: a second update of the same cloud uploads it
-    return tsdf_integrate(h, stats);
+    lap(tp, h->sp.b_issue);
+    rc = tsdf_integrate(h, stats);
+    lap(tp, h->sp.b_integrate);
+    return rc;
 }
 
 int tsdf_sample(tsdf_handle* h, const double* vox, int32_t n, float* val, int32_t* ok) {

@@ -147,6 +147,14 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
                             unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */, bool queue,
                             const PackArgs* pack = nullptr /* the frame's records are still to be packed: done inside this launch */,
                             const ReleaseWord* release = nullptr /* with pack of borrowed planes: told to the host once they are read */);
+// the two halves of launch_integrate, for a caller that can issue the list before the frame's records are complete
+hipError_t launch_integrate_list(hipStream_t s, const IntegrateParams& p, void* worklist, unsigned* work_count,
+                                 unsigned launch_parity, const PackArgs* pack = nullptr);
+hipError_t launch_integrate_list_reset(hipStream_t s, unsigned* work_count, unsigned launch_parity);   // forget a list launched ahead
+hipError_t launch_integrate_items(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
+                                  const float4* pn, unsigned long long* counters,
+                                  void* worklist, unsigned* work_count, int n_blocks,
+                                  unsigned launch_parity, unsigned long long* wg_counts, bool queue, const ReleaseWord* release = nullptr);
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit

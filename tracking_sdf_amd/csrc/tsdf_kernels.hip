@@ -1676,11 +1676,12 @@ static bool use_exp_poly(const IntegrateParams& p) {
     return span >= 0.0 && 0.5 * span * span <= 0.04;
 }
 
-hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
-                            const float4* pn, unsigned long long* counters,
-                            void* worklist, unsigned* work_count, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts, bool queue, const PackArgs* pack,
-                            const ReleaseWord* release) {
+// The integrate launch is two kernels: the list (launch_integrate_list: list_rows_kernel, whose appended workgroups may
+// pack a frame's pixel records) and the items (launch_integrate_items: integrate_kernel over that list).  The list
+// depends on the pose and the image SIZE only, so a caller that still waits for the frame's normals can launch it ahead
+// (tsdf_integrate_aos); launch_integrate issues both back to back.
+hipError_t launch_integrate_list(hipStream_t s, const IntegrateParams& p, void* worklist, unsigned* work_count,
+                                 unsigned launch_parity, const PackArgs* pack) {
     const int m = p.g.m;
     const int nx = p.g.xe - p.g.xs;
     if (nx <= 0 || m <= 0) return hipSuccess;
@@ -1688,11 +1689,8 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     if (!make_tiling(p, tl)) return hipErrorInvalidValue;
     // two bookkeeping sets used alternately (see kBinSetWords)
     unsigned* const cur = work_count + (launch_parity & 1) * kBinSetWords;
-    unsigned* const nxt = work_count + ((launch_parity + 1) & 1) * kBinSetWords;
     unsigned* const xcd_fb = work_count + 2 * kBinSetWords;
-    if (n_blocks < 8 || (n_blocks & 7)) return hipErrorInvalidValue;      // eight XCDs take equal numbers of workgroups
     ItemDesc* const list = static_cast<ItemDesc*>(worklist);
-    hipError_t e = hipSuccess;
     const long long cblocks = (tl.n_rows + kClipBlock - 1) / kClipBlock;
     const unsigned ovf_base = (unsigned)integrate_band_region_entries(p.g);    // band regions in front of the overflow region
     // (pack: the frame's pixel records are still to be written -- workgroups behind the list's own do it, see the kernel)
@@ -1700,8 +1698,35 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
     const unsigned ptiles = pack ? (unsigned)pack_tiles(*pack) : 0u;
     list_rows_kernel<<<dim3((unsigned)cblocks + ptiles), dim3(kClipBlock), 0, s>>>(p, tl, cur, list, ovf_base, xcd_fb,
                                                                                    (unsigned)cblocks, pack ? *pack : no_pack);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// a list that was launched ahead and is not wanted after all (pose / intrinsics / frame changed before its integration):
+// put the launch parity's bookkeeping set back to what the previous integrate_kernel left (cursors 0, nothing overflowed)
+__global__ __launch_bounds__(64) void reset_list_kernel(unsigned* __restrict__ set) {
+    for (int t = threadIdx.x; t < kBins; t += 64) { set[kSetCur + t] = 0u; set[kSetFirstOvf + t] = ~0u; }
+    if (threadIdx.x == 0) set[kSetOvf] = 0u;
+}
+hipError_t launch_integrate_list_reset(hipStream_t s, unsigned* work_count, unsigned launch_parity) {
+    reset_list_kernel<<<dim3(1), dim3(64), 0, s>>>(work_count + (launch_parity & 1) * kBinSetWords);
+    return hipGetLastError();
+}
+
+hipError_t launch_integrate_items(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
+                                  const float4* pn, unsigned long long* counters,
+                                  void* worklist, unsigned* work_count, int n_blocks,
+                                  unsigned launch_parity, unsigned long long* wg_counts, bool queue, const ReleaseWord* release) {
+    const int m = p.g.m;
+    const int nx = p.g.xe - p.g.xs;
+    if (nx <= 0 || m <= 0) return hipSuccess;
+    IntegrateTiling tl;
+    if (!make_tiling(p, tl)) return hipErrorInvalidValue;
+    unsigned* const cur = work_count + (launch_parity & 1) * kBinSetWords;
+    unsigned* const nxt = work_count + ((launch_parity + 1) & 1) * kBinSetWords;
+    unsigned* const xcd_fb = work_count + 2 * kBinSetWords;
+    if (n_blocks < 8 || (n_blocks & 7)) return hipErrorInvalidValue;      // eight XCDs take equal numbers of workgroups
+    ItemDesc* const list = static_cast<ItemDesc*>(worklist);
+    const unsigned ovf_base = (unsigned)integrate_band_region_entries(p.g);
     const bool exp_poly = use_exp_poly(p);
     const bool ktab = m <= 1024;                                       // 24 bytes of LDS per k
     const size_t lds = ktab ? (size_t)m * 24 : 0;
@@ -1719,6 +1744,17 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
 #undef TSDF_LAUNCH_INTEGRATE3
 #undef TSDF_LAUNCH_INTEGRATE
     return hipGetLastError();
+}
+
+hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
+                            const float4* pn, unsigned long long* counters,
+                            void* worklist, unsigned* work_count, int n_blocks,
+                            unsigned launch_parity, unsigned long long* wg_counts, bool queue, const PackArgs* pack,
+                            const ReleaseWord* release) {
+    if (n_blocks < 8 || (n_blocks & 7)) return hipErrorInvalidValue;
+    const hipError_t e = launch_integrate_list(s, p, worklist, work_count, launch_parity, pack);
+    if (e != hipSuccess) return e;
+    return launch_integrate_items(s, p, dw, crgb, pn, counters, worklist, work_count, n_blocks, launch_parity, wg_counts, queue, release);
 }
 
 // ------------------------------------------------------------------------------------------------
