@@ -102,8 +102,9 @@ private:
     }
     // A frame's host-side work comes as 2-4 short jobs in quick succession (gather the samples, repack the cloud, repack
     // the normals, compare): waking a sleeping thread costs 20-50 us each time -- as much as the job.  A worker therefore
-    // keeps looking for the next job for spin_ns_ after the last one (TSDF_POOL_SPIN_US, default 150) before it sleeps;
-    // between frames of a live stream (33 ms) everybody sleeps.
+    // can keep looking for the next job for TSDF_POOL_SPIN_US microseconds after the last one before it sleeps.  Default 0:
+    // on the GPU boxes (16-CPU quota, other tenants) 150 us of spinning changed nothing (medians 2186 against 2165 frames/s
+    // through the reference's two calls, 8 alternations) and eleven spinning workers eat most of such a quota.
     void loop(int part) {
         unsigned long long seen = 0;
         for (;;) {
@@ -135,7 +136,7 @@ private:
     std::atomic<unsigned long long> gen_{0};
     std::atomic<int> pending_{0}, sleepers_{0};
     std::atomic<bool> stop_{false};
-    long long spin_ns_ = 150000;
+    long long spin_ns_ = 0;
 };
 
 }  // namespace
@@ -258,10 +259,7 @@ struct tsdf_handle {
     double* shard_host = nullptr;  // pinned: kTrackShards slots of kShardSlotDoubles (host side of the fan-in)
     bool host_fanin = true;        // the second level of the tracker fan-in runs on the host (TSDF_HOST_FANIN=0: on the device)
     unsigned integrate_launches = 0;
-    // tsdf_integrate_aos issues the frame's list_rows_kernel as soon as it is called (the list needs the pose, not the
-    // normals): tsdf_integrate then launches integrate_kernel alone -- if pose and intrinsics are still the ones listed for
-    bool list_ahead = false;
-    IntegrateParams list_ahead_params{};
+
     bool poll = true;              // spin on the pass-number word instead of hipStreamSynchronize
     unsigned long long* track_stamps = nullptr;   // TSDF_TRACK_STAMPS=1: 8 device words per tracker workgroup (phase stamps of the last pass)
     // TSDF_TRACK_PROFILE=1: host-side clock of a pass, printed by tsdf_destroy (ns sums: parameters, launch call, wait
@@ -281,7 +279,7 @@ struct tsdf_handle {
         double handoff = 0;      // queue call -> the staging thread starts the job
         // tsdf_track_aos / tsdf_integrate_aos (ns sums)
         long long aos_frames = 0;
-        double a_prep = 0, a_gather = 0, a_issue = 0, a_loop = 0, a_wait = 0, b_normals = 0, b_verify = 0, b_issue = 0, b_integrate = 0;
+        double a_prep1 = 0, a_prep2 = 0, a_prep = 0, a_gather = 0, a_issue = 0, a_loop = 0, a_wait = 0, b_normals = 0, b_verify = 0, b_issue = 0, b_integrate = 0;
     } sp;
 
     // comm
@@ -623,7 +621,6 @@ int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t
 }
 
 void fill_integrate_params(const tsdf_handle* h, IntegrateParams& p) {
-    std::memset(&p, 0, sizeof p);            // (compared bytewise by tsdf_integrate: no stray padding)
     p.g = h->grid;
     std::memcpy(p.rot_inv, h->pose.rot_inv, sizeof p.rot_inv);
     std::memcpy(p.rot_inv_trans, h->pose.rot_inv_trans, sizeof p.rot_inv_trans);
@@ -1229,10 +1226,10 @@ void tsdf_destroy(tsdf_handle* h) {
     }
     if (h->sp.on && h->sp.aos_frames) {
         const double f = (double)h->sp.aos_frames * 1e3;
-        std::fprintf(stderr, "AOS_PROFILE frames %lld  us per frame: tsdf_track_aos: prepare %.1f  gather samples %.1f  issue copy + start staging %.1f  "
+        std::fprintf(stderr, "AOS_PROFILE frames %lld  us per frame: tsdf_track_aos: checks + buffers %.1f  wait for the staging set %.1f  prepare %.1f  gather samples %.1f  issue copy + start staging %.1f  "
                              "Gauss-Newton loop %.1f  wait for the staging %.1f | tsdf_integrate_aos: repack normals + issue copy %.1f  compare cloud %.1f  "
                              "pack launch + events %.1f  tsdf_integrate call %.1f\n",
-                     h->sp.aos_frames, h->sp.a_prep / f, h->sp.a_gather / f, h->sp.a_issue / f, h->sp.a_loop / f, h->sp.a_wait / f,
+                     h->sp.aos_frames, h->sp.a_prep1 / f, h->sp.a_prep2 / f, h->sp.a_prep / f, h->sp.a_gather / f, h->sp.a_issue / f, h->sp.a_loop / f, h->sp.a_wait / f,
                      h->sp.b_normals / f, h->sp.b_verify / f, h->sp.b_issue / f, h->sp.b_integrate / f);
     }
     if (h->track_profile && h->tp_passes)
@@ -2005,12 +2002,6 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     if (h->deferred.pending) choose_pixel_layout(h);      // the records are written in this launch: lay them out for the pose they are read at
     IntegrateParams p;
     fill_integrate_params(h, p);
-    // a list launched ahead (tsdf_integrate_aos) is this frame's list if nothing it was built from has changed since
-    const bool list_done = h->list_ahead && std::memcmp(&p, &h->list_ahead_params, sizeof p) == 0 && !h->deferred.pending &&
-                           !(h->queued.active && h->queued.device && h->queued.deferred && !h->queued.packed);
-    if (h->list_ahead && !list_done)         // launched ahead for another pose / frame (an error path in between): forget it
-        HIP_TRY(h, launch_integrate_list_reset(h->stream, h->work_count, h->integrate_launches));
-    h->list_ahead = false;
     unsigned long long before[kNumCounters];
     if (stats) {
         rc = fetch_counters(h);
@@ -2048,12 +2039,9 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
         fused = true;
     }
     {
-        const hipError_t le = list_done
-            ? launch_integrate_items(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                                     h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue, nullptr)
-            : launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                               h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue,
-                               fused ? &pa : nullptr, fused ? &rel : nullptr);
+        const hipError_t le = launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
+                                               h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue,
+                                               fused ? &pa : nullptr, fused ? &rel : nullptr);
         if (le != hipSuccess) {
             // nothing was packed: the frames stay borrowed and unpacked (a later launch, or tsdf_synchronize, packs them)
             if (fused) for (auto& b : h->borrowed) if (b.stream == 0 && b.ticket == rel.ticket && b.serial >= h->frame_serial + (fused_queued ? 1 : 0)) b.stream = -1;
@@ -2229,6 +2217,7 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
     const size_t npix = (size_t)width * height;
     rc = ensure_second_staging_set(h, npix);
     if (rc) return rc;
+    lap(tp, h->sp.a_prep1);
     const size_t ns = (size_t)h->n_samples;
     if (ns > h->pin_samples_cap) {
         HIP_TRY(h, hipStreamSynchronize(h->fstream));
@@ -2245,6 +2234,7 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
     std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
     std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
     if (h->stage_recorded[0]) HIP_TRY(h, hipEventSynchronize(h->ev_stage_done[0]));
+    lap(tp, h->sp.a_prep2);
     h->staged_xyz = false;
     h->tracked = tsdf_handle::TrackedCloud();
     if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
@@ -2354,17 +2344,10 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
     if (rc) return rc;
     if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "camera matrix not received (reference: sdf.cpp:227-230 exits)");
     if (h->cfg.with_color && !h->frame_has_rgb) return fail(h, TSDF_E_NO_FRAME, "with_color=1 needs rgb in the current frame");
-    // 0. the work list of this integration depends on the pose and the image size, not on the normals: its kernel runs on
-    //    the main stream while the normals are repacked and copied
+    // (Launching the integration's list_rows_kernel here, ahead of the normals -- the list needs the pose only -- was built
+    // and measured in round 5: 8 alternations, median 2186 frames/s with it against 2311 without.  The launch call delays
+    // the repack of the normals by as much as the kernel would later cost: profiles/r05_entry_points.json.)
     choose_pixel_layout(h);
-    {
-        static const bool ahead = [] { const char* e = std::getenv("TSDF_LIST_AHEAD"); return !(e && std::atoi(e) == 0); }();
-        if (ahead) {
-            fill_integrate_params(h, h->list_ahead_params);
-            HIP_TRY(h, launch_integrate_list(h->stream, h->list_ahead_params, h->worklist, h->work_count, h->integrate_launches, nullptr));
-            h->list_ahead = true;
-        }
-    }
     const size_t npix = (size_t)width * height;
     const tsdf_aos_layout lay = *L;
     HostPool* const pool = host_pool(h);
@@ -2373,14 +2356,21 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
         // multiples of four points, so that the 16-byte stores of the repack stay aligned in every part
         *i0 = (npix * (size_t)part / (size_t)parts) & ~(size_t)3; *i1 = part + 1 == parts ? npix : (npix * (size_t)(part + 1) / (size_t)parts) & ~(size_t)3;
     };
-    // 1. the normals: repack into the pinned plane of the set that holds the cloud, one copy
+    // 1. the normals: repack into the pinned plane of the set that holds the cloud and copy (this copy is on the frame's
+    //    critical path; TSDF_NORMAL_CHUNKS pieces repack piece c+1 while piece c travels -- measured, 8 alternations each:
+    //    medians 2223 / 2186 / 2224 frames/s with 1 / 2 / 3 pieces, so one)
     {
-        const std::function<void(int, int)> fill = [&](int part, int parts) {
-            size_t i0, i1; split(part, parts, &i0, &i1);
-            repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
-        };
-        if (pool) pool->run(fill); else fill(0, 1);
-        HIP_TRY(h, hipMemcpyAsync(h->in_nrm, pnm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        static const int kNc = [] { const char* e = std::getenv("TSDF_NORMAL_CHUNKS"); const int n = e ? std::atoi(e) : 1; return n < 1 ? 1 : n > 8 ? 8 : n; }();
+        for (int c = 0; c < kNc; ++c) {
+            const size_t c0 = (npix * (size_t)c / (size_t)kNc) & ~(size_t)3, c1 = c + 1 == kNc ? npix : (npix * (size_t)(c + 1) / (size_t)kNc) & ~(size_t)3;
+            const std::function<void(int, int)> fill = [&](int part, int parts) {
+                const size_t n = c1 - c0;
+                const size_t i0 = c0 + ((n * (size_t)part / (size_t)parts) & ~(size_t)3), i1 = part + 1 == parts ? c1 : c0 + ((n * (size_t)(part + 1) / (size_t)parts) & ~(size_t)3);
+                repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
+            };
+            if (pool) pool->run(fill); else fill(0, 1);
+            HIP_TRY(h, hipMemcpyAsync(h->in_nrm + 3 * c0, pnm + 3 * c0, (c1 - c0) * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        }
     }
     lap(tp, h->sp.b_normals);
     // 2. under that copy: is `points` still, byte for byte, what was repacked when it was tracked?  (A cloud filtered in

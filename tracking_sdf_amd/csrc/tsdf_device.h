@@ -150,7 +150,6 @@ hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw,
 // the two halves of launch_integrate, for a caller that can issue the list before the frame's records are complete
 hipError_t launch_integrate_list(hipStream_t s, const IntegrateParams& p, void* worklist, unsigned* work_count,
                                  unsigned launch_parity, const PackArgs* pack = nullptr);
-hipError_t launch_integrate_list_reset(hipStream_t s, unsigned* work_count, unsigned launch_parity);   // forget a list launched ahead
 hipError_t launch_integrate_items(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                                   const float4* pn, unsigned long long* counters,
                                   void* worklist, unsigned* work_count, int n_blocks,

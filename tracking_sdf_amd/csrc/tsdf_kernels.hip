@@ -1701,17 +1701,6 @@ hipError_t launch_integrate_list(hipStream_t s, const IntegrateParams& p, void* 
     return hipGetLastError();
 }
 
-// a list that was launched ahead and is not wanted after all (pose / intrinsics / frame changed before its integration):
-// put the launch parity's bookkeeping set back to what the previous integrate_kernel left (cursors 0, nothing overflowed)
-__global__ __launch_bounds__(64) void reset_list_kernel(unsigned* __restrict__ set) {
-    for (int t = threadIdx.x; t < kBins; t += 64) { set[kSetCur + t] = 0u; set[kSetFirstOvf + t] = ~0u; }
-    if (threadIdx.x == 0) set[kSetOvf] = 0u;
-}
-hipError_t launch_integrate_list_reset(hipStream_t s, unsigned* work_count, unsigned launch_parity) {
-    reset_list_kernel<<<dim3(1), dim3(64), 0, s>>>(work_count + (launch_parity & 1) * kBinSetWords);
-    return hipGetLastError();
-}
-
 hipError_t launch_integrate_items(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                                   const float4* pn, unsigned long long* counters,
                                   void* worklist, unsigned* work_count, int n_blocks,
