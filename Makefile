@@ -81,3 +81,11 @@ shim_fields_demo: $(LIB)
 	g++ -std=c++11 -O2 -Wall -Wextra -DTSDF_WITH_EIGEN_PCL -DTSDF_WITH_ROS -I$(ROOT)tests/mock -I$(ROOT)include \
 	    -o $(ROOT)build/shim_fields_demo $(ROOT)tests/mock/shim_fields_demo.cpp -L$(LIBDIR) -ltsdf_hip -Wl,-rpath,$(LIBDIR)
 .PHONY: shim_fields_demo
+
+# hand-written AQL dispatch on a user-mode queue of our own against hipLaunchKernel, for the shape of a tracker pass
+# (tools/aql_probe.hip); run on the GPU box: build/aql_probe build/aql_probe_kernel.hsaco
+aql_probe:
+	@mkdir -p $(ROOT)build
+	$(HIPCC) --offload-arch=gfx950 -O2 --genco --no-gpu-bundle-output -DPROBE_DEVICE_ONLY -o $(ROOT)build/aql_probe_kernel.hsaco $(ROOT)tools/aql_probe.hip
+	$(HIPCC) --offload-arch=gfx950 -O2 -o $(ROOT)build/aql_probe $(ROOT)tools/aql_probe.hip -lhsa-runtime64
+.PHONY: aql_probe

@@ -71,13 +71,15 @@ def main():
             for rep in range(2):                   # the second sweep gives warm numbers (band capacities, XCD shares)
                 sdf.read_timing(reset=True)
                 sdf.read_counters(reset=True)
-                t0 = time.perf_counter()
+                per_frame = []
                 for k in range(args.frames):
                     trk.set_camera_transformation(seq.R[k], seq.t[k])
                     sdf.set_frame_device(d[k][0].data_ptr(), d[k][1].data_ptr(), d[k][2].data_ptr(), w, h)
+                    t0 = time.perf_counter()
                     sdf.update(want_stats=False)
-                sdf.synchronize()
-                wall = (time.perf_counter() - t0) / args.frames
+                    sdf.synchronize()
+                    per_frame.append(time.perf_counter() - t0)
+                wall = float(np.median(per_frame))
                 tm, cn = sdf.read_timing(), sdf.read_counters()
             sdf.set_timing(False)
             k = args.frames - 1
@@ -85,13 +87,15 @@ def main():
             sdf.set_frame_device(d[k][0].data_ptr(), d[k][1].data_ptr(), d[k][2].data_ptr(), w, h)
             for _ in range(5):
                 trk.accumulate()
-            t0 = time.perf_counter()
+            walls = []
             for _ in range(args.passes):
+                t0 = time.perf_counter()
                 A, b, st = trk.accumulate()
-            pass_wall = (time.perf_counter() - t0) / args.passes
+                walls.append(time.perf_counter() - t0)
+            pass_wall = float(np.median(walls))        # (host hiccups of a shared box: the median, not the mean)
             rows.append({"rank": r, "slab": [x0, x1], "stored_layers": min(m, x1 + halo) - max(0, x0 - halo),
                          "integrate_launch_us": 1e3 * tm["integrate_ms"] / max(1, tm["integrate_launches"]),
-                         "integrate_back_to_back_wall_us": 1e6 * wall,
+                         "integrate_call_to_completion_wall_us_median": 1e6 * wall,
                          "work_items_per_launch": cn["integrate_items"] / max(1, cn["integrate_calls"]),
                          "updated_voxels_per_launch": (cn["n_updated"] + cn["n_updated_halo"]) / max(1, cn["integrate_calls"]),
                          "updated_in_halo_fraction": cn["n_updated_halo"] / max(1, cn["n_updated"] + cn["n_updated_halo"]),

@@ -182,7 +182,9 @@ struct tsdf_handle {
     bool qbusy = false, qstop = false;
     void* worklist = nullptr;      // integrate work items (32-byte descriptors: row << 6 | chunk, the row's share of rot_inv * g)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
-    int integrate_blocks = 0;      // persistent grid of integrate_kernel
+    int integrate_blocks = 0;      // persistent grid of integrate_kernel: the most workgroups a launch uses (CUs x workgroups per CU)
+    int integrate_cus = 0;         // CUs (rounded up to whole XCD groups of 8 workgroups)
+    bool integrate_grid_by_work = true;   // TSDF_INTEGRATE_GRID_BY_WORK=0: always the full grid
     int integrate_debug = 0;       // timing experiments; only honoured by builds with -DTSDF_INTEGRATE_DEBUG=1
 
     // frame
@@ -1157,6 +1159,10 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
         const char* env = std::getenv("TSDF_INTEGRATE_BLOCKS_PER_CU");
         const int per_cu = env ? std::atoi(env) : integrate_blocks_per_cu(h->integrate_queue);
         h->integrate_blocks = (prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4) + 7) / 8 * 8;   // whole XCD groups
+        h->integrate_cus = prop.multiProcessorCount;
+        { const char* ev = std::getenv("TSDF_INTEGRATE_GRID_BY_WORK"); h->integrate_grid_by_work = !(ev && std::atoi(ev) == 0); }
+        // the measurement builds index their per-wavefront words by the full grid
+        if (h->integrate_debug || std::getenv("TSDF_WG_FINISH") || std::getenv("TSDF_LIVE_HIST")) h->integrate_grid_by_work = false;
     }
     // 2 words per workgroup (updated voxels: owned, halo) + 4 x 6 more behind them for the stage profile of debug builds
     CREATE_TRY(hipMalloc((void**)&h->wg_counts, 26 * (size_t)h->integrate_blocks * sizeof(unsigned long long)));
@@ -1165,8 +1171,9 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipMalloc((void**)&h->red_dev, kRedWidth * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->red_host, (kRedWidth + 2) * sizeof(double), hipHostMallocDefault));
     std::memset(h->red_host, 0, (kRedWidth + 2) * sizeof(double));
-    CREATE_TRY(hipHostMalloc((void**)&h->release_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void**)&h->release_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
     h->release_host[0] = h->release_host[1] = 0ull;
+    h->release_host[2] = ~0ull;              // work items of the last integrate launch (none yet: the full grid)
     { const char* ev = std::getenv("TSDF_NO_POLL"); h->poll = !(ev && std::atoi(ev) != 0); }
     { const char* ev = std::getenv("TSDF_DEFER_PACK"); h->defer_device_pack = !(ev && std::atoi(ev) == 0); h->deferred_list_samples = !(ev && std::atoi(ev) == 2); }
     { const char* ev = std::getenv("TSDF_HOST_FOLD"); h->host_fold = !(ev && std::atoi(ev) == 0); }
@@ -2039,9 +2046,25 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
         fused = true;
     }
     {
+        // Grid by work: a persistent workgroup costs ~2.5 us of launch per workgroup and CU whatever it finds to do (segment
+        // table, k table, pipeline fill and drain), so the grid follows the work -- enough workgroups per CU that a
+        // wavefront gets >= 16 items, going by the LAST launch's item count (consecutive frames list nearly the same rows;
+        // the count arrives in pinned memory, nothing waits for it).  A whole 512^3 volume lists ~195 k items and keeps
+        // five workgroups per CU; the 1/8 slab of an 8-GPU job lists ~24 k and gets two.  Only the schedule changes.
+        int blocks = h->integrate_blocks;
+        const unsigned long long last_items = __atomic_load_n(h->release_host + 2, __ATOMIC_RELAXED);
+        if (h->integrate_grid_by_work && last_items != ~0ull && h->integrate_cus > 0) {
+            const unsigned long long per_wg_cu = (unsigned long long)h->integrate_cus * (kIntegrateBlock / 64) * 16ull;   // items that give every wavefront 16
+            const int max_per_cu = h->integrate_blocks / ((h->integrate_cus + 7) / 8 * 8) > 0 ? h->integrate_blocks / ((h->integrate_cus + 7) / 8 * 8) : 1;
+            int want = (int)((last_items + per_wg_cu - 1) / per_wg_cu);
+            want = want < 1 ? 1 : want > max_per_cu ? max_per_cu : want;
+            blocks = (h->integrate_cus * want + 7) / 8 * 8;
+            if (blocks > h->integrate_blocks) blocks = h->integrate_blocks;
+        }
+        rel.items_word = h->release_host + 2;
         const hipError_t le = launch_integrate(h->stream, p, h->dw, h->crgb, h->pn, h->counters, h->worklist, h->work_count,
-                                               h->integrate_blocks, h->integrate_launches, h->wg_counts, h->integrate_queue,
-                                               fused ? &pa : nullptr, fused ? &rel : nullptr);
+                                               blocks, h->integrate_launches, h->wg_counts, h->integrate_queue,
+                                               fused ? &pa : nullptr, &rel);
         if (le != hipSuccess) {
             // nothing was packed: the frames stay borrowed and unpacked (a later launch, or tsdf_synchronize, packs them)
             if (fused) for (auto& b : h->borrowed) if (b.stream == 0 && b.ticket == rel.ticket && b.serial >= h->frame_serial + (fused_queued ? 1 : 0)) b.stream = -1;

@@ -124,7 +124,10 @@ struct MeshParams {
 enum Counter { kCntUpdatedOwned = 0, kCntUpdatedHalo = 1, kCntItems = 2, kCntOverflowItems = 3, kNumCounters = 4 };
 
 // pinned host word + the value a launch stores there once the caller's device planes have been read (tsdf_device_frame_released)
-struct ReleaseWord { unsigned long long* word = nullptr; unsigned long long ticket = 0; };
+struct ReleaseWord {
+    unsigned long long* word = nullptr; unsigned long long ticket = 0;
+    unsigned long long* items_word = nullptr;   // pinned host word (may be null): integrate_kernel leaves the launch's work-item count there
+};
 hipError_t launch_release(hipStream_t s, const ReleaseWord& rel);   // behind a launch_pack of borrowed device planes
 
 hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0);

@@ -736,7 +736,8 @@ __device__ __forceinline__ unsigned share_split(unsigned n, unsigned i, unsigned
 // (first wavefront of the workgroup; the caller's barrier publishes the table)
 static_assert(kBins <= 64, "one lane per band in the segment scan");
 __device__ __forceinline__ void build_segment_table(const unsigned* __restrict__ set, unsigned* __restrict__ next_set, unsigned ovf_base,
-                                                    unsigned long long* __restrict__ totals, unsigned* s_vstart, unsigned* s_delta, int tid) {
+                                                    unsigned long long* __restrict__ totals, unsigned* s_vstart, unsigned* s_delta, int tid,
+                                                    unsigned long long* items_out = nullptr /* pinned host: this launch's item count */) {
     if (tid < 64) {
         const bool is_band = tid < kBins;
         const unsigned cur = is_band ? set[kSetCur + tid] : 0u, fo = is_band ? set[kSetFirstOvf + tid] : 0u;
@@ -775,6 +776,8 @@ __device__ __forceinline__ void build_segment_table(const unsigned* __restrict__
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
             if (tid == 0 && tot) atomicAdd(&totals[kCntItems], tot);
+            // the host sizes the NEXT launch's grid from it (tsdf_integrate: a wavefront should have >= 16 items)
+            if (tid == 0 && items_out) __hip_atomic_store(items_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (tid == 0 && set[kSetOvf]) atomicAdd(&totals[kCntOverflowItems], (unsigned long long)set[kSetOvf]);
         }
     }
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(kIntegrateBlock, TSDF_INTEGRATE_MIN_WAVES) void int
     constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
     __shared__ unsigned s_vstart[kBins + 2], s_delta[kBins + 1];
     publish_release(rel, tid);      // list_rows_kernel -- and the packing of a device frame in its appended workgroups -- is complete
-    build_segment_table(set, next_set, ovf_base, totals, s_vstart, s_delta, tid);
+    build_segment_table(set, next_set, ovf_base, totals, s_vstart, s_delta, tid, rel.items_word);
     if (KTAB) build_k_table(p, s_tab, tid, kIntegrateBlock);
     else __syncthreads();
     const unsigned n_items = __builtin_amdgcn_readfirstlane(s_vstart[kBins + 1]);   // (an LDS load is a per-lane value to the compiler)
@@ -1268,7 +1271,7 @@ __global__ __launch_bounds__(kIntegrateBlock, 4) void integrate_queue_kernel(
     const float delta = p.g.delta, eps = p.g.epsilon, neg_delta = -p.g.delta;
     constexpr unsigned NW = kIntegrateBlock / 64;             // wavefronts per workgroup
     __shared__ unsigned s_vstart[kBins + 2], s_delta[kBins + 1];
-    build_segment_table(set, next_set, ovf_base, totals, s_vstart, s_delta, tid);
+    build_segment_table(set, next_set, ovf_base, totals, s_vstart, s_delta, tid, rel.items_word);
     if (KTAB) build_k_table(p, s_tab, tid, kIntegrateBlock);
     else __syncthreads();
     const unsigned n_items = __builtin_amdgcn_readfirstlane(s_vstart[kBins + 1]);
