@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--frame-step", type=int, default=1, help="use every n-th 30 Hz pose")
     ap.add_argument("--max-range", type=float, default=6.0, help="metres; sizes the slab halo")
+    ap.add_argument("--slabs", default="balanced", choices=["balanced", "uniform"],
+                    help="N > 1: balanced = x-slabs of equal expected WORK (tsdf_slab_range_weighted on the view frustum of the reference's "
+                         "initial pose, camera_tracking.cpp:5-7: thin slabs where the camera looks); uniform = equal thickness (tsdf_slab_range)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -397,9 +400,15 @@ def run(args):
 
         def __init__(self, m, w, h, K):
             self.m, self.w, self.h = m, w, h
-            x0, x1 = ts.slab_range(m, world, rank)
             cfg0 = ts.default_config(m=m)
             self.halo = ts.halo_for(cfg0, args.max_range) if world > 1 else 0
+            if world > 1 and args.slabs == "balanced":
+                # every rank computes the same cuts: frustum of the reference's initial pose, up to the sensor's 5 m
+                wts = ts.frustum_layer_weights(cfg0, K, w, h, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1], 5.0)
+                x0, x1 = ts.slab_range_weighted(m, world, rank, self.halo, wts)
+            else:
+                x0, x1 = ts.slab_range(m, world, rank)
+            self.slab = (x0, x1)
             self.sdf = ts.SDF(m, with_color=not args.no_color, slab=(x0, x1), halo=self.halo, device=dev_index)
             self.trk = ts.CameraTracking(sdf=self.sdf)
             self.trk.set_K(K)
@@ -520,6 +529,7 @@ def run(args):
     seq, d_frames = render_frames(width, height, n_frames, args.frame_step,
                                   np.array(FR3_K) if args.config == 4 and (width, height) == (640, 480) else None)
     leg = Leg(m, width, height, seq.K)
+    leg_slab0 = leg.slab
     sdf = leg.sdf
     halo_main = leg.halo
 
@@ -911,7 +921,7 @@ def run(args):
                                    f"pillars/domes/furniture), {width}x{height} depth with Kinect noise + 2% holes, "
                                    f"{m}^3 voxels, 6x6x3.5 m volume, colour lanes {'off' if args.no_color else 'on'}; "
                                    f"TUM images are not available on the box",
-                       "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}",
+                       "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}" + (f" ({args.slabs} slabs, rank 0 owns layers [{leg_slab0[0]}, {leg_slab0[1]}))" if world > 1 else ""),
                        "halo": halo_main,
                        "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us},
             "ate_rmse_m": ate, "ate_frames": len(est_main) - 1, "abs_trajectory_rmse_m": raw,

@@ -320,6 +320,19 @@ int tsdf_mesh_device(tsdf_handle *h, const float **vertices, const float **color
 /* ---- multi-GPU (one process per GPU; the volume is sharded in x-slabs) ------------------- */
 /* Owned range of `rank` out of `nranks` for an m-voxel axis (balanced contiguous slabs). */
 int tsdf_slab_range(int32_t m, int32_t nranks, int32_t rank, int32_t *x0, int32_t *x1);
+/* Slabs of equal WORK instead of equal thickness.  A camera frustum covers the middle of the volume: with equal slabs the
+ * 8-way split of config 5 gives the busiest rank 4.5 x the average work (profiles/r05_rank_costs_*), and every Gauss-Newton
+ * pass and every integration waits for that rank.  layer_weight[i] >= 0 is the expected work of x layer i (m entries, e.g.
+ * from tsdf_frustum_layer_weights); a rank pays for the layers it STORES (slab + halo per side); the boundaries minimise the
+ * largest such sum.  Deterministic: every rank computes the same cuts from the same weights.  All-zero weights give
+ * tsdf_slab_range's equal slabs. */
+int tsdf_slab_range_weighted(int32_t m, int32_t nranks, int32_t rank, int32_t halo, const double *layer_weight,
+                             int32_t *x0, int32_t *x1);
+/* Expected integration work per x layer (in 64-voxel work items) for a camera at (rot, trans) with intrinsics K and a
+ * width x height image: the layer's voxels inside the view frustum up to max_depth metres, plus a floor per stored layer.
+ * ADDS to weights[0..m), so several poses (the initial one; a planned path) accumulate.  Host only, no handle. */
+int tsdf_frustum_layer_weights(const tsdf_config *cfg, const double K[9], int32_t width, int32_t height, const double rot[9],
+                               const double trans[3], float max_depth, double *weights);
 /* Halo (x layers per side) that covers every tracking look-up of points up to max_range metres
  * from the world origin: ceil(w_h * max_range * m/width) + ceil(v_h) + 2. */
 int32_t tsdf_halo_for(const tsdf_config *cfg, float max_range);

@@ -84,6 +84,48 @@ def test_slab_ranges_partition_the_axis():
         ts.slab_range(64, 4, 4)
 
 
+def test_weighted_slab_ranges_partition_the_axis_and_balance_the_work():
+    """tsdf_slab_range_weighted: contiguous non-empty slabs that partition the axis, deterministic; the largest cost
+    (weights of the stored layers: slab + halo) is no larger than with equal slabs and within a layer's weight of the
+    optimum a brute-force search finds; zero weights fall back to equal slabs.  tsdf_frustum_layer_weights: the initial
+    pose looks along -y from the middle of the x extent, so the weights are symmetric in x and largest in the middle."""
+    from tracking_sdf_amd import synth
+    rng = np.random.default_rng(3)
+    for m, n, halo in ((48, 4, 2), (64, 8, 3), (100, 3, 0), (33, 5, 4)):
+        for trial in range(6):
+            w = rng.random(m) ** 3 * (1 + 50 * (np.abs(np.arange(m) - rng.integers(m)) < m // 6))
+            cuts = [ts.slab_range_weighted(m, n, r, halo, w) for r in range(n)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == m and all(b > a for a, b in cuts)
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(n - 1))
+            assert cuts == [ts.slab_range_weighted(m, n, r, halo, w.copy()) for r in range(n)]
+            pre = np.concatenate([[0.0], np.cumsum(w)])
+            cost = lambda a, b: pre[min(m, b + halo)] - pre[max(0, a - halo)]
+            got = max(cost(a, b) for a, b in cuts)
+            uni = max(cost(*ts.slab_range(m, n, r)) for r in range(n))
+            assert got <= uni * (1 + 1e-9)
+            # brute force (dynamic programme over the cut positions)
+            best = np.full((n + 1, m + 1), np.inf)
+            best[0, 0] = 0.0
+            for r in range(1, n + 1):
+                for b in range(r, m - (n - r) + 1):
+                    best[r, b] = min(max(best[r - 1, a], cost(a, b)) for a in range(r - 1, b))
+            assert got <= best[n, m] * (1 + 1e-9) + 1e-12
+    assert [ts.slab_range_weighted(64, 4, r, 2, np.zeros(64)) for r in range(4)] == [ts.slab_range(64, 4, r) for r in range(4)]
+    with pytest.raises(ts.TsdfError):
+        ts.slab_range_weighted(64, 4, 0, 2, -np.ones(64))
+    with pytest.raises(ValueError):
+        ts.slab_range_weighted(64, 4, 0, 2, np.ones(63))
+    cfg = ts.default_config(m=128)
+    K = synth.default_intrinsics(640, 480)
+    W = ts.frustum_layer_weights(cfg, K, 640, 480, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1], 5.0)
+    assert W.shape == (128,) and np.all(W > 0) and np.allclose(W, W[::-1], rtol=1e-9) and W[64] > 5 * W[0]
+    W2 = ts.frustum_layer_weights(cfg, K, 640, 480, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1], 5.0, weights=W.copy())
+    assert np.allclose(W2, 2 * W)                         # poses accumulate
+    cuts = [ts.slab_range_weighted(128, 8, r, 4, W) for r in range(8)]
+    sizes = [b - a for a, b in cuts]
+    assert sizes[0] > 2 * sizes[3] and sizes == sizes[::-1]      # thick slabs at the edges, thin ones where the camera looks
+
+
 def test_halo_covers_the_rotational_reach():
     cfg = ts.default_config(m=512)
     # w_h * range * m/width = 0.01 * 6 m * 85.33 voxel/m = 5.12 -> 6, + ceil(v_h) = 1, + 2 safety

@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--frame-step", type=int, default=2)
     ap.add_argument("--passes", type=int, default=60)
     ap.add_argument("--max-range", type=float, default=6.0)
+    ap.add_argument("--slabs", default="uniform", choices=["uniform", "balanced"],
+                    help="uniform: tsdf_slab_range (equal thickness); balanced: tsdf_slab_range_weighted on the frustum weights of the "
+                         "reference's initial pose (what bench.py --slabs balanced does)")
     ap.add_argument("--passes-per-frame", type=float, default=3.1, help="Gauss-Newton passes per frame of the bench stream (driver line)")
     ap.add_argument("--exchange-us", type=float, nargs="*", default=[0.0, 4.0, 10.0, 25.0],
                     help="exchange step per pass to evaluate the model at (us): 0 = none, ~4 = host fan-in through shared memory, "
@@ -57,13 +60,16 @@ def main():
     d = [seq.frame_torch(k, dev) for k in range(args.frames)]
     torch.cuda.synchronize()
     out = {"what": __doc__.split("\n\n")[0], "shape": args.shape, "image": [w, h], "frames_fused": args.frames,
-           "passes_timed": args.passes, "colour": True, "by_ranks": {}}
+           "passes_timed": args.passes, "colour": True, "slabs": args.slabs, "by_ranks": {}}
     for n in args.ranks:
         m = m8 if not weak else int(round(m8 * (n / 8.0) ** (1.0 / 3.0) / 2.0)) * 2
         halo = ts.halo_for(ts.default_config(m=m), args.max_range) if n > 1 else 0
         rows = []
+        weights = None
+        if args.slabs == "balanced" and n > 1:
+            weights = ts.frustum_layer_weights(ts.default_config(m=m), seq.K, w, h, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1])
         for r in range(n):
-            x0, x1 = ts.slab_range(m, n, r)
+            x0, x1 = ts.slab_range(m, n, r) if weights is None else ts.slab_range_weighted(m, n, r, halo, weights)
             sdf = ts.SDF(m, with_color=True, slab=(x0, x1), halo=halo)
             trk = ts.CameraTracking(sdf=sdf)
             trk.set_K(seq.K)

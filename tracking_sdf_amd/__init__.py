@@ -13,7 +13,8 @@ import os
 
 import numpy as np
 
-__all__ = ["SDF", "CameraTracking", "TsdfError", "Config", "lib", "lib_path", "build", "slab_range", "halo_for"]
+__all__ = ["SDF", "CameraTracking", "TsdfError", "Config", "lib", "lib_path", "build", "slab_range", "slab_range_weighted",
+           "frustum_layer_weights", "halo_for"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
@@ -107,7 +108,7 @@ ABI_SYMBOLS = (
     "tsdf_set_frame_device", "tsdf_device_frame_released", "tsdf_set_frame_aos", "tsdf_track_aos", "tsdf_integrate_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_queue_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
-    "tsdf_slab_range", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
+    "tsdf_slab_range", "tsdf_slab_range_weighted", "tsdf_frustum_layer_weights", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
 
@@ -187,6 +188,8 @@ def lib():
         "tsdf_save": (C.c_int, [H, C.c_char_p]),
         "tsdf_load": (C.c_int, [H, C.c_char_p]),
         "tsdf_slab_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, ip, ip]),
+        "tsdf_slab_range_weighted": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip, ip]),
+        "tsdf_frustum_layer_weights": (C.c_int, [C.POINTER(Config), dp, C.c_int32, C.c_int32, dp, dp, C.c_float, dp]),
         "tsdf_halo_for": (C.c_int32, [C.POINTER(Config), C.c_float]),
         "tsdf_comm_unique_id": (C.c_int, [C.c_void_p]),
         "tsdf_comm_init": (C.c_int, [H, C.c_int32, C.c_int32, C.c_void_p]),
@@ -231,6 +234,28 @@ def slab_range(m: int, nranks: int, rank: int):
     if rc:
         raise TsdfError(rc, "tsdf_slab_range: bad argument")
     return int(x0.value), int(x1.value)
+
+
+def slab_range_weighted(m: int, nranks: int, rank: int, halo: int, layer_weight):
+    """tsdf_slab_range_weighted: slabs of equal expected work (weights per x layer, e.g. from frustum_layer_weights)."""
+    w = np.ascontiguousarray(layer_weight, dtype=np.float64)
+    if w.size != m:
+        raise ValueError(f"expected {m} layer weights, got {w.size}")
+    x0, x1 = C.c_int32(), C.c_int32()
+    rc = lib().tsdf_slab_range_weighted(m, nranks, rank, int(halo), _dptr(w), C.byref(x0), C.byref(x1))
+    if rc:
+        raise TsdfError(rc, "tsdf_slab_range_weighted: bad argument")
+    return int(x0.value), int(x1.value)
+
+
+def frustum_layer_weights(cfg: Config, K, width, height, rot, trans, max_depth=5.0, weights=None):
+    """tsdf_frustum_layer_weights: expected integration work per x layer for one pose, added to `weights`."""
+    w = np.zeros(int(cfg.m)) if weights is None else weights
+    k, r, t = _d(K, 9), _d(rot, 9), _d(trans, 3)
+    rc = lib().tsdf_frustum_layer_weights(C.byref(cfg), _dptr(k), int(width), int(height), _dptr(r), _dptr(t), float(max_depth), _dptr(w))
+    if rc:
+        raise TsdfError(rc, "tsdf_frustum_layer_weights: bad argument")
+    return w
 
 
 def halo_for(cfg: Config, max_range: float) -> int:

@@ -1049,6 +1049,96 @@ int tsdf_slab_range(int32_t m, int32_t nranks, int32_t rank, int32_t* x0, int32_
     return TSDF_OK;
 }
 
+// Slabs of equal WORK instead of equal thickness.  The cost of a rank is the weight of the layers it STORES (slab + halo
+// per side: halo layers are integrated too); boundaries minimise the largest cost.  Monotone greedy under a bisected
+// bound: every rank computes the same boundaries from the same weights.
+int tsdf_slab_range_weighted(int32_t m, int32_t nranks, int32_t rank, int32_t halo, const double* w, int32_t* x0, int32_t* x1) {
+    if (m <= 0 || nranks <= 0 || nranks > m || rank < 0 || rank >= nranks || halo < 0 || !w || !x0 || !x1) return TSDF_E_BADARG;
+    std::vector<double> pre((size_t)m + 1, 0.0);
+    for (int32_t i = 0; i < m; ++i) {
+        if (!(w[i] >= 0.0) || !std::isfinite(w[i])) return TSDF_E_BADARG;
+        pre[(size_t)i + 1] = pre[(size_t)i] + w[i];
+    }
+    if (!(pre[(size_t)m] > 0.0)) return tsdf_slab_range(m, nranks, rank, x0, x1);      // no information: equal thickness
+    auto cost = [&](int32_t a, int32_t b) {                       // stored layers of the slab [a, b)
+        const int32_t lo = a - halo < 0 ? 0 : a - halo, hi = b + halo > m ? m : b + halo;
+        return pre[(size_t)hi] - pre[(size_t)lo];
+    };
+    std::vector<int32_t> cut((size_t)nranks + 1, 0);
+    auto greedy = [&](double T, std::vector<int32_t>& c) {
+        int32_t x = 0;
+        c[0] = 0;
+        for (int32_t r = 0; r < nranks; ++r) {
+            const int32_t last = m - (nranks - 1 - r);            // leave a layer for every rank behind this one
+            if (r == nranks - 1) { if (cost(x, m) > T) return false; c[(size_t)r + 1] = m; return true; }
+            if (cost(x, x + 1) > T) return false;
+            int32_t lo = x + 1, hi = last;                        // the largest b in [x+1, last] with cost(x, b) <= T
+            while (lo < hi) { const int32_t mid = lo + (hi - lo + 1) / 2; if (cost(x, mid) <= T) lo = mid; else hi = mid - 1; }
+            x = lo;
+            c[(size_t)r + 1] = x;
+        }
+        return true;
+    };
+    double lo = 0.0, hi = pre[(size_t)m];
+    for (int it = 0; it < 100 && hi - lo > 1e-12 * pre[(size_t)m]; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        std::vector<int32_t> c((size_t)nranks + 1, 0);
+        if (greedy(mid, c)) hi = mid; else lo = mid;
+    }
+    if (!greedy(hi, cut)) return TSDF_E_BADARG;
+    // the greedy cut loads the early ranks to the bound and leaves the last ones light: pull the cuts back while no cost
+    // exceeds the bound, so that thickness is shared where work is not (rank memory stays reasonable)
+    for (int32_t r = nranks - 1; r >= 1; --r) {
+        int32_t lo_c = cut[(size_t)r - 1] + 1, hi_c = cut[(size_t)r];          // the smallest cut[r] that keeps rank r within the bound
+        while (lo_c < hi_c) { const int32_t mid = lo_c + (hi_c - lo_c) / 2; if (cost(mid, cut[(size_t)r + 1]) <= hi) hi_c = mid; else lo_c = mid + 1; }
+        // half-way between "as early as the bound allows" and the greedy position
+        cut[(size_t)r] = lo_c + (cut[(size_t)r] - lo_c) / 2;
+    }
+    *x0 = cut[(size_t)rank]; *x1 = cut[(size_t)rank + 1];
+    return TSDF_OK;
+}
+
+// Expected integration work per x layer for one camera pose: the voxels of the layer inside the view frustum up to
+// max_depth (rows sampled every `step`-th j, their k intervals from the same affine tests list_rows_kernel uses), in units of
+// 64-voxel work items, plus a floor for the per-row work every stored layer costs.  ADDS to weights[0..m): poses accumulate.
+int tsdf_frustum_layer_weights(const tsdf_config* c, const double K[9], int32_t width, int32_t height, const double rot[9],
+                               const double trans[3], float max_depth, double* weights) {
+    if (!c || !K || !rot || !trans || !weights || c->m <= 0 || width <= 0 || height <= 0 || !(max_depth > 0.f)) return TSDF_E_BADARG;
+    hm::Pose ps;
+    hm::set_pose(ps, rot, trans);
+    const int m = c->m;
+    const double cw = (double)(c->width / (float)m), ch = (double)(c->height / (float)m), cd = (double)(c->depth / (float)m);
+    const int step = m >= 256 ? m / 128 : 1;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    for (int i = 0; i < m; ++i) {
+        const double gx = cw * (i + 0.5) + c->origin[0];
+        double voxels = 0.0;
+        for (int j = step / 2; j < m; j += step) {
+            const double gy = ch * (j + 0.5) + c->origin[1], gz0 = cd * 0.5 + c->origin[2];
+            double Q0[3], Q1[3];
+            for (int a = 0; a < 3; ++a) {
+                Q0[a] = ps.rot_inv[3 * a] * gx + ps.rot_inv[3 * a + 1] * gy + ps.rot_inv[3 * a + 2] * gz0 + ps.rot_inv_trans[a];
+                Q1[a] = ps.rot_inv[3 * a + 2] * cd;
+            }
+            double lo = 0.0, hi = (double)m;
+            auto clip = [&](double a, double b) {                 // a + k b >= 0
+                if (b > 0.0) { const double t = -a / b; if (t > lo) lo = t; }
+                else if (b < 0.0) { const double t = -a / b; if (t < hi) hi = t; }
+                else if (a < 0.0) { lo = 1.0; hi = 0.0; }
+            };
+            clip(Q0[2] - 0.05, Q1[2]);                                                    // in front of the camera
+            clip((double)max_depth - Q0[2], -Q1[2]);                                      // within the sensor's range
+            clip(fx * Q0[0] + (cx + 0.5) * Q0[2], fx * Q1[0] + (cx + 0.5) * Q1[2]);       // u >= -0.5
+            clip(-(fx * Q0[0] + (cx - (width - 0.5)) * Q0[2]), -(fx * Q1[0] + (cx - (width - 0.5)) * Q1[2]));
+            clip(fy * Q0[1] + (cy + 0.5) * Q0[2], fy * Q1[1] + (cy + 0.5) * Q1[2]);
+            clip(-(fy * Q0[1] + (cy - (height - 0.5)) * Q0[2]), -(fy * Q1[1] + (cy - (height - 0.5)) * Q1[2]));
+            if (hi > lo) voxels += (hi - lo) * step;
+        }
+        weights[i] += voxels / 64.0 + 0.02 * (double)m * (double)m / 64.0;
+    }
+    return TSDF_OK;
+}
+
 int32_t tsdf_halo_for(const tsdf_config* c, float max_range) {
     if (!c || c->m <= 0 || !(c->width > 0)) return -1;
     const double per_m = (double)c->m / (double)c->width;
