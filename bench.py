@@ -74,11 +74,13 @@ def parse(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes")
     ap.add_argument("--no-full-sequence", action="store_true")
     ap.add_argument("--no-weak-leg", action="store_true")
-    ap.add_argument("--allreduce", choices=["rccl", "auto", "shm", "peer", "torch"], default="rccl",
-                    help="exchange step of a Gauss-Newton pass: rccl = in-library RCCL all-reduce (falls back to the "
-                         "shared-memory fan-in only if RCCL fails its self-test); shm = host-side fan-in through a POSIX "
-                         "shared segment; peer = device-side exchange through HIP-IPC-mapped buffers (tsdf_comm_init_peer); "
-                         "auto = self-test and time all three, keep the fastest")
+    ap.add_argument("--allreduce", choices=["rccl", "auto", "shm", "peer", "torch"], default="auto",
+                    help="exchange step of a Gauss-Newton pass: auto (default) = every in-library step that passes its self-test runs "
+                         "a short trial of the frame loop on this machine and the fastest is kept (a pass costs ~25 us: the exchange "
+                         "step must be chosen by what it costs INSIDE a pass, on the node at hand -- DESIGN.md section 6); rccl = "
+                         "in-library RCCL all-reduce (falls back to the shared-memory fan-in only if RCCL fails its self-test); shm = "
+                         "host-side fan-in through a POSIX shared segment; peer = device-side exchange through HIP-IPC-mapped buffers "
+                         "(tsdf_comm_init_peer)")
     ap.add_argument("--frame-queue", action="store_true",
                     help="queue the HBM-resident frame k+1 (tsdf_queue_frame_device) while frame k is processed instead of setting "
                          "every frame in front of its own tracker passes: frame k+1 is then packed, sample list included, inside frame k's "
@@ -536,6 +538,7 @@ def run(args):
     # ---- exchange step of a Gauss-Newton pass (N > 1)
     allreduce_kind = "none"
     exchange_us = {}
+    exchange_trial = {}
     comm_state = {"kind": "none"}
 
     def all_agree(flag):
@@ -636,8 +639,25 @@ def run(args):
             dist.barrier()
         want = args.allreduce
         if want == "auto":
-            choice = [min(exchange_us, key=exchange_us.get) if exchange_us else "torch"]
-            dist.broadcast_object_list(choice, 0)           # every rank must take the same decision: rank 0's timings
+            # What an exchange step costs as a stand-alone tsdf_allreduce (above) includes a copy, a launch and a wait that a
+            # tracker pass does not pay, differently for each of the three: the choice is made on a short trial of the frame
+            # loop itself (first frame + up to 8 tracked frames, max over ranks), same frames, volume restarted each time.
+            trial_n = min(8, len(d_frames) - 1)
+            for mode in list(exchange_us):
+                if setup_exchange(sdf, mode) != KIND[mode]:
+                    continue
+                leg.restart()
+                leg.first_frame(d_frames)
+                sdf.synchronize()
+                barrier()
+                t0 = perf()
+                for k in range(1, 1 + trial_n):
+                    leg.step(k, d_frames)
+                sdf.synchronize()
+                exchange_trial[mode] = trial_n / max_over_ranks(perf() - t0)
+            leg.restart()
+            choice = [max(exchange_trial, key=exchange_trial.get) if exchange_trial else (min(exchange_us, key=exchange_us.get) if exchange_us else "torch")]
+            dist.broadcast_object_list(choice, 0)           # every rank must take the same decision: rank 0's
             want = choice[0]
         allreduce_kind = setup_exchange(sdf, want)
         if args.allreduce in ("shm", "peer") and allreduce_kind != KIND[args.allreduce]:
@@ -793,16 +813,18 @@ def run(args):
 
     # ---- N > 1: the same timed region with the other exchange step, for comparison
     def leg_other_exchange():
+        # the same timed region with each of the other in-library exchange steps (the main line ran with `allreduce_kind`)
         lg = state["leg"]
-        for mode, key in (("shm", "value_with_shared_memory_fan_in"), ("peer", "value_with_device_side_peer_exchange")):
-            if mode in exchange_us and setup_exchange(lg.sdf, mode) == KIND[mode]:
+        chosen = [k for k, v in KIND.items() if v == allreduce_kind]
+        for mode, key in (("rccl", "value_with_in_library_rccl"), ("shm", "value_with_shared_memory_fan_in"),
+                          ("peer", "value_with_device_side_peer_exchange")):
+            if mode in exchange_us and mode not in chosen and setup_exchange(lg.sdf, mode) == KIND[mode]:
                 lg.restart()
                 e4, _, _ = lg.timed_region(d_frames, events=False)
                 extras[key] = args.steps / e4
-        state["kind"] = setup_exchange(lg.sdf, "rccl")
+        state["kind"] = setup_exchange(lg.sdf, chosen[0] if chosen else "rccl")
         dist.barrier()
-    if world > 1 and not args.no_extras and args.dist_backend == "nccl" and allreduce_kind == "rccl-in-library" \
-            and ("shm" in exchange_us or "peer" in exchange_us):
+    if world > 1 and not args.no_extras and len(exchange_us) > 1:
         guarded("other_exchange", leg_other_exchange)
 
     # ---- full fr1/plant sequence (1246 frames): ATE-RMSE and tracking failures at 256^3 and at the benchmark m
@@ -923,7 +945,8 @@ def run(args):
                                    f"TUM images are not available on the box",
                        "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}" + (f" ({args.slabs} slabs, rank 0 owns layers [{leg_slab0[0]}, {leg_slab0[1]}))" if world > 1 else ""),
                        "halo": halo_main,
-                       "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us},
+                       "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us,
+                       "exchange_trial_frames_per_s": exchange_trial, "slabs": args.slabs if world > 1 else None},
             "ate_rmse_m": ate, "ate_frames": len(est_main) - 1, "abs_trajectory_rmse_m": raw,
             "gn_iterations_per_frame": cn["track_iterations"] / max(1, cn["track_calls"]),
             "stage_ms_per_frame": {"track_wall": 1e3 * track_wall_main / args.steps,

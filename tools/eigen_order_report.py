@@ -87,6 +87,53 @@ def free_run(m, width, height, n):
             "same_iteration_counts": iters[32] == iters[33], "iterations_eigen32": iters[32], "iterations_eigen33": iters[33]}
 
 
+def polar_factor_effect(m, width, height, n):
+    """camera_tracking.cpp:237-238 composes the pose with `aff.rotation()`.  In Eigen that is not the linear block of the
+    exponential map's Affine3d but its POLAR FACTOR: Transform::rotation() -> computeRotationScaling -> JacobiSVD,
+    R = U diag(1, 1, det(U V^T)) V^T.  The block is orthogonal to rounding (eigen_utils.cpp:72-80 builds it from cos / sinc
+    terms), so the factor equals it to ~1e-16 -- the oracle and the library use the block.  Quantified here: the same
+    free run twice with the Gauss-Newton loop spelled out in NumPy on the oracle's primitives (accumulate, 6x6 inverse,
+    exponential map), once with the block and once with NumPy's SVD polar factor of it (LAPACK's U, V differ from a Jacobi
+    SVD's, U V^T is unique up to rounding)."""
+    seq = synth.Sequence(n_frames=n, width=width, height=height, noise=True, holes=0.02, step=4)
+    res = {}
+    worst_block_gap = 0.0
+    for polar in (False, True):
+        s, t = make(m, seq.K)
+        pp, it = [], []
+        for k in range(n):
+            xyz, nrm, rgb = seq.frame(k)
+            c = orc.Cloud(xyz, nrm, rgb)
+            if k > 0:
+                g = 0
+                for g in range(20):
+                    A, b, st = t.accumulate(s, c, threads=1, stale_carry=True)
+                    Ainv, ok = orc.inverse6(A)
+                    tw = Ainv @ b
+                    T = orc.direct_exponential_map(tw, 1.0)
+                    Rd, td = T[:, :3].copy(), T[:, 3].copy()
+                    if polar:
+                        U, _, Vt = np.linalg.svd(Rd)
+                        x = np.linalg.det(U @ Vt)
+                        U[:, 0] /= x
+                        Rp = U @ Vt
+                        worst_block_gap = max(worst_block_gap, float(np.max(np.abs(Rp - Rd))))
+                        Rd = Rp
+                    stop = bool(np.all(tw < 0.001))                      # signed, camera_tracking.cpp:216-224
+                    t.set_camera_transformation(Rd.T @ t.rot, t.trans - Rd.T @ td)
+                    if stop:
+                        break
+                it.append(g + 1)
+            s.update(t, c, with_color=False)
+            pp.append((t.rot.copy(), t.trans.copy()))
+        res[polar] = (pp, it)
+    dt = [float(np.max(np.abs(a[1] - b[1]))) for a, b in zip(res[False][0], res[True][0])]
+    dr = [float(np.max(np.abs(a[0] - b[0]))) for a, b in zip(res[False][0], res[True][0])]
+    return {"frames": n, "max_abs_difference_polar_factor_vs_block_over_all_passes": worst_block_gap,
+            "translation_max_abs_difference_m_by_frame": dt, "rotation_max_abs_difference_by_frame": dr,
+            "same_iteration_counts": res[False][1] == res[True][1], "iterations": res[False][1]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=64)
@@ -95,7 +142,8 @@ def main():
     ap.add_argument("--frames", type=int, default=10)
     a = ap.parse_args()
     print(json.dumps({"integration_one_frame": integration(a.m, a.width, a.height),
-                      "free_run": free_run(a.m, a.width, a.height, a.frames)}, indent=1))
+                      "free_run": free_run(a.m, a.width, a.height, a.frames),
+                      "rotation_as_svd_polar_factor": polar_factor_effect(a.m, a.width, a.height, a.frames)}, indent=1))
 
 
 if __name__ == "__main__":
