@@ -145,14 +145,17 @@ def test_points_without_colour_and_argument_checks():
 
 
 def test_staging_threads_chunks_and_sets_do_not_change_the_result():
-    """the pageable path's knobs (pool size, chunked copies, one or two staging sets) move bytes, never values: an odd
+    """the pageable path's knobs (pool size, chunked copies, one or two staging sets, the tracker's samples uploaded ahead of
+    the planes or written by the packing kernel) move bytes, never values: an odd
     image size (planes that are no multiple of 16 bytes, a block whose planes need padding), set one by one and queued"""
     code = ("import numpy as np, tracking_sdf_amd as ts\n"
             "from tracking_sdf_amd import synth\n"
             "seq = synth.Sequence(n_frames=4, width=203, height=117, noise=True, holes=0.02, step=4)\n"
             "s = ts.SDF(32); t = ts.CameraTracking(sdf=s); t.set_K(seq.K)\n"
             "for k in range(2):\n"
-            "    s.set_frame(*seq.frame(k)); s.update()\n"
+            "    s.set_frame(*seq.frame(k))\n"
+            "    if k: t.estimate_new_position()\n"
+            "    s.update()\n"
             "fr = [tuple(np.ascontiguousarray(a) for a in seq.frame(k)) for k in range(4)]\n"
             "s.queue_frame(*fr[2])\n"
             "for k in (2, 3):\n"
@@ -162,7 +165,7 @@ def test_staging_threads_chunks_and_sets_do_not_change_the_result():
             "D, W = s.download(); print(float(D.sum()), float(W.sum()), int((W > 0).sum()), t.trans.tolist())\n")
     outs = []
     for knobs in ({"TSDF_HOST_THREADS": "1"}, {"TSDF_HOST_THREADS": "3"}, {"TSDF_HOST_THREADS": "7", "TSDF_STAGE_CHUNKS": "4"},
-                  {"TSDF_STAGE_CHUNKS": "3", "TSDF_STAGE_SETS": "1"}):
+                  {"TSDF_STAGE_CHUNKS": "3", "TSDF_STAGE_SETS": "1"}, {"TSDF_SAMPLES_FIRST": "0"}, {"TSDF_SAMPLES_FIRST": "0", "TSDF_HOST_THREADS": "2"}):
         env = dict(os.environ, **knobs)
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                                    cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip())

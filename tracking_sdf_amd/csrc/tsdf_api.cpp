@@ -222,6 +222,9 @@ struct tsdf_handle {
     // read buffer b (the tracker passes are host-synchronous and need no event).
     hipStream_t fstream = nullptr;
     hipEvent_t ev_frame = nullptr;
+    hipEvent_t ev_samples = nullptr;           // the frame's sample list is on the device (samples-first uploads)
+    bool records_pending = false;              // the frame's pixel records are still being produced on the frame stream (ev_frame):
+                                               // the tracker may run (it reads the sample list), tsdf_integrate waits for them
     hipEvent_t ev_copied = nullptr;            // the H2D copies of a frame handed over in page-locked caller buffers
     hipEvent_t ev_buf_used[2] = {nullptr, nullptr};
     bool used_valid[2] = {false, false};
@@ -569,7 +572,9 @@ int64_t released_serial(tsdf_handle* h) {
 // st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
 // overlaps the running integration like they do.  Device-resident inputs pack on the main stream: measured, a
 // pack_kernel squeezed in beside the persistent integrate_kernel slows that one down by as much as it takes.
-int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st, bool borrowed_planes = false) {
+int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st, bool borrowed_planes = false,
+             bool samples_first = false /* the sample list of this frame went up ahead (upload_samples_first): the pack writes the
+                                           records only and the main stream is NOT made to wait for it here -- tsdf_integrate does */) {
     if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
@@ -580,16 +585,22 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     EventPair* ep;
     int rc = timed_begin(h, 1, &ep, st);
     if (rc) return rc;
-    HIP_TRY(h, launch_pack(st, pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb)));
+    {
+        PackArgs pa = pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb);
+        if (samples_first) pa.samples = nullptr;
+        HIP_TRY(h, launch_pack(st, pa));
+    }
     if (borrowed_planes) {
         borrow_device_frame(h, h->frame_serial + 1);
         HIP_TRY(h, launch_release(st, release_for(h, h->frame_serial + 1, side ? 1 : 0)));
     }
     rc = timed_end(h, ep, st);
     if (rc) return rc;
+    h->records_pending = false;
     if (side) {
         HIP_TRY(h, hipEventRecord(h->ev_frame, st));
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));   // everything queued on `stream` from here on sees the frame
+        if (samples_first) h->records_pending = true;          // the tracker needs the sample list only (main stream waits for ev_samples)
+        else HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));   // everything queued on `stream` from here on sees the frame
     }
     h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
     h->have_frame = true;
@@ -597,6 +608,49 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     h->frame_has_nrm = nrm != nullptr;
     h->frame_has_rgb = rgb != nullptr;
     h->deferred = tsdf_handle::DeferredPack();
+    return TSDF_OK;
+}
+
+// Samples first: a frame that arrives in host memory needs 8.3 MB (640x480) on the device before it can be integrated, but the
+// tracker only reads every pixel_stride-th point of every pixel_stride-th row -- 34 240 points, 0.5 MB.  They are gathered
+// from the caller's memory (pixel p at base + p * pixel_bytes + xyz_offset: planes or arrays of structs) by the staging
+// threads, in the reference's visiting order (columns outer, rows inner, camera_tracking.cpp:162-163), copied in front of
+// everything else of the frame, and the main stream waits for THAT copy only: the Gauss-Newton passes run while the planes
+// are still travelling.  Writes the list of the record buffer the frame is about to take (fidx ^ 1).
+HostPool* host_pool(tsdf_handle* h);        // (the staging threads, defined with the frame entry points below)
+int ensure_pin_samples(tsdf_handle* h) {
+    const size_t ns = (size_t)h->n_samples;
+    if (ns <= h->pin_samples_cap) return TSDF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
+    h->pin_samples_cap = 0;
+    for (int b = 0; b < 2; ++b) HIP_TRY(h, hipHostMalloc((void**)&h->pin_samples[b], ns * sizeof(float4), hipHostMallocDefault));
+    h->pin_samples_cap = ns;
+    return TSDF_OK;
+}
+int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width) {
+    int rc = ensure_pin_samples(h);
+    if (rc) return rc;
+    const int nb = h->fidx ^ 1;
+    float4* const ps = h->pin_samples[nb];
+    const int32_t st = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows;
+    const std::function<void(int, int)> gather = [&](int part, int parts) {
+        const int r0 = (int)((long long)nrows * part / parts), r1 = (int)((long long)nrows * (part + 1) / parts);
+        for (int rj = r0; rj < r1; ++rj) {
+            const char* rowp = (const char*)base + ((size_t)rj * st * width) * pixel_bytes + xyz_offset;
+            for (int ci = 0; ci < ncols; ++ci) {
+                float4 v;
+                std::memcpy(&v, rowp + (size_t)ci * st * pixel_bytes, 12);
+                v.w = 0.0f;
+                ps[(size_t)ci * nrows + rj] = v;
+            }
+        }
+    };
+    HostPool* const pool = host_pool(h);
+    if (pool) pool->run(gather); else gather(0, 1);
+    HIP_TRY(h, hipMemcpyAsync(h->samples_buf[nb], ps, (size_t)h->n_samples * sizeof(float4), hipMemcpyHostToDevice, h->fstream));
+    HIP_TRY(h, hipEventRecord(h->ev_samples, h->fstream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_samples, 0));
     return TSDF_OK;
 }
 
@@ -619,6 +673,7 @@ int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t
     h->frame_has_rgb = rgb != nullptr;
     h->deferred = tsdf_handle::DeferredPack();
     h->deferred.pending = true; h->deferred.xyz = xyz; h->deferred.nrm = nrm; h->deferred.rgb = rgb;
+    h->records_pending = false;
     return TSDF_OK;
 }
 
@@ -1214,6 +1269,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_samples, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_queued, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[0], hipEventDisableTiming));
@@ -1355,6 +1411,7 @@ void tsdf_destroy(tsdf_handle* h) {
     }
     if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
+    if (h->ev_samples) (void)hipEventDestroy(h->ev_samples);
     if (h->ev_queued) (void)hipEventDestroy(h->ev_queued);
     for (int b = 0; b < 2; ++b) if (h->ev_stage_done[b]) (void)hipEventDestroy(h->ev_stage_done[b]);
     if (h->partials) (void)hipFree(h->partials);
@@ -1619,13 +1676,15 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     if (!direct) {
+        static const bool samples_first = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
+        if (samples_first) { rc = upload_samples_first(h, xyz, 12, 0, width); if (rc) return rc; }
         HIP_TRY(h, stage_and_upload(h, npix, true, nrm != nullptr, rgb != nullptr, [&](size_t i0, size_t i1) {
             std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
         }));
         h->staged_xyz = true;
-        return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
+        return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
     }
     HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
@@ -1890,12 +1949,16 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
     const tsdf_aos_layout lay = *L;
+    // a new cloud: its tracker samples go up first (the passes of a following tsdf_track run under the planes' copy)
+    static const bool samples_first_on = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
+    const bool samples_first = samples_first_on && points != nullptr;
+    if (samples_first) { rc = upload_samples_first(h, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset, width); if (rc) return rc; }
     HIP_TRY(h, stage_and_upload(h, npix, points != nullptr, normals != nullptr, color, [&](size_t i0, size_t i1) {
         repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
     }));
     const bool has_rgb = points ? color : had_rgb;
     h->staged_xyz = true;
-    return run_pack(h, h->in_xyz, normals ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, h->fstream);
+    return run_pack(h, h->in_xyz, normals ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
 }
 
 // ---- depth pre-processing (optional stage in front of the hot path) -------------------------------------------
@@ -2096,6 +2159,10 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     if (!h->frame_has_nrm) return fail(h, TSDF_E_NO_FRAME, "tsdf_integrate needs normals in the current frame");
     if (h->cfg.with_color && !h->frame_has_rgb)
         return fail(h, TSDF_E_NO_FRAME, "with_color=1 needs rgb in the current frame");
+    if (h->records_pending) {                // samples-first frame: the records come off the frame stream behind the planes' copy
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
+        h->records_pending = false;
+    }
     if (h->deferred.pending) choose_pixel_layout(h);      // the records are written in this launch: lay them out for the pose they are read at
     IntegrateParams p;
     fill_integrate_params(h, p);
@@ -2331,14 +2398,8 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
     rc = ensure_second_staging_set(h, npix);
     if (rc) return rc;
     lap(tp, h->sp.a_prep1);
-    const size_t ns = (size_t)h->n_samples;
-    if (ns > h->pin_samples_cap) {
-        HIP_TRY(h, hipStreamSynchronize(h->fstream));
-        for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
-        h->pin_samples_cap = 0;
-        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipHostMalloc((void**)&h->pin_samples[b], ns * sizeof(float4), hipHostMallocDefault));
-        h->pin_samples_cap = ns;
-    }
+    rc = ensure_pin_samples(h);
+    if (rc) return rc;
     if (!h->qthread.joinable()) {
         try { h->qthread = std::thread(queue_thread_main, h); }
         catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_track_aos: cannot start the staging thread"); }
@@ -2352,34 +2413,13 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
     h->tracked = tsdf_handle::TrackedCloud();
     if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
     h->deferred = tsdf_handle::DeferredPack();
-    // 1. the tracker's samples, in the reference's visiting order (columns outer, rows inner, camera_tracking.cpp:162-163),
-    //    straight from the cloud: sample (ci, rj) = point (ci * stride, rj * stride).  Sample rows are shared out over the
-    //    library threads (each reads along image rows).
+    // 1. the tracker's samples, straight from the cloud, in front of everything else (upload_samples_first)
     const int nb = h->fidx ^ 1;
-    {
-        float4* const ps = h->pin_samples[nb];
-        const int32_t st = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows;
-        const tsdf_aos_layout lay = *L;
-        const std::function<void(int, int)> gather = [&](int part, int parts) {
-            const int r0 = (int)((long long)nrows * part / parts), r1 = (int)((long long)nrows * (part + 1) / parts);
-            for (int rj = r0; rj < r1; ++rj) {
-                const char* rowp = (const char*)points + ((size_t)rj * st * width) * (size_t)lay.point_stride + lay.xyz_offset;
-                for (int ci = 0; ci < ncols; ++ci) {
-                    float4 v;
-                    std::memcpy(&v, rowp + (size_t)ci * st * (size_t)lay.point_stride, 12);
-                    v.w = 0.0f;
-                    ps[(size_t)ci * nrows + rj] = v;
-                }
-            }
-        };
-        HostPool* const pool = host_pool(h);
-        lap(tp, h->sp.a_prep);
-        if (pool) pool->run(gather); else gather(0, 1);
-        lap(tp, h->sp.a_gather);
-        HIP_TRY(h, hipMemcpyAsync(h->samples_buf[nb], ps, ns * sizeof(float4), hipMemcpyHostToDevice, h->fstream));
-        HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
-    }
+    lap(tp, h->sp.a_prep);
+    rc = upload_samples_first(h, points, (size_t)L->point_stride, (size_t)L->xyz_offset, width);
+    if (rc) return rc;
+    lap(tp, h->sp.a_gather);
+    h->records_pending = false;              // (this frame's records are written by tsdf_integrate_aos, which orders them itself)
     choose_pixel_layout(h);
     h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
     h->have_frame = true;
