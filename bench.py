@@ -725,8 +725,8 @@ def run(args):
         e2 = best_of_two("host", host_frames)
         extras["value_h2d_inclusive"] = args.steps / e2
         extras["h2d_inclusive_note"] = ("best of two repetitions; xyz + normals + rgb (27 B/pixel) handed over as HOST buffers every frame through "
-                                        "tsdf_set_frame: staging copy + H2D + pack on the frame side stream, overlapping the "
-                                        "previous integration")
+                                        "tsdf_set_frame, one frame at a time: the tracker's 34 240 samples are copied first and its passes run "
+                                        "under the planes' copy (round 5); staging copy + H2D + pack on the frame side stream")
         e2p = best_of_two("host", pinned_frames)
         extras["value_h2d_inclusive_pinned_buffers"] = args.steps / e2p
         extras["h2d_inclusive_pinned_note"] = ("the same with the caller's buffers page-locked: tsdf_set_frame copies from them "
