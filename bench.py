@@ -423,8 +423,8 @@ def run(args):
         def first_frame(self, fr, mode=MAIN_MODE, host=None, depth16=None):
             """frame 1: integrate only at the reference's initial pose (sdf_reconstruction.cpp:69)"""
             self.est = []
-            if mode in ("ref_calls", "ref_calls_r4"):
-                self.sdf.update_aos(*host[0]) if mode == "ref_calls" else (self.sdf.set_frame_aos(*host[0]), self.sdf.update(want_stats=False))
+            if mode in ("ref_calls", "ref_calls_r4", "ref_calls_normals"):
+                self.sdf.update_aos(*host[0]) if mode != "ref_calls_r4" else (self.sdf.set_frame_aos(*host[0]), self.sdf.update(want_stats=False))
             else:
                 self.feed(0, fr, mode, host, depth16)
                 self.sdf.update(want_stats=False)
@@ -472,13 +472,16 @@ def run(args):
                 self.sdf.set_depth_frame(depth16[k], host[k][2])
 
         def step(self, k, fr, mode=MAIN_MODE, host=None, depth16=None, timed=False):
-            if mode in ("ref_calls", "ref_calls_r4"):
+            if mode in ("ref_calls", "ref_calls_r4", "ref_calls_normals"):
                 # exactly what kinect_callback does (sdf_reconstruction.cpp:70,74), synchronously, on pageable PCL-layout
                 # clouds: estimate_new_position(sdf, cloud) then update(tracker, cloud, normals)
                 pts, nn = host[k]
                 if mode == "ref_calls":
                     self.sdf.track_aos(pts)                        # samples first, the cloud staged under the passes
                     self.sdf.update_aos(pts, nn)                   # normals; the cloud is compared, not uploaded again
+                elif mode == "ref_calls_normals":                  # one more argument at :70: the normals at tracking time
+                    self.sdf.track_aos(pts, nn)                    # the whole frame staged and packed under the passes
+                    self.sdf._check(L.tsdf_integrate(self.sdf._h, None))
                 else:                                              # round 4's shim: two uploads, a host wait for the frame stream
                     self.sdf.set_frame_aos(pts, None)
                     self.sdf._check(L.tsdf_track(self.sdf._h, None))
@@ -749,13 +752,17 @@ def run(args):
         # the rate through the reference's own two entry points, called the way kinect_callback calls them
         extras["value_reference_entry_points"] = args.steps / best_of_two("ref_calls", aos)
         extras["value_reference_entry_points_round4_sequence"] = args.steps / best_of_two("ref_calls_r4", aos)
+        extras["value_reference_entry_points_normals_at_track"] = args.steps / best_of_two("ref_calls_normals", aos)
         extras["reference_entry_points_note"] = (
             "estimate_new_position(sdf, cloud) then update(tracker, cloud, normals), synchronously, one frame at a time, clouds as arrays of "
             "PCL's 32-byte structs in pageable memory (sdf_reconstruction.cpp:33-49,70,74) = tsdf_track_aos + tsdf_integrate_aos, which the "
             "exact-type shim forwards to: the tracker's 34 240 samples are copied first, the cloud is staged under the Gauss-Newton passes, "
             "update adds the normals and compares the cloud instead of uploading it again.  _round4_sequence: what the shim issued until "
             "round 4 (tsdf_set_frame_aos(points) -> tsdf_track -> tsdf_set_frame_aos(normals only) -> tsdf_integrate).  The normals are only "
-            "handed over by update, so their repack and copy (3.7 MB) sit between a frame's last pass and its integration whatever the library does")
+            "handed over by update, so their repack and copy (3.7 MB) sit between a frame's last pass and its integration whatever the library does.  "
+            "_normals_at_track: NOT the reference's call -- estimate_new_position(sdf, cloud, normals), one more argument at "
+            "sdf_reconstruction.cpp:70 (kinect_callback holds the normals by then): the whole frame is staged and packed under the passes "
+            "(tsdf_track_frame_aos) and update integrates what was staged")
         # ... and the same loop in C++ through the reference's exact signatures (tests/mock/refcall_demo.cpp, built against the
         # mock Eigen / PCL headers: test infrastructure; the library underneath is the product), on the same frames
         try:
@@ -771,14 +778,15 @@ def run(args):
                         f.write(struct.pack("<d", float(seq.stamps[k])))
                         f.write(np.ascontiguousarray(x, dtype="<f4").tobytes()); f.write(np.ascontiguousarray(n_, dtype="<f4").tobytes())
                         f.write(np.ascontiguousarray(c, dtype=np.uint8).tobytes())
-                best = 0.0
-                for _ in range(2):
-                    pr = subprocess.run([os.path.join(ROOT, "build", "refcall_demo"), fb, str(m), os.path.join(td, "traj.txt")],
-                                        capture_output=True, text=True, timeout=300)
-                    for line in pr.stderr.splitlines():
-                        if line.startswith("RATE "):
-                            best = max(best, float(line.split()[1]))
-                extras["value_reference_entry_points_cpp"] = best if best > 0 else None
+                for key, flag in (("value_reference_entry_points_cpp", []), ("value_reference_entry_points_normals_at_track_cpp", ["normals-at-track"])):
+                    best = 0.0
+                    for _ in range(2):
+                        pr = subprocess.run([os.path.join(ROOT, "build", "refcall_demo"), fb, str(m), os.path.join(td, "traj.txt")] + flag,
+                                            capture_output=True, text=True, timeout=300)
+                        for line in pr.stderr.splitlines():
+                            if line.startswith("RATE "):
+                                best = max(best, float(line.split()[1]))
+                    extras[key] = best if best > 0 else None
         except Exception as e:      # noqa: BLE001
             extras["value_reference_entry_points_cpp"] = None
             extras["reference_entry_points_cpp_error"] = f"{type(e).__name__}: {e}"

@@ -388,6 +388,29 @@ public:
         pull();
         sdf->check(rc, "tsdf_track_aos");
     }
+    // NOT in the reference: the same call with the frame's normals, which kinect_callback has in hand before it tracks
+    // (sdf_reconstruction.cpp:44-49).  One more argument at :70 -- estimate_new_position(sdf, cloud_filtered, normals) --
+    // lets the library stage the WHOLE frame under the Gauss-Newton passes; update(tracker, cloud_filtered, normals) with
+    // the same two clouds then integrates what was staged without another upload or comparison: the caller vouches that
+    // neither cloud changes between the two calls (pass other clouds, or use the two-argument form, when that is not so).
+    void estimate_new_position(const SDF* sdf, const pcl::PointCloud<pcl::PointXYZRGB>::Ptr& point_cloud,
+                               const pcl::PointCloud<pcl::Normal>::Ptr& normals) {
+        push(sdf);
+        vouched_points_ = vouched_normals_ = nullptr;
+        const int rc = tsdf_track_frame_aos(sdf->handle(), point_cloud->points.data(), normals->points.data(), &pcl_layout(),
+                                            (int32_t)point_cloud->width, (int32_t)point_cloud->height, nullptr);
+        pull();
+        sdf->check(rc, "tsdf_track_frame_aos");
+        vouched_points_ = point_cloud->points.data(); vouched_normals_ = normals->points.data();
+        vouched_serial_ = tsdf_frame_serial(sdf->handle());
+    }
+    // one-shot: does update() receive the very clouds the three-argument estimate_new_position staged?
+    bool take_vouched(const SDF* sdf, const void* points, const void* normals) {
+        const bool yes = vouched_points_ && points == vouched_points_ && normals == vouched_normals_ &&
+                         vouched_serial_ == tsdf_frame_serial(sdf->handle());
+        vouched_points_ = vouched_normals_ = nullptr;
+        return yes;
+    }
     // camera_tracking.cpp:40-47: ij = K * camera_point, (u, v) = ij.xy / ij.z   (fixed-size product, Eigen 3.2 order)
     void project_camera_to_image_plane(Eigen::Vector3d& camera_point, Eigen::Vector2d& image_point) {
         double ij[3];
@@ -496,6 +519,7 @@ public:
 
 private:
     tsdf_shim::CameraTracking impl_;
+    const void* vouched_points_ = nullptr; const void* vouched_normals_ = nullptr; int64_t vouched_serial_ = -1;
     Eigen::Matrix3d seen_rot_, seen_rot_inv_, seen_K_;
     Eigen::Vector3d seen_trans_, seen_rot_inv_trans_;
 };
@@ -508,6 +532,10 @@ private:
 inline void SDF::update(CameraTracking* camera_tracking, pcl::PointCloud<pcl::PointXYZRGB>::Ptr cloud_filtered,
                         pcl::PointCloud<pcl::Normal>::Ptr normals) {
     if (camera_tracking) camera_tracking->push(this);
+    if (camera_tracking && camera_tracking->take_vouched(this, cloud_filtered->points.data(), normals->points.data())) {
+        check(tsdf_integrate(handle(), nullptr), "tsdf_integrate");      // staged whole by the three-argument estimate_new_position
+        return;
+    }
     check(tsdf_integrate_aos(handle(), cloud_filtered->points.data(), normals->points.data(), &pcl_layout(),
                              (int32_t)cloud_filtered->width, (int32_t)cloud_filtered->height, nullptr), "tsdf_integrate_aos");
 }

@@ -225,6 +225,15 @@ int tsdf_queue_frame_aos(tsdf_handle *h, const void *points, const void *normals
  * tsdf_set_frame_aos(points, normals) + tsdf_integrate.  Buffers are borrowed for the call only. */
 int tsdf_track_aos(tsdf_handle *h, const void *points, const tsdf_aos_layout *layout, int32_t width, int32_t height,
                    tsdf_track_stats *stats);
+/* The same with the frame's normals handed over at tracking time -- one more argument than the reference's
+ * estimate_new_position has, for a caller that can give it: kinect_callback holds `normals` before it tracks
+ * (sdf_reconstruction.cpp:44-49,70).  The whole frame (8.3 MB at 640x480) is then staged and copied under the
+ * Gauss-Newton passes, and its pixel records are packed behind the copy: when the call returns the frame is complete and
+ * tsdf_integrate (no further upload) integrates it -- the synchronous callback then runs at about the rate of the two-deep
+ * queue.  Both clouds are borrowed for the call only.  tsdf_integrate_aos after this call still compares BOTH clouds with
+ * what was staged, every point and normal, and uploads what differs; tsdf_integrate takes the staged frame as it is. */
+int tsdf_track_frame_aos(tsdf_handle *h, const void *points, const void *normals, const tsdf_aos_layout *layout,
+                         int32_t width, int32_t height, tsdf_track_stats *stats);
 int tsdf_integrate_aos(tsdf_handle *h, const void *points, const void *normals, const tsdf_aos_layout *layout,
                        int32_t width, int32_t height, tsdf_integrate_stats *stats);
 

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "sdf_3d_reconstruction/hotpath.hpp"
@@ -20,6 +21,7 @@ int main(int argc, char** argv) {
     sensor_msgs::CameraInfo info;
     if (std::fread(hdr, sizeof hdr, 1, f) != 1 || std::fread(info.K, sizeof(double), 9, f) != 9) return 2;
     const int n = hdr[0], w = hdr[1], h = hdr[2];
+    const bool normals_early = argc > 4 && std::string(argv[4]) == "normals-at-track";
     try {
         Vector3d sdf_origin(-3.0, -3.0, -0.5);
         SDF* sdf = new SDF(std::atoi(argv[2]), 6.0, 6.0, 3.5, sdf_origin, 0.3, 0.025);          // sdf_reconstruction.cpp:85
@@ -61,7 +63,8 @@ int main(int argc, char** argv) {
             const pcl::PointCloud<pcl::PointXYZRGB>::Ptr& cloud_filtered = clouds[frame_num - 1];
             const pcl::PointCloud<pcl::Normal>::Ptr& normals = normal_clouds[frame_num - 1];
             if (frame_num > 1) {                                                                  // :69-72
-                camera_tracking->estimate_new_position(sdf, cloud_filtered);
+                if (normals_early) camera_tracking->estimate_new_position(sdf, cloud_filtered, normals);   // one more argument than :70
+                else camera_tracking->estimate_new_position(sdf, cloud_filtered);
                 const Eigen::Vector3d& trans = camera_tracking->trans;
                 std::fprintf(out, "%.4f %.4f %.4f %.4f\n", stamps[frame_num - 1], trans.x(), trans.y(), trans.z());
             }
@@ -70,8 +73,8 @@ int main(int argc, char** argv) {
         tsdf_synchronize(sdf->handle());
         if (n - 1 - warm > 0) {
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            std::fprintf(stderr, "RATE %.1f frames/s over %d frames of %dx%d through estimate_new_position + update (exact reference signatures)\n",
-                         (double)(n - 1 - warm) / sec, n - 1 - warm, w, h);
+            std::fprintf(stderr, "RATE %.1f frames/s over %d frames of %dx%d through estimate_new_position + update (exact reference signatures%s)\n",
+                         (double)(n - 1 - warm) / sec, n - 1 - warm, w, h, normals_early ? "; the normals handed to estimate_new_position as well" : "");
         }
         std::fclose(out);
         std::printf("final pose t = %.9f %.9f %.9f  rot00 = %.9f\n", camera_tracking->trans(0), camera_tracking->trans(1),

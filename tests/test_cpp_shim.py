@@ -59,11 +59,14 @@ def test_exact_type_call_sites_give_the_same_trajectory_as_the_plain_shim(tmp_pa
     frames_bin = str(tmp_path / "frames.bin")
     dump(frames_bin, n=4, width=160, height=120, step=2)
     outs = []
-    for exe, name in ((exe_plain, "a.txt"), (exe_ref, "b.txt")):
-        p = subprocess.run([exe, frames_bin, "64", str(tmp_path / name)], capture_output=True, text=True)
+    # (the third run: the shim's three-argument estimate_new_position(sdf, cloud, normals) -- the whole frame staged under
+    # the passes, update() integrates what was staged -- must give the same trajectory again)
+    for exe, name, extra in ((exe_plain, "a.txt", []), (exe_ref, "b.txt", []), (exe_ref, "c.txt", ["normals-at-track"])):
+        p = subprocess.run([exe, frames_bin, "64", str(tmp_path / name)] + extra, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
         outs.append((np.loadtxt(str(tmp_path / name))[:, :4], [float(x) for x in p.stdout.split("=")[1].split()[:3]]))
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][0], outs[2][0]) and outs[0][1] == outs[2][1]
 
 
 @pytest.mark.gpu

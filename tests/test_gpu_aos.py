@@ -91,6 +91,25 @@ def aos_entry_points_no_cloud(s, t, k, xyz, nrm, rgb):
         s.update_aos(pts, nn)
 
 
+def aos_entry_points_whole_frame(s, t, k, xyz, nrm, rgb):
+    """tsdf_track_frame_aos: the normals handed over at tracking time, the whole frame staged and packed under the passes;
+    plain tsdf_integrate then integrates what was staged"""
+    pts, nn = clouds(xyz, nrm, rgb)
+    if k > 0:
+        s.track_aos(pts, nn)
+        s.update()
+    else:
+        s.update_aos(pts, nn)
+
+
+def aos_entry_points_whole_frame_checked(s, t, k, xyz, nrm, rgb):
+    """... and tsdf_integrate_aos behind it: both clouds compared with what was staged, nothing uploaded again"""
+    pts, nn = clouds(xyz, nrm, rgb)
+    if k > 0:
+        s.track_aos(pts, nn)
+    s.update_aos(pts if k % 2 else None, nn) if k > 0 else s.update_aos(pts, nn)
+
+
 def aos_entry_points_tight(s, t, k, xyz, nrm, rgb):
     pd = np.dtype({"names": ["r", "g", "b", "x", "y", "z"], "formats": ["u1", "u1", "u1", "<f4", "<f4", "<f4"],
                    "offsets": [0, 1, 2, 4, 8, 12], "itemsize": 16})
@@ -101,7 +120,8 @@ def aos_entry_points_tight(s, t, k, xyz, nrm, rgb):
     s.update_aos(pts, nn)
 
 
-@pytest.mark.parametrize("feed", [aos_reference_order, aos_tight, aos_entry_points, aos_entry_points_no_cloud, aos_entry_points_tight])
+@pytest.mark.parametrize("feed", [aos_reference_order, aos_tight, aos_entry_points, aos_entry_points_no_cloud, aos_entry_points_tight,
+                                  aos_entry_points_whole_frame, aos_entry_points_whole_frame_checked])
 def test_aos_frames_give_the_planar_result(feed):
     want = run_sequence(planar)
     got = run_sequence(feed)
@@ -253,7 +273,7 @@ def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
     seq = synth.Sequence(n_frames=3, width=W, height=H, noise=True, holes=0.02, step=4)
     fr = [seq.frame(k) for k in range(3)]
 
-    def run(entry_points, variant):
+    def run(entry_points, variant, whole=False):
         s = ts.SDF(M, with_color=True)
         t = ts.CameraTracking(sdf=s)
         t.set_K(seq.K)
@@ -261,7 +281,7 @@ def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
         xyz, nrm, rgb = (a.copy() for a in fr[1])
         pts, nn = clouds(xyz, nrm, rgb)
         if entry_points:
-            st = s.track_aos(pts)
+            st = s.track_aos(pts, nn if whole else None)
         else:
             s.set_frame(xyz, None, rgb)
             st = t.estimate_new_position()
@@ -271,6 +291,10 @@ def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
             for r, c in valid[np.linspace(500, len(valid) - 500, 8).astype(int)]:
                 xyz[r, c, 2] += 0.05; pts["z"][r, c] = xyz[r, c, 2]
                 rgb[r, c, 1] ^= 0x40; pts["g"][r, c] = rgb[r, c, 1]
+        elif variant == "one normal":            # ... or a handful of normals (only the whole-frame staging holds them yet)
+            valid = np.argwhere(np.isfinite(xyz[..., 2]) & np.isfinite(nrm[..., 2]))
+            for r, c in valid[np.linspace(700, len(valid) - 700, 8).astype(int)]:
+                nrm[r, c] = nrm[r, c] * np.float32(0.5); nn["normal_x"][r, c], nn["normal_y"][r, c], nn["normal_z"][r, c] = nrm[r, c]
         elif variant == "other cloud":
             xyz, nrm, rgb = (a.copy() for a in fr[2])
             pts, nn = clouds(xyz, nrm, rgb)
@@ -285,14 +309,18 @@ def test_update_integrates_the_cloud_as_it_is_when_update_is_called():
         out = (pose, s.download(), s.download_color())
         s.close()
         return out
-    for variant in ("same", "one point", "other cloud", "twice"):
-        want, got = run(False, variant), run(True, variant)
-        assert np.array_equal(want[0][0], got[0][0]) and np.array_equal(want[0][1], got[0][1]) and want[0][2] == got[0][2], variant
-        for a, b in zip(want[1] + want[2], got[1] + got[2]):
-            assert np.array_equal(a, b), variant
+    for variant in ("same", "one point", "one normal", "other cloud", "twice"):
+        want = run(False, variant)
+        for whole in (False, True):
+            got = run(True, variant, whole)
+            assert np.array_equal(want[0][0], got[0][0]) and np.array_equal(want[0][1], got[0][1]) and want[0][2] == got[0][2], (variant, whole)
+            for a, b in zip(want[1] + want[2], got[1] + got[2]):
+                assert np.array_equal(a, b), (variant, whole)
     # and the one changed point really changes the volume (the test would notice a skipped upload)
     a, b = run(True, "same"), run(True, "one point")
     assert not np.array_equal(a[1][0], b[1][0]) and not np.array_equal(a[2][2], b[2][2])
+    a, b = run(True, "same", True), run(True, "one normal", True)
+    assert not np.array_equal(a[1][0], b[1][0])             # half-length normals halve the point-to-plane distances
 
 
 def test_track_aos_state_and_argument_checks():

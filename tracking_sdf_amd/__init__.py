@@ -105,7 +105,7 @@ ABI_SYMBOLS = (
     "tsdf_abi_version", "tsdf_default_config", "tsdf_create", "tsdf_destroy", "tsdf_last_error", "tsdf_strerror",
     "tsdf_get_config", "tsdf_set_intrinsics", "tsdf_set_camera_transformation", "tsdf_set_tracker_params", "tsdf_get_pose", "tsdf_set_frame",
     "tsdf_frame_serial", "tsdf_queue_frame", "tsdf_queue_frame_device", "tsdf_queue_frame_aos", "tsdf_next_frame",
-    "tsdf_set_frame_device", "tsdf_device_frame_released", "tsdf_set_frame_aos", "tsdf_track_aos", "tsdf_integrate_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_queue_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
+    "tsdf_set_frame_device", "tsdf_device_frame_released", "tsdf_set_frame_aos", "tsdf_track_aos", "tsdf_track_frame_aos", "tsdf_integrate_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_queue_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
     "tsdf_slab_range", "tsdf_slab_range_weighted", "tsdf_frustum_layer_weights", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
@@ -164,6 +164,7 @@ def lib():
         "tsdf_queue_frame_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
         "tsdf_set_frame_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32]),
         "tsdf_track_aos": (C.c_int, [H, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32, C.POINTER(TrackStats)]),
+        "tsdf_track_frame_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32, C.POINTER(TrackStats)]),
         "tsdf_integrate_aos": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(AosLayout), C.c_int32, C.c_int32, C.POINTER(IntegrateStats)]),
         "tsdf_default_preproc": (None, [C.POINTER(PreprocParams)]),
         "tsdf_set_depth_frame": (C.c_int, [H, C.POINTER(C.c_uint16), fp, u8p, C.c_int32, C.c_int32, C.POINTER(PreprocParams)]),
@@ -466,14 +467,20 @@ class SDF:
             lay.normal_stride, lay.normal_offset = normals.dtype.itemsize, g["normal_x"][1]
         return lay
 
-    def track_aos(self, points):
+    def track_aos(self, points, normals=None):
         """tsdf_track_aos = CameraTracking::estimate_new_position(sdf, cloud) on an array of point structs (C-contiguous
-        structured array of shape (height, width)): samples first, the rest of the cloud staged under the passes."""
-        if not points.flags["C_CONTIGUOUS"] or points.ndim != 2:
+        structured array of shape (height, width)): samples first, the rest of the cloud staged under the passes.  With
+        `normals` (tsdf_track_frame_aos) the whole frame is staged and packed under the passes: follow with update()."""
+        if not points.flags["C_CONTIGUOUS"] or points.ndim != 2 or (normals is not None and not normals.flags["C_CONTIGUOUS"]):
             raise ValueError("an organized C-contiguous cloud of shape (height, width) is needed")
-        lay = self._aos_layout(points)
+        lay = self._aos_layout(points, normals)
         st = TrackStats()
-        self._check(lib().tsdf_track_aos(self._h, C.c_void_p(points.ctypes.data), C.byref(lay), points.shape[1], points.shape[0], C.byref(st)))
+        if normals is None:
+            rc = lib().tsdf_track_aos(self._h, C.c_void_p(points.ctypes.data), C.byref(lay), points.shape[1], points.shape[0], C.byref(st))
+        else:
+            rc = lib().tsdf_track_frame_aos(self._h, C.c_void_p(points.ctypes.data), C.c_void_p(normals.ctypes.data), C.byref(lay),
+                                            points.shape[1], points.shape[0], C.byref(st))
+        self._check(rc)
         return {"iterations": int(st.iterations), "stopped": int(st.stopped), "n_terms_last": int(st.n_terms_last),
                 "last_twist": np.array(st.last_twist)}
 

@@ -202,6 +202,7 @@ struct tsdf_handle {
     struct TrackedCloud {
         bool valid = false, color = false;
         const void* points = nullptr; int32_t w = 0, h = 0; int64_t serial = -1;
+        const void* normals = nullptr;         // non-null: tsdf_track_frame_aos staged the normals too (the frame is complete)
         tsdf_aos_layout lay{};
     } tracked;
     hipEvent_t ev_stage_done[2] = {nullptr, nullptr};   // [0]: the copies out of the set in use have been issued up to here; [1]: the other set's
@@ -2373,21 +2374,39 @@ bool points_equal_planes(const tsdf_aos_layout& lay, const void* points, bool co
     }
     return diff == 0u;
 }
+bool normals_equal_plane(const tsdf_aos_layout& lay, const void* normals, const float* pnm, size_t i0, size_t i1) {
+    const char* p = (const char*)normals + i0 * (size_t)lay.normal_stride + lay.normal_offset;
+    unsigned diff = 0u;
+    for (size_t i = i0; i < i1; ++i, p += lay.normal_stride) diff |= (unsigned)(std::memcmp(pnm + 3 * i, p, 12) != 0);
+    return diff == 0u;
+}
+int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height, tsdf_track_stats* stats);
 }  // namespace
 
 int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L, int32_t width, int32_t height, tsdf_track_stats* stats) {
+    return track_aos_impl(h, points, nullptr, L, width, height, stats);
+}
+int tsdf_track_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height,
+                         tsdf_track_stats* stats) {
+    if (h && !normals) return fail(h, TSDF_E_BADARG, "tsdf_track_frame_aos: the normals are required (tsdf_track_aos takes the points alone)");
+    return track_aos_impl(h, points, normals, L, width, height, stats);
+}
+
+namespace {
+int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height, tsdf_track_stats* stats) {
     if (!h || !L || !points || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_track_aos: bad argument") : TSDF_E_BADARG;
     if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_track_aos");
     bool color = false;
     int rc = check_point_layout(h, "tsdf_track_aos", L, &color);
     if (rc) return rc;
+    if (normals) { rc = check_normal_layout(h, "tsdf_track_frame_aos", L); if (rc) return rc; }
     using pclk = std::chrono::steady_clock;
     const bool prof = h->sp.on;
     auto lap = [prof](pclk::time_point& t, double& acc) { if (prof) { const pclk::time_point n = pclk::now(); acc += std::chrono::duration<double, std::nano>(n - t).count(); t = n; } };
     pclk::time_point tp = prof ? pclk::now() : pclk::time_point();
     static const bool plain = [] { const char* e = std::getenv("TSDF_TRACK_AOS"); return e && std::atoi(e) == 0; }();
     if (plain) {                                 // TSDF_TRACK_AOS=0 (comparison): the whole cloud in front of the passes, as round 4's shim did
-        rc = tsdf_set_frame_aos(h, points, nullptr, L, width, height);
+        rc = tsdf_set_frame_aos(h, points, normals, L, width, height);
         return rc ? rc : tsdf_track(h, stats);
     }
     rc = bind_device(h);
@@ -2424,20 +2443,32 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
     h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
     h->have_frame = true;
     h->frame_serial++;
-    h->frame_has_nrm = false;                // the pixel records are written when the normals arrive (tsdf_integrate_aos)
+    h->frame_has_nrm = false;                // the pixel records are written when the normals arrive (tsdf_integrate_aos) ...
     h->frame_has_rgb = color;
     h->frame_side = true;
     // 2. the whole cloud -> pinned planes -> in_xyz / in_rgb, on the library threads and the frame stream, under the passes
+    //    (tsdf_track_frame_aos: the normals as well -- one block, one copy -- and the pixel records behind them: the frame is
+    //    complete when the passes are over and tsdf_integrate only waits for that packing on the device)
     {
         const tsdf_aos_layout lay = *L;
+        PackArgs pa;
+        if (normals) {
+            rc = wait_buffer_free(h, nb, h->fstream);
+            if (rc) return rc;
+            pa = pack_args(h, h->in_xyz, h->in_nrm, color ? h->in_rgb : nullptr, h->pix_su, h->pix_sv, nb);
+            pa.samples = nullptr;                // uploaded above
+        }
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
         h->queued.err = hipSuccess;
-        h->qjob = [h, npix, points, lay, color] {
-            float* const px = h->pin_xyz; uint8_t* const pc = h->pin_rgb;
-            h->queued.err = stage_and_upload(h, npix, true, false, color, [&](size_t i0, size_t i1) {
-                repack_aos(lay, points, nullptr, color, px, nullptr, pc, i0, i1);
+        h->qjob = [h, npix, points, normals, lay, color, pa] {
+            float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
+            hipError_t e = stage_and_upload(h, npix, true, normals != nullptr, color, [&](size_t i0, size_t i1) {
+                repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
             });
+            if (e == hipSuccess && normals) e = launch_pack(h->fstream, pa);
+            if (e == hipSuccess && normals) e = hipEventRecord(h->ev_frame, h->fstream);
+            h->queued.err = e;
         };
     }
     h->qcv.notify_all();
@@ -2458,8 +2489,11 @@ int tsdf_track_aos(tsdf_handle* h, const void* points, const tsdf_aos_layout* L,
     h->staged_xyz = true;
     h->tracked.valid = true; h->tracked.color = color; h->tracked.points = points; h->tracked.w = width; h->tracked.h = height;
     h->tracked.serial = h->frame_serial; h->tracked.lay = *L;
+    h->tracked.normals = normals;
+    if (normals) { h->frame_has_nrm = true; h->records_pending = true; }       // ... or are on their way already (ev_frame)
     return rc_track;
 }
+}  // namespace
 
 int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height,
                        tsdf_integrate_stats* stats) {
@@ -2481,6 +2515,36 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
             rc = tsdf_set_frame_aos(h, keep ? nullptr : points, normals, L, width, height);
             return rc ? rc : tsdf_integrate(h, stats);
         }
+    }
+    if (h->tracked.valid && h->tracked.normals) {
+        // The frame was tracked WITH its normals (tsdf_track_frame_aos) and is complete on the device.  This call still
+        // integrates the clouds as they are NOW: both are compared with what was staged, every point; what changed (or
+        // another cloud) goes up again.  A caller that vouches for its clouds calls tsdf_integrate instead and skips the
+        // comparison (the shim's three-argument estimate_new_position does).
+        const tsdf_handle::TrackedCloud& t = h->tracked;
+        const bool ident = h->have_frame && h->staged_xyz && t.serial == h->frame_serial && t.w == width && t.h == height && normals == t.normals &&
+                           L->normal_stride == t.lay.normal_stride && L->normal_offset == t.lay.normal_offset &&
+                           (!points || (points == t.points && color == t.color && L->point_stride == t.lay.point_stride && L->xyz_offset == t.lay.xyz_offset &&
+                                        L->r_offset == t.lay.r_offset && L->g_offset == t.lay.g_offset && L->b_offset == t.lay.b_offset));
+        bool same = ident;
+        if (ident) {
+            const size_t npix = (size_t)width * height;
+            const tsdf_aos_layout lay = *L;
+            std::atomic<int> differs{0};
+            const float* const px = h->pin_xyz; const float* const pnm = h->pin_nrm; const uint8_t* const pc = h->pin_rgb;
+            const std::function<void(int, int)> verify = [&](int part, int parts) {
+                const size_t i0 = npix * (size_t)part / (size_t)parts, i1 = npix * (size_t)(part + 1) / (size_t)parts;
+                if ((points && !points_equal_planes(lay, points, color, px, pc, i0, i1)) || !normals_equal_plane(lay, normals, pnm, i0, i1))
+                    differs.store(1, std::memory_order_relaxed);
+            };
+            HostPool* const pool = host_pool(h);
+            if (pool) pool->run(verify); else verify(0, 1);
+            same = differs.load() == 0;
+        }
+        h->tracked.valid = false;
+        if (same) return tsdf_integrate(h, stats);
+        rc = tsdf_set_frame_aos(h, points, normals, L, width, height);        // (points == NULL: the staged xyz / rgb are kept)
+        return rc ? rc : tsdf_integrate(h, stats);
     }
     const tsdf_handle::TrackedCloud& tc = h->tracked;
     // is the frame in the library the cloud estimate_new_position was given?  Identity first (cheap), contents below.
