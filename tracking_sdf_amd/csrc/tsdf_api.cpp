@@ -1599,9 +1599,13 @@ HostPool* host_pool(tsdf_handle* h) {
 // the queue: 8 chunks 2490 frames/s, 4 chunks 3450, 2 chunks 4010, 1 chunk = 3 copies 4140).  Default now: one chunk,
 // and the three planes in one block = ONE copy per frame.  TSDF_STAGE_CHUNKS keeps the pipelined form for large images.
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
-                            const std::function<void(size_t, size_t)>& fill) {
+                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset = 1) {
     constexpr int kMaxChunks = 16;
-    static const int kChunks = [] { const char* e = std::getenv("TSDF_STAGE_CHUNKS"); const int n = e ? std::atoi(e) : 1; return n < 1 ? 1 : n > kMaxChunks ? kMaxChunks : n; }();
+    // TSDF_STAGE_CHUNKS overrides; otherwise the caller's choice: 1 where only throughput counts (the frame queue), 2 where
+    // the frame's LATENCY to the device is on the critical path (tsdf_track_frame_aos: medians 2570 / 2850 / 2790 / 2760
+    // frames/s with 1 / 2 / 3 / 4 pieces, six alternations)
+    static const int kEnvChunks = [] { const char* e = std::getenv("TSDF_STAGE_CHUNKS"); const int n = e ? std::atoi(e) : 0; return n < 0 ? 0 : n > kMaxChunks ? kMaxChunks : n; }();
+    const int kChunks = kEnvChunks > 0 ? kEnvChunks : (chunks_when_unset < 1 ? 1 : chunks_when_unset > kMaxChunks ? kMaxChunks : chunks_when_unset);
     std::atomic<int> done[kMaxChunks];
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     hipError_t err = hipSuccess;
@@ -1610,7 +1614,7 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
     const clk::time_point t_begin = prof ? clk::now() : clk::time_point();
     std::atomic<long long> fill_ns_max{0};
     double upload_ns = 0, first_ns = 0;
-    auto chunk_lo = [npix](int c) { return npix * (size_t)c / (size_t)kChunks; };
+    auto chunk_lo = [npix, kChunks](int c) { return npix * (size_t)c / (size_t)kChunks; };
     auto upload = [&](int c) {
         const size_t i0 = chunk_lo(c), n = chunk_lo(c + 1) - i0;
         if (!n || err != hipSuccess) return;
@@ -2465,7 +2469,7 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
             float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
             hipError_t e = stage_and_upload(h, npix, true, normals != nullptr, color, [&](size_t i0, size_t i1) {
                 repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
-            });
+            }, normals ? 2 : 1);
             if (e == hipSuccess && normals) e = launch_pack(h->fstream, pa);
             if (e == hipSuccess && normals) e = hipEventRecord(h->ev_frame, h->fstream);
             h->queued.err = e;
