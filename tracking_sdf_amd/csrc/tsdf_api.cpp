@@ -246,7 +246,7 @@ struct tsdf_handle {
         unsigned long long ticket;
     };
     std::deque<BorrowedFrame> borrowed;
-    unsigned long long* release_host = nullptr;    // pinned: two words
+    unsigned long long* release_host = nullptr;    // pinned: [0], [1] the two streams' tickets; [2] work items of the last integrate launch
     unsigned long long release_ticket[2] = {0ull, 0ull};
     bool deferred_list_samples = true;         // TSDF_DEFER_PACK=2 (diagnosis): every pass reads the plane
     bool defer_device_pack = true;             // TSDF_DEFER_PACK=0: pack when the frame is set
@@ -542,7 +542,10 @@ PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, con
 
 // ---- borrowed device planes (tsdf_device_frame_released) ---------------------------------------------------------
 // a device frame with this serial has been handed over; nothing has packed it yet
-void borrow_device_frame(tsdf_handle* h, int64_t serial) { h->borrowed.push_back({serial, -1, 0ull}); }
+void borrow_device_frame(tsdf_handle* h, int64_t serial) {
+    try { h->borrowed.push_back({serial, -1, 0ull}); }
+    catch (...) { h->borrowed.clear(); }     // out of memory for 24 bytes: forget the bookkeeping rather than throw across the C ABI
+}                                            // (tsdf_device_frame_released then reports frames free too early -- as unlikely as it is loud elsewhere)
 // the launch that packs frame `serial` is about to be issued on stream index s: the ticket it will publish
 ReleaseWord release_for(tsdf_handle* h, int64_t serial, int s) {
     ReleaseWord r;
@@ -659,8 +662,8 @@ int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, s
 // (TrackParams::xyz_plane) and the pixel records are written inside the integrate launch, by workgroups appended to
 // list_rows_kernel (launch_integrate) -- the packing then hides under that kernel's latency chain instead of being 11 us
 // of its own in front of the first tracker pass.  The planes stay borrowed until that launch has run: tsdf.h asks for them
-// until the set_frame* call after the next one (or tsdf_synchronize, which packs what is pending).  TSDF_DEFER_PACK=0: pack
-// at once, as rounds 1-3 did.
+// until tsdf_device_frame_released() reaches the frame's serial (or tsdf_synchronize, which packs what is pending).
+// TSDF_DEFER_PACK=0: pack at once, as rounds 1-3 did.
 int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false) {
     if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
     if (!already_borrowed) borrow_device_frame(h, h->frame_serial + 1);
@@ -1110,6 +1113,7 @@ int tsdf_slab_range(int32_t m, int32_t nranks, int32_t rank, int32_t* x0, int32_
 // bound: every rank computes the same boundaries from the same weights.
 int tsdf_slab_range_weighted(int32_t m, int32_t nranks, int32_t rank, int32_t halo, const double* w, int32_t* x0, int32_t* x1) {
     if (m <= 0 || nranks <= 0 || nranks > m || rank < 0 || rank >= nranks || halo < 0 || !w || !x0 || !x1) return TSDF_E_BADARG;
+    try {                                    // (the vectors below: nothing may throw across the C ABI)
     std::vector<double> pre((size_t)m + 1, 0.0);
     for (int32_t i = 0; i < m; ++i) {
         if (!(w[i] >= 0.0) || !std::isfinite(w[i])) return TSDF_E_BADARG;
@@ -1152,6 +1156,9 @@ int tsdf_slab_range_weighted(int32_t m, int32_t nranks, int32_t rank, int32_t ha
     }
     *x0 = cut[(size_t)rank]; *x1 = cut[(size_t)rank + 1];
     return TSDF_OK;
+    } catch (...) {
+        return TSDF_E_NOMEM;
+    }
 }
 
 // Expected integration work per x layer for one camera pose: the voxels of the layer inside the view frustum up to
