@@ -246,6 +246,7 @@ struct tsdf_handle {
         unsigned long long ticket;
     };
     std::deque<BorrowedFrame> borrowed;
+    int64_t borrow_lost = -1;                      // >= 0: an entry could not be recorded for this serial (see borrow_device_frame)
     unsigned long long* release_host = nullptr;    // pinned: [0], [1] the two streams' tickets; [2] work items of the last integrate launch
     unsigned long long release_ticket[2] = {0ull, 0ull};
     bool deferred_list_samples = true;         // TSDF_DEFER_PACK=2 (diagnosis): every pass reads the plane
@@ -544,8 +545,8 @@ PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, con
 // a device frame with this serial has been handed over; nothing has packed it yet
 void borrow_device_frame(tsdf_handle* h, int64_t serial) {
     try { h->borrowed.push_back({serial, -1, 0ull}); }
-    catch (...) { h->borrowed.clear(); }     // out of memory for 24 bytes: forget the bookkeeping rather than throw across the C ABI
-}                                            // (tsdf_device_frame_released then reports frames free too early -- as unlikely as it is loud elsewhere)
+    catch (...) { if (h->borrow_lost < 0) h->borrow_lost = serial; }    // out of memory for 24 bytes: nothing may throw across the C ABI;
+}                                                                        // frames from here on are reported borrowed until tsdf_synchronize
 // the launch that packs frame `serial` is about to be issued on stream index s: the ticket it will publish
 ReleaseWord release_for(tsdf_handle* h, int64_t serial, int s) {
     ReleaseWord r;
@@ -569,8 +570,9 @@ int64_t released_serial(tsdf_handle* h) {
         if (b.ticket && __atomic_load_n(h->release_host + b.stream, __ATOMIC_ACQUIRE) < b.ticket) break;
         h->borrowed.pop_front();
     }
-    if (h->borrowed.empty()) return h->frame_serial + ((h->queued.active && h->queued.device) ? 1 : 0);
-    return h->borrowed.front().serial - 1;
+    int64_t rel = h->borrowed.empty() ? h->frame_serial + ((h->queued.active && h->queued.device) ? 1 : 0) : h->borrowed.front().serial - 1;
+    if (h->borrow_lost >= 0 && rel >= h->borrow_lost) rel = h->borrow_lost - 1;
+    return rel;
 }
 
 // st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
@@ -3367,6 +3369,7 @@ int tsdf_synchronize(tsdf_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->borrowed.clear();                     // nothing launched so far reads a borrowed plane any more
+    h->borrow_lost = -1;
     return TSDF_OK;
 }
 
