@@ -12,14 +12,21 @@ LIB     := $(LIBDIR)/libtsdf_hip.so
 HIPEXTRA ?=
 HIPFLAGS := $(HIPEXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter
-SRCS := $(CSRC)/tsdf_kernels.hip $(CSRC)/preproc_kernels.hip $(CSRC)/mesh_kernels.hip $(CSRC)/tsdf_api.cpp $(CSRC)/rccl_dyn.cpp
-HDRS := $(CSRC)/tsdf_device.h $(CSRC)/mc_tables.h $(CSRC)/host_math.hpp $(CSRC)/rccl_dyn.hpp $(ROOT)include/tsdf.h
+SRCS := $(CSRC)/tsdf_kernels.hip $(CSRC)/preproc_kernels.hip $(CSRC)/mesh_kernels.hip $(CSRC)/tsdf_api.cpp $(CSRC)/rccl_dyn.cpp $(CSRC)/aql_queue.cpp
+HDRS := $(CSRC)/tsdf_device.h $(CSRC)/mc_tables.h $(CSRC)/host_math.hpp $(CSRC)/rccl_dyn.hpp $(CSRC)/aql_queue.hpp $(ROOT)include/tsdf.h
+# the hot kernels once more as a stand-alone code object: the library's own AQL queue (csrc/aql_queue.cpp) dispatches
+# track_kernel from it for Gauss-Newton passes >= 1; same source, same flags, next to the library
+HSACO := $(patsubst %/libtsdf_hip.so,%/tsdf_kernels.hsaco,$(patsubst %.so,%.hsaco,$(LIB)))
+ifeq ($(notdir $(LIB)),libtsdf_hip.so)
+HSACO := $(LIBDIR)/tsdf_kernels.hsaco
+endif
 
 all: $(LIB) oracle
 
 $(LIB): $(SRCS) $(HDRS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS) -ldl -pthread
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS) -ldl -pthread -lhsa-runtime64
+	$(HIPCC) $(HIPFLAGS) --genco --no-gpu-bundle-output -o $(HSACO) -x hip $(CSRC)/tsdf_kernels.hip
 
 oracle:
 	$(MAKE) -C $(ROOT)oracle
@@ -31,7 +38,7 @@ asm:
 	    -Rpass-analysis=kernel-resource-usage 2> $(ROOT)build/resource_usage.txt || true
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(HSACO)
 	$(MAKE) -C $(ROOT)oracle clean
 .PHONY: all oracle asm clean
 

@@ -35,6 +35,9 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+
+#include "aql_queue.hpp"
 #include "host_math.hpp"
 #include "rccl_dyn.hpp"
 #include "tsdf_device.h"
@@ -262,7 +265,13 @@ struct tsdf_handle {
     double* red_host = nullptr;    // pinned, kRedWidth doubles + the pass-number word the host polls
     unsigned long long pass_seq = 0;
     bool host_fold = true;         // shared-memory fan-in: the host publishes this rank's row (TSDF_HOST_FOLD=0: the device writes the slot itself)
-    unsigned* fold_ctr = nullptr;  // arrival counters of the in-launch fan-in of track_kernel
+    unsigned* fold_ctr = nullptr;  // arrival counters of the in-launch fan-in of track_kernel: two sets, alternating by pass parity
+    // Gauss-Newton passes >= 1 of a tsdf_track call go through a user-mode queue of the library's own (2.3 us per pass less
+    // than hipLaunchKernel: profiles/r05_aql_probe.json) when the row is handed to this host anyway (single rank / host
+    // fan-in); pass 0 stays on the stream, behind the integration.  TSDF_AQL=0: every pass through the stream.
+    AqlQueue aql;
+    bool aql_on = false;
+    long long aql_passes = 0;
     double* shard_host = nullptr;  // pinned: kTrackShards slots of kShardSlotDoubles (host side of the fan-in)
     bool host_fanin = true;        // the second level of the tracker fan-in runs on the host (TSDF_HOST_FANIN=0: on the device)
     unsigned integrate_launches = 0;
@@ -807,7 +816,7 @@ PeerExchange peer_exchange_for(const tsdf_handle* h, unsigned long long seq) {
 
 // Launch one accumulation pass and wait for its kRedWidth-double result row in h->red_host.
 // reduce_ranks: sum the leading kRedAllreduce entries over ranks (RCCL on the device buffer, or hook).
-int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
+int accumulate_pass(tsdf_handle* h, bool reduce_ranks, bool later_pass = false /* pass >= 1 of a tsdf_track call */) {
     const auto tp0 = h->track_profile ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     TrackParams p;
     fill_track_params(h, p);
@@ -838,9 +847,13 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
     PeerExchange px;
     if (use_peer) px = peer_exchange_for(h, seq);
     const auto tp1 = h->track_profile ? std::chrono::steady_clock::now() : tp0;
-    HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr, h->red_dev,
+    // passes >= 1 whose row comes to this host: through the library's own queue (pass 0 stays on the stream, ordered behind
+    // the integration; a later pass is only submitted after the host has seen the row of the one before it)
+    const bool via_aql = h->aql_on && later_pass && host_fanin && !from_plane;
+    if (via_aql) h->aql_passes++;
+    HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr + (seq & 1ull) * track_fold_counter_words(), h->red_dev,
                                    use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq,
-                                   use_peer ? &px : nullptr, h->track_stamps));
+                                   use_peer ? &px : nullptr, h->track_stamps, via_aql ? &h->aql : nullptr));
     if (from_plane && h->deferred_list_samples) h->deferred.samples_listed = true;
     const auto tp2 = h->track_profile ? std::chrono::steady_clock::now() : tp0;
     if (h->track_profile) {
@@ -882,6 +895,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks) {
         }
         if (!all) {                                            // a shard row did not show up in time: synchronise for real
             HIP_TRY(h, hipStreamSynchronize(h->stream));
+            h->aql.wait_idle();
             for (int sh = 0; sh < ns; ++sh)
                 for (int e = 0; e < kPartWidth; ++e) {
                     const volatile Pair* sp = pairs + (size_t)sh * (kShardSlotDoubles / 2);
@@ -1343,8 +1357,29 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
       } }
     { const char* ev = std::getenv("TSDF_TRACK_PROFILE"); h->track_profile = ev && std::atoi(ev) != 0; }
     { const char* ev = std::getenv("TSDF_STAGE_PROFILE"); h->sp.on = ev && std::atoi(ev) != 0; }
-    CREATE_TRY(hipMalloc((void**)&h->fold_ctr, track_fold_counter_words() * sizeof(unsigned)));
-    CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, track_fold_counter_words() * sizeof(unsigned), h->stream));
+    CREATE_TRY(hipMalloc((void**)&h->fold_ctr, 2 * track_fold_counter_words() * sizeof(unsigned)));
+    CREATE_TRY(hipMemsetAsync(h->fold_ctr, 0, 2 * track_fold_counter_words() * sizeof(unsigned), h->stream));
+    {
+        const char* ev = std::getenv("TSDF_AQL");
+        if (!(ev && std::atoi(ev) == 0) && !h->track_stamps) {
+            // the code object sits next to this library
+            Dl_info info;
+            std::string path;
+            if (dladdr(reinterpret_cast<const void*>(&tsdf_abi_version), &info) && info.dli_fname) {
+                path = info.dli_fname;
+                const size_t slash = path.find_last_of('/');
+                std::string base = slash == std::string::npos ? path : path.substr(slash + 1);
+                const std::string dir = slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+                const size_t dot = base.rfind(".so");
+                base = base == "libtsdf_hip.so" ? std::string("tsdf_kernels.hsaco") : base.substr(0, dot) + ".hsaco";
+                path = dir + "/" + base;
+            }
+            std::string why;
+            h->aql_on = !path.empty() && h->aql.init(h->device, path.c_str(), track_kernel_symbol_prefix(), track_kernel_explicit_arg_bytes(), &why);
+            if (!h->aql_on && ev && std::atoi(ev) == 2)          // TSDF_AQL=2: say why the queue is not in use
+                std::fprintf(stderr, "[tsdf] AQL queue for the tracker passes not in use: %s\n", why.c_str());
+        }
+    }
     CREATE_TRY(hipEventCreate(&h->ev_track.a));
     CREATE_TRY(hipEventCreate(&h->ev_track.b));
     CREATE_TRY(launch_fill(h->stream, g, h->dw, h->crgb, cfg->width + cfg->height + cfg->depth));   // sdf.cpp:29
@@ -1409,6 +1444,7 @@ void tsdf_destroy(tsdf_handle* h) {
     }
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->aql.destroy();                        // (waits for its last packet)
     h->comm.destroy();
     peer_close(h);
     shm_close(h);
@@ -2319,7 +2355,7 @@ int track_loop(tsdf_handle* h, tsdf_track_stats* stats) {
     for (g = 0; g < h->cfg.gn_max_iter && !stop; ++g) {            // camera_tracking.cpp:79
         const auto tq0 = h->track_profile ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         const double waited = h->tp_wait, before = h->tp_fill + h->tp_launch;
-        rc = accumulate_pass(h, true);
+        rc = accumulate_pass(h, true, g > 0);
         if (rc) { h->pose = entry; return rc; }
         n_terms = (int64_t)h->red_host[27];
         if (n_terms == 0) {
@@ -3368,6 +3404,7 @@ int tsdf_synchronize(tsdf_handle* h) {
     }
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->aql.wait_idle();
     h->borrowed.clear();                     // nothing launched so far reads a borrowed plane any more
     h->borrow_lost = -1;
     return TSDF_OK;

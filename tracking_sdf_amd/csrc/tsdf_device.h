@@ -176,10 +176,16 @@ struct PeerExchange {
     unsigned long long word = 0;    // what is released behind a row, and waited for
     long long timeout_ticks = 0;    // wall_clock64() ticks (100 MHz) a rank waits for the others before it gives up
 };
+class AqlQueue;   // aql_queue.hpp
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
                                unsigned long long word, unsigned long long pass, const PeerExchange* peers = nullptr,
-                               unsigned long long* stamps = nullptr /* diagnosis: 8 words per workgroup */);
+                               unsigned long long* stamps = nullptr /* diagnosis: 8 words per workgroup */,
+                               AqlQueue* aql = nullptr /* dispatch through the library's own queue instead of the stream (falls
+                                                          back to the stream when the queue refuses) */);
+// what AqlQueue::init needs to know about track_kernel: the size of its explicit arguments and how its symbol begins
+size_t track_kernel_explicit_arg_bytes();
+const char* track_kernel_symbol_prefix();
 // the same exchange for a row that is already in red_dev (tsdf_allreduce): one wavefront; n_sum leading entries are added
 hipError_t launch_peer_exchange(hipStream_t s, const PeerExchange& px, double* red_dev, int n_sum, double* host_row,
                                 unsigned long long host_word);

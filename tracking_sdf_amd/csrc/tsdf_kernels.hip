@@ -17,6 +17,7 @@
 #include <limits.h>
 #include <math.h>
 
+#include "aql_queue.hpp"
 #include "tsdf_device.h"
 
 namespace tsdf {
@@ -2094,7 +2095,15 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         const int wcls = classify_sample(p, smp, exists, win);
         // first pass over a frame whose packing is deferred: leave the own samples in the list for the passes after it
         // (a plane read is one cold line per lane, 23 KB apart; the list is 16 contiguous bytes per sample)
-        if (p.xyz_plane && p.sample_list_out && exists && lane < kSamplesPerBlock) p.sample_list_out[base + lane] = smp;
+        // (written THROUGH, device scope: the next pass may come off another queue -- AqlQueue -- before this kernel's
+        // end-of-kernel release has happened; this wavefront drains its stores before the workgroup arrives)
+        if (p.xyz_plane && p.sample_list_out && exists && lane < kSamplesPerBlock) {
+            unsigned long long* out = reinterpret_cast<unsigned long long*>(&p.sample_list_out[base + lane]);
+            unsigned long long lo, hi;
+            __builtin_memcpy(&lo, &smp.x, 8); __builtin_memcpy(&hi, &smp.z, 8);
+            __hip_atomic_store(out, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(out + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (lane < kSamplesPerBlock) {
             s_geom[lane][0] = win.px; s_geom[lane][1] = win.py; s_geom[lane][2] = win.pz;
             s_geom[lane][3] = win.vx; s_geom[lane][4] = win.vy; s_geom[lane][5] = win.vz;
@@ -2467,11 +2476,17 @@ hipError_t launch_track_publish(hipStream_t s, const double* red_dev, double* re
 int track_num_blocks(int32_t n_samples) { return (n_samples + kSamplesPerBlock - 1) / kSamplesPerBlock; }
 size_t track_partials_doubles(int32_t n_samples) { return ((size_t)track_num_blocks(n_samples) + kTrackShards) * kPartWidth; }
 
+// track_kernel's explicit arguments as a code object lays them out: by-value structs and pointers in declaration order,
+// each at its natural alignment (AqlQueue::init checks the total against the code object's kernarg segment)
+struct TrackKernarg { TrackParams p; const float2* dw; const float4* samples; double* partials; TrackFold fold; };
+static_assert(sizeof(TrackKernarg) % 8 == 0, "kernel arguments are 8-byte aligned");
+
 // One launch per pass: rows, fan-in and result row inside track_kernel.  ctr: track_fold_counter_words() unsigned, zero
 // before the first pass (the kernel re-zeroes them); shard rows live behind the per-workgroup rows in `partials`.
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
-                               unsigned long long word, unsigned long long pass, const PeerExchange* peers, unsigned long long* stamps) {
+                               unsigned long long word, unsigned long long pass, const PeerExchange* peers, unsigned long long* stamps,
+                               AqlQueue* aql) {
     const int nb = track_num_blocks(p.n_samples);
     if (nb <= 0) return hipErrorInvalidValue;
     if (peers && (peers->n < 0 || peers->n > kPeerMaxRanks || host_shards)) return hipErrorInvalidValue;
@@ -2485,10 +2500,18 @@ hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2
     f.tag = (double)(pass & 0xFFFFFFFFFFFFull);
     if (peers) f.peers = *peers;
     f.stamps = stamps;
+    if (aql) {
+        TrackKernarg ka{p, dw, samples, partials, f};
+        if (aql->submit(&ka, (uint32_t)nb, (uint32_t)kTrackBlock)) return hipSuccess;
+    }
     track_kernel<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, f);
     return hipGetLastError();
 }
+size_t track_kernel_explicit_arg_bytes() { return sizeof(TrackKernarg); }
+const char* track_kernel_symbol_prefix() { return "_ZN4tsdf12track_kernelE"; }
 
+// (two sets, used alternately by pass parity: with passes coming off two queues a set's re-zeroing store is no longer
+// ordered before the NEXT pass's arrivals, only before the one after it)
 size_t track_fold_counter_words() { return 32 * (size_t)(kTrackShards + 1); }
 int track_num_shards(int32_t n_samples) {
     const int nb = track_num_blocks(n_samples);
