@@ -649,15 +649,22 @@ def run(args):
             for mode in list(exchange_us):
                 if setup_exchange(sdf, mode) != KIND[mode]:
                     continue
-                leg.restart()
-                leg.first_frame(d_frames)
-                sdf.synchronize()
-                barrier()
-                t0 = perf()
-                for k in range(1, 1 + trial_n):
-                    leg.step(k, d_frames)
-                sdf.synchronize()
-                exchange_trial[mode] = trial_n / max_over_ranks(perf() - t0)
+                good, t_trial = True, float("inf")
+                try:                    # a step that fails on this node (a rank that does not show up ...) must not take the run down
+                    leg.restart()
+                    leg.first_frame(d_frames)
+                    sdf.synchronize()
+                    barrier()
+                    t0 = perf()
+                    for k in range(1, 1 + trial_n):
+                        leg.step(k, d_frames)
+                    sdf.synchronize()
+                    t_trial = perf() - t0
+                except Exception as e:      # noqa: BLE001
+                    print(f"[bench] rank {rank}: exchange step '{mode}' failed in its trial ({e})", file=sys.stderr)
+                    good = False
+                if all_agree(good):         # every rank takes the same branch
+                    exchange_trial[mode] = trial_n / max_over_ranks(t_trial)
             leg.restart()
             choice = [max(exchange_trial, key=exchange_trial.get) if exchange_trial else (min(exchange_us, key=exchange_us.get) if exchange_us else "torch")]
             dist.broadcast_object_list(choice, 0)           # every rank must take the same decision: rank 0's
