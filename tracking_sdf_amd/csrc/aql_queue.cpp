@@ -59,6 +59,7 @@ bool set_err(std::string* err, const char* what, hsa_status_t s) {
     return false;
 }
 constexpr size_t kHiddenBytes = 256;           // code object v5: the implicit arguments behind the explicit ones
+constexpr hsa_signal_value_t kSignalStart = (hsa_signal_value_t)1 << 40;
 
 }  // namespace
 
@@ -127,8 +128,10 @@ bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_p
         return false;
     }
     std::memset(kernarg_, 0, 2 * kernarg_stride_);
+    // one signal counts DOWN over all packets (every completion subtracts one): the queue is idle when it has come down by
+    // as many as were submitted -- re-arming a signal per packet would race with the completion of the packet before
     hsa_signal_t sig;
-    st = hsa_signal_create(0, 0, nullptr, &sig);
+    st = hsa_signal_create(kSignalStart, 0, nullptr, &sig);
     if (st != HSA_STATUS_SUCCESS) { set_err(err, "hsa_signal_create", st); destroy(); return false; }
     signal_ = sig.handle;
     hsa_queue_t* q = nullptr;
@@ -163,7 +166,6 @@ bool AqlQueue::submit(const void* explicit_args, uint32_t workgroups, uint32_t b
     p->kernarg_address = ka;
     p->reserved2 = 0;
     hsa_signal_t sig; sig.handle = signal_;
-    hsa_signal_store_relaxed(sig, 1);
     p->completion_signal = sig;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
@@ -179,8 +181,9 @@ void AqlQueue::wait_idle() {
     if (!queue_ || !submitted_) return;
     hsa_signal_t sig; sig.handle = signal_;
     // bounded: a pass is tens of microseconds; give up after 2 s rather than hang the caller
+    const hsa_signal_value_t idle = kSignalStart - (hsa_signal_value_t)submitted_;
     for (int i = 0; i < 2000; ++i)
-        if (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, 1000000ull /* ~1 ms in timestamp ticks at 1 GHz; a hint */, HSA_WAIT_STATE_BLOCKED) < 1) return;
+        if (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, idle + 1, 1000000ull /* a hint, in timestamp ticks */, HSA_WAIT_STATE_BLOCKED) <= idle) return;
 }
 
 void AqlQueue::destroy() {
