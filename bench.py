@@ -994,6 +994,7 @@ def run(args):
             # on what is left of the frame after the integrate and pack launches
             "tracker_gather": {"in_grid_samples_per_pass": cn["track_in_grid"] / max(1, cn["track_iterations"]),
                                "passes": cn["track_iterations"],
+                               "passes_through_the_librarys_own_queue": cn.get("track_passes_own_queue"),
                                "avg_pass_wall_ms": max(0.0, 1e3 * elapsed - args.steps * (avg_ms + pack_ms)) / max(1, cn["track_iterations"]),
                                "track_call_wall_ms_incl_wait_for_integrate": 1e3 * track_wall_main / max(1, cn["track_iterations"]),
                                "achieved_GBs_on_832B_per_sample": 832.0 * cn["track_in_grid"]

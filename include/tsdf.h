@@ -413,6 +413,8 @@ typedef struct tsdf_counters {
     int64_t track_in_grid;      /* owned in-grid samples over all passes (each does <= 13 look-ups)    */
     int64_t track_terms;
     int64_t integrate_items;    /* 64-voxel work items the row clip produced (each is one 512-byte {D,W} segment) */
+    int64_t track_passes_own_queue; /* Gauss-Newton passes submitted through the library's own AQL queue (0: tsdf_kernels.hsaco
+                                 * was not found next to the library, TSDF_AQL=0, or no pass >= 1 qualified); ABI 3 */
 } tsdf_counters;
 int tsdf_set_timing(tsdf_handle *h, int32_t on);
 int tsdf_read_timing(tsdf_handle *h, tsdf_timing *out, int32_t reset);

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     assert ts.Config.origin.offset == 16 and ts.Config.delta.offset == 40 and ts.Config.carry_threads.offset == 72
     assert ts.Config.device.offset == 92
     assert C.sizeof(ts.IntegrateStats) == 24 and C.sizeof(ts.AccumStats) == 48
-    assert C.sizeof(ts.TrackStats) == 64 and C.sizeof(ts.Timing) == 48 and C.sizeof(ts.Counters) == 72
+    assert C.sizeof(ts.TrackStats) == 64 and C.sizeof(ts.Timing) == 48 and C.sizeof(ts.Counters) == 80   # ABI 3: + track_passes_own_queue
 
 
 def test_default_config_is_the_reference_constants():

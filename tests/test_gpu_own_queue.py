@@ -1,0 +1,87 @@
+"""Gauss-Newton passes >= 1 through the library's own AQL queue (csrc/aql_queue.cpp).
+
+The queue is a submission path, not an algorithm: with it (default on a GPU box: tsdf_kernels.hsaco lies next to the
+library) and without it (TSDF_AQL=0, read by tsdf_create) every pose, every voxel and every pass count must be the same
+bits.  The first test also fails when the queue is silently NOT in use on a box where it should be."""
+import numpy as np
+import pytest
+
+from tracking_sdf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, M, N = 160, 120, 48, 8
+
+
+def run(monkeypatch, aql, device_frames):
+    import torch
+    import tracking_sdf_amd as ts
+    if aql is None:
+        monkeypatch.delenv("TSDF_AQL", raising=False)
+    else:
+        monkeypatch.setenv("TSDF_AQL", aql)
+    seq = synth.Sequence(n_frames=N, width=W, height=H, noise=True, holes=0.02, step=4)
+    s = ts.SDF(M, with_color=True)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    poses, iters, keep = [], [], []
+    for k in range(N):
+        if device_frames:
+            fr = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in seq.frame(k)]
+            torch.cuda.synchronize()
+            keep.append(fr)
+            s.set_frame_device(fr[0].data_ptr(), fr[1].data_ptr(), fr[2].data_ptr(), W, H, keep=fr)
+        else:
+            s.set_frame(*seq.frame(k))
+        if k > 0:
+            st = t.estimate_new_position()
+            iters.append(st["iterations"] if isinstance(st, dict) else None)
+        s.update()
+        poses.append((t.rot.copy(), t.trans.copy()))
+    cn = s.read_counters()
+    D, Wt = s.download()
+    col = s.download_color()
+    s.close()
+    return poses, iters, cn, D, Wt, col
+
+
+@pytest.mark.parametrize("device_frames", [False, True])
+def test_passes_through_the_own_queue_give_the_same_bits_as_through_the_stream(monkeypatch, device_frames):
+    on = run(monkeypatch, None, device_frames)
+    off = run(monkeypatch, "0", device_frames)
+    # the queue really carried the later passes (every pass but the first of each tracked frame) -- and none with TSDF_AQL=0
+    assert off[2]["track_passes_own_queue"] == 0
+    later = on[2]["track_iterations"] - on[2]["track_calls"]
+    assert later > 0 and on[2]["track_passes_own_queue"] == later, on[2]
+    assert on[1] == off[1]
+    for (r0, t0), (r1, t1) in zip(on[0], off[0]):
+        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+    assert np.array_equal(on[3], off[3]) and np.array_equal(on[4], off[4])
+    for a, b in zip(on[5], off[5]):
+        assert np.array_equal(a, b)
+    for k in ("n_updated", "track_iterations", "track_terms", "track_in_grid", "integrate_items"):
+        assert on[2][k] == off[2][k], k
+
+
+def test_two_handles_keep_their_own_queues_apart(monkeypatch):
+    """two trackers alternating frame by frame (two AQL queues, two kernarg rings, one device): each equals a run alone"""
+    import tracking_sdf_amd as ts
+    monkeypatch.delenv("TSDF_AQL", raising=False)
+    alone = run(monkeypatch, None, False)
+    seqs = [synth.Sequence(n_frames=N, width=W, height=H, noise=True, holes=0.02, step=4) for _ in range(2)]
+    ss = [ts.SDF(M, with_color=True) for _ in range(2)]
+    tt = [ts.CameraTracking(sdf=s) for s in ss]
+    for t, q in zip(tt, seqs):
+        t.set_K(q.K)
+    for k in range(N):
+        for s, t, q in zip(ss, tt, seqs):
+            s.set_frame(*q.frame(k))
+            if k > 0:
+                t.estimate_new_position()
+            s.update()
+    for s, t in zip(ss, tt):
+        assert np.array_equal(t.rot, alone[0][-1][0]) and np.array_equal(t.trans, alone[0][-1][1])
+        D, Wt = s.download()
+        assert np.array_equal(D, alone[3]) and np.array_equal(Wt, alone[4])
+        assert s.read_counters()["track_passes_own_queue"] > 0
+        s.close()

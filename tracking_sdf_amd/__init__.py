@@ -87,7 +87,8 @@ class Timing(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("n_updated", C.c_int64), ("n_updated_halo", C.c_int64), ("n_voxels_swept", C.c_int64),
                 ("integrate_calls", C.c_int64), ("track_calls", C.c_int64), ("track_iterations", C.c_int64),
-                ("track_in_grid", C.c_int64), ("track_terms", C.c_int64), ("integrate_items", C.c_int64)]
+                ("track_in_grid", C.c_int64), ("track_terms", C.c_int64), ("integrate_items", C.c_int64),
+                ("track_passes_own_queue", C.c_int64)]
 
 
 def _struct_dict(s):

@@ -850,7 +850,7 @@ int accumulate_pass(tsdf_handle* h, bool reduce_ranks, bool later_pass = false /
     // passes >= 1 whose row comes to this host: through the library's own queue (pass 0 stays on the stream, ordered behind
     // the integration; a later pass is only submitted after the host has seen the row of the one before it)
     const bool via_aql = h->aql_on && later_pass && host_fanin && !from_plane;
-    if (via_aql) h->aql_passes++;
+    if (via_aql) { h->aql_passes++; h->cnt.track_passes_own_queue++; }
     HIP_TRY(h, launch_track_folded(h->stream, p, h->dw, h->samples, h->partials, h->fold_ctr + (seq & 1ull) * track_fold_counter_words(), h->red_dev,
                                    use_rccl ? nullptr : host_row, host_fanin ? h->shard_host : nullptr, dev_word, seq,
                                    use_peer ? &px : nullptr, h->track_stamps, via_aql ? &h->aql : nullptr));
