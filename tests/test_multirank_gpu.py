@@ -99,7 +99,9 @@ def test_gpus_flag_starts_that_many_ranks_itself(tmp_path):
     assert len(lines) == 1, "exactly one JSON line on stdout"
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["parallelism"].startswith("x-slab x2") and j["config"]["halo"] > 0
-    assert "shared-memory" in j["config"]["allreduce"] and "shm" in j["config"]["exchange_step_us_measured"]
+    # (the default --allreduce auto picks the in-library exchange that wins a short trial on this box: either may)
+    kind = j["config"]["allreduce"]
+    assert ("shared-memory" in kind or "peer exchange" in kind) and "shm" in j["config"]["exchange_step_us_measured"]
     j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
     assert np.array_equal(np.loadtxt(traj), t1)
 

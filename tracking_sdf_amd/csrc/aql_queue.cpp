@@ -6,8 +6,12 @@
 #include <hsa/hsa_ext_amd.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace tsdf {
 namespace {
@@ -138,6 +142,7 @@ bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_p
     st = hsa_queue_create(ap.gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q);
     if (st != HSA_STATUS_SUCCESS) { set_err(err, "hsa_queue_create", st); destroy(); return false; }
     queue_ = q;
+    { const char* ev = std::getenv("TSDF_AQL_READBACK"); readback_ = !(ev && std::atoi(ev) == 0); }   // 0: measurement only
     return true;
 }
 
@@ -156,6 +161,19 @@ bool AqlQueue::submit(const void* explicit_args, uint32_t workgroups, uint32_t b
     std::memcpy(hid + 12, sizes, sizeof sizes);
     const uint16_t dims = 1;
     std::memcpy(hid + 64, &dims, sizeof dims);
+    // The arguments must BE in device memory before the doorbell is rung: the stores above go through write-combining
+    // buffers and the PCIe BAR, the doorbell takes another path inside the GPU.  As the HIP runtime does for its own
+    // device-resident kernel arguments: drain the buffers, then read one byte back -- a PCIe read does not pass the posted
+    // writes in front of it, so when it returns they have been performed (~0.9 us of host time per submission).
+#if defined(__SSE2__)
+    _mm_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+    if (readback_) {
+        const volatile unsigned char* last = reinterpret_cast<const volatile unsigned char*>(hid + 65);
+        readback_sink_ += *last;
+    }
     hsa_kernel_dispatch_packet_t* p = static_cast<hsa_kernel_dispatch_packet_t*>(q->base_address) + (idx & (q->size - 1));
     p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     p->workgroup_size_x = (uint16_t)block; p->workgroup_size_y = 1; p->workgroup_size_z = 1;

@@ -39,6 +39,8 @@ private:
     uint64_t signal_ = 0;              // hsa_signal_t handle: completion of the last packet
     uint64_t executable_ = 0, reader_ = 0;
     bool hsa_up_ = false;
+    bool readback_ = true;             // read a byte of the arguments back before the doorbell (TSDF_AQL_READBACK=0: not)
+    unsigned readback_sink_ = 0;
 };
 
 }  // namespace tsdf
