@@ -2,7 +2,8 @@
 //
 // A pass is one launch whose result the host waits for before it can launch the next one; hipLaunchKernel spends 2.5-2.8 us
 // of host time per launch on that critical path, a hand-written AQL dispatch 0.2 (tools/aql_probe.hip, profiles/
-// r05_aql_probe.json: 14.7 -> 12.3 us from submission to the host seeing the result).  The kernel is the SAME device code:
+// r05_aql_probe.json: 14.7 -> 12.3 us from submission to the host seeing the result; submit() adds the 0.9 us read-back of the
+// arguments that makes the doorbell safe: r05_aql_readback.json).  The kernel is the SAME device code:
 // the build also emits tsdf_kernels.hip as a stand-alone code object (lib/tsdf_kernels.hsaco), loaded here through HSA.
 // Anything that goes wrong while setting this up (no code object, symbol, queue ...) just leaves the HIP launch in place.
 #pragma once
