@@ -200,8 +200,8 @@ void AqlQueue::wait_idle() {
     hsa_signal_t sig; sig.handle = signal_;
     // bounded: a pass is tens of microseconds; give up after 2 s rather than hang the caller
     const hsa_signal_value_t idle = kSignalStart - (hsa_signal_value_t)submitted_;
-    for (int i = 0; i < 2000; ++i)
-        if (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, idle + 1, 1000000ull /* a hint, in timestamp ticks */, HSA_WAIT_STATE_BLOCKED) <= idle) return;
+    for (int i = 0; i < 200; ++i)          // 200 x 10 ms (the hint is in 100 MHz timestamp ticks)
+        if (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, idle + 1, 1000000ull, HSA_WAIT_STATE_BLOCKED) <= idle) return;
 }
 
 void AqlQueue::destroy() {
