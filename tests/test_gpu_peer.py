@@ -76,7 +76,7 @@ def test_a_rank_whose_peers_never_arrive_gives_up(tmp_path):
     outs = run_ranks(2, "absent", tmp_path)
     r0 = outs[0]
     assert r0["error"] and "peer exchange" in r0["error"], r0
-    assert 4.0 < r0["seconds"] < 7.5            # the kernel's own 5 s limit, not a hung GPU
+    assert 4.0 < r0["seconds"] < 15.0           # the kernel's own 5 s limit, not a hung GPU (slack: a busy box)
 
 
 def test_more_than_64_ranks_are_refused():
