@@ -64,6 +64,9 @@ bool set_err(std::string* err, const char* what, hsa_status_t s) {
 }
 constexpr size_t kHiddenBytes = 256;           // code object v5: the implicit arguments behind the explicit ones
 constexpr hsa_signal_value_t kSignalStart = (hsa_signal_value_t)1 << 40;
+// Argument buffers, used round robin: a buffer comes round again after 16 passes (four frames, > 1 GB of traffic through
+// the L2s), not after two -- nothing relies on a line of an old pass having left a cache, this only makes it remote.
+constexpr size_t kKernargRing = 16;
 
 }  // namespace
 
@@ -125,13 +128,13 @@ bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_p
     PoolPick pp{};
     hsa_amd_agent_iterate_memory_pools(ap.gpu, pick_pool, &pp);
     kernarg_stride_ = ((size_t)kernarg_bytes_ + 4095) & ~(size_t)4095;
-    if (!pp.have || hsa_amd_memory_pool_allocate(pp.pool, 2 * kernarg_stride_, 0, (void**)&kernarg_) != HSA_STATUS_SUCCESS ||
+    if (!pp.have || hsa_amd_memory_pool_allocate(pp.pool, kKernargRing * kernarg_stride_, 0, (void**)&kernarg_) != HSA_STATUS_SUCCESS ||
         hsa_amd_agents_allow_access(1, &ap.cpu, nullptr, kernarg_) != HSA_STATUS_SUCCESS) {
         if (err) *err = "no host-writable device memory for the kernel arguments";
         destroy();
         return false;
     }
-    std::memset(kernarg_, 0, 2 * kernarg_stride_);
+    std::memset(kernarg_, 0, kKernargRing * kernarg_stride_);
     // one signal counts DOWN over all packets (every completion subtracts one): the queue is idle when it has come down by
     // as many as were submitted -- re-arming a signal per packet would race with the completion of the packet before
     hsa_signal_t sig;
@@ -151,7 +154,7 @@ bool AqlQueue::submit(const void* explicit_args, uint32_t workgroups, uint32_t b
     if (!q) return false;
     const uint64_t idx = hsa_queue_load_write_index_relaxed(q);
     if (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) return false;       // ring full
-    char* ka = kernarg_ + (size_t)(submitted_ & 1ull) * kernarg_stride_;
+    char* ka = kernarg_ + (size_t)(submitted_ % kKernargRing) * kernarg_stride_;
     std::memcpy(ka, explicit_args, explicit_bytes_);
     // code object v5 hidden arguments (tsdf_kernels.hip uses gridDim.x; blockDim is a compile-time constant there)
     char* hid = ka + ((explicit_bytes_ + 7) & ~(size_t)7);

@@ -34,7 +34,7 @@ private:
     uint64_t kernel_object_ = 0;
     uint32_t group_bytes_ = 0, private_bytes_ = 0, kernarg_bytes_ = 0;
     size_t explicit_bytes_ = 0;
-    char* kernarg_ = nullptr;          // two buffers in device memory the host writes through the BAR, used alternately
+    char* kernarg_ = nullptr;          // a ring of buffers in device memory the host writes through the BAR
     size_t kernarg_stride_ = 0;
     uint64_t submitted_ = 0;
     uint64_t signal_ = 0;              // hsa_signal_t handle: completion of the last packet
