@@ -16,15 +16,17 @@
 namespace tsdf {
 namespace {
 
-struct AgentPick { uint32_t want_bdf; bool any; hsa_agent_t gpu; bool have_gpu; hsa_agent_t cpu; bool have_cpu; };
+struct AgentPick { uint32_t want_bdf, want_domain; bool any; hsa_agent_t gpu; bool have_gpu; hsa_agent_t cpu; bool have_cpu; };
 hsa_status_t pick_agent(hsa_agent_t a, void* data) {
     AgentPick* p = static_cast<AgentPick*>(data);
     hsa_device_type_t t;
     if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
     if (t == HSA_DEVICE_TYPE_CPU && !p->have_cpu) { p->cpu = a; p->have_cpu = true; }
     if (t == HSA_DEVICE_TYPE_GPU && !p->have_gpu) {
-        uint32_t bdf = 0;
-        if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS && (p->any || bdf == p->want_bdf)) {
+        uint32_t bdf = 0, domain = 0;
+        const bool have_domain = hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain) == HSA_STATUS_SUCCESS;
+        if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS &&
+            (p->any || (bdf == p->want_bdf && (!have_domain || domain == p->want_domain)))) {     // (8-GPU nodes repeat bus numbers across PCI domains)
             p->gpu = a; p->have_gpu = true;
         }
     }
@@ -82,7 +84,9 @@ bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_p
         unsigned dom = 0, b = 0, d = 0, f = 0;
         ap.any = hipDeviceGetPCIBusId(bus, sizeof bus, hip_device) != hipSuccess || std::sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) < 3;
         ap.want_bdf = (b << 8) | (d << 3) | f;
+        ap.want_domain = dom;
     }
+    if (ap.any) { if (err) *err = "the HIP device has no PCI address to find its HSA agent by"; destroy(); return false; }
     st = hsa_iterate_agents(pick_agent, &ap);
     if (st != HSA_STATUS_SUCCESS || !ap.have_gpu || !ap.have_cpu) { if (err) *err = "no HSA agent for this HIP device"; destroy(); return false; }
     // the code object
