@@ -12,21 +12,31 @@ LIB     := $(LIBDIR)/libtsdf_hip.so
 HIPEXTRA ?=
 HIPFLAGS := $(HIPEXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter
-SRCS := $(CSRC)/tsdf_kernels.hip $(CSRC)/preproc_kernels.hip $(CSRC)/mesh_kernels.hip $(CSRC)/tsdf_api.cpp $(CSRC)/rccl_dyn.cpp $(CSRC)/aql_queue.cpp
-HDRS := $(CSRC)/tsdf_device.h $(CSRC)/mc_tables.h $(CSRC)/host_math.hpp $(CSRC)/rccl_dyn.hpp $(CSRC)/aql_queue.hpp $(ROOT)include/tsdf.h
-# the hot kernels once more as a stand-alone code object: the library's own AQL queue (csrc/aql_queue.cpp) dispatches
-# track_kernel from it for Gauss-Newton passes >= 1; same source, same flags, next to the library
-HSACO := $(patsubst %/libtsdf_hip.so,%/tsdf_kernels.hsaco,$(patsubst %.so,%.hsaco,$(LIB)))
-ifeq ($(notdir $(LIB)),libtsdf_hip.so)
-HSACO := $(LIBDIR)/tsdf_kernels.hsaco
-endif
+KERNELS := $(CSRC)/integrate_kernels.hip $(CSRC)/track_kernels.hip $(CSRC)/volume_kernels.hip $(CSRC)/preproc_kernels.hip $(CSRC)/mesh_kernels.hip
+HOSTSRC := $(CSRC)/api_core.cpp $(CSRC)/api_frames.cpp $(CSRC)/api_hotpath.cpp $(CSRC)/api_comm.cpp $(CSRC)/api_volume.cpp \
+           $(CSRC)/host_util.cpp $(CSRC)/rccl_dyn.cpp $(CSRC)/aql_queue.cpp
+SRCS := $(KERNELS) $(HOSTSRC)
+HDRS := $(CSRC)/handle.hpp $(CSRC)/host_util.hpp $(CSRC)/tsdf_device.h $(CSRC)/device_util.h $(CSRC)/mc_tables.h $(CSRC)/host_math.hpp $(CSRC)/rccl_dyn.hpp $(CSRC)/aql_queue.hpp $(ROOT)include/tsdf.h
+# The tracker kernels once more as a stand-alone code object: the library's own AQL queue (csrc/aql_queue.cpp, opt-in with
+# TSDF_AQL=1) dispatches track_kernel from it for Gauss-Newton passes >= 1.  Same source, same flags, next to the library.
+# Both artefacts carry TSDF_BUILD_ID (a hash of the tracker's sources and the flags): AqlQueue::init refuses a code object
+# whose id is not the library's, so a stale or foreign .hsaco next to the .so can never run in place of the library's kernel.
+TRACK_DEPS := $(CSRC)/track_kernels.hip $(CSRC)/tsdf_device.h $(CSRC)/device_util.h $(CSRC)/aql_queue.hpp
+HSACO := $(LIBDIR)/$(patsubst lib%_hip.so,%,$(notdir $(LIB)))_track.hsaco
+BUILD_ID := $(shell (cat $(TRACK_DEPS); echo '$(HIPFLAGS)') | sha256sum | cut -c1-32)
+IDFLAG := -DTSDF_BUILD_ID='"$(BUILD_ID)"'
 
-all: $(LIB) oracle
+.DELETE_ON_ERROR:
+all: lib oracle
+lib: $(LIB) $(HSACO)
 
 $(LIB): $(SRCS) $(HDRS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS) -ldl -pthread -lhsa-runtime64
-	$(HIPCC) $(HIPFLAGS) --genco --no-gpu-bundle-output -o $(HSACO) -x hip $(CSRC)/tsdf_kernels.hip
+	$(HIPCC) $(HIPFLAGS) $(IDFLAG) -shared -o $@ -x hip $(SRCS) -ldl -pthread -lhsa-runtime64
+
+$(HSACO): $(TRACK_DEPS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(IDFLAG) --genco --no-gpu-bundle-output -o $@ -x hip $(CSRC)/track_kernels.hip
 
 oracle:
 	$(MAKE) -C $(ROOT)oracle
@@ -34,13 +44,13 @@ oracle:
 # kernel resource usage + ISA for inspection
 asm:
 	@mkdir -p $(ROOT)build
-	$(HIPCC) $(HIPFLAGS) -x hip -c $(CSRC)/tsdf_kernels.hip --cuda-device-only -S -o $(ROOT)build/tsdf_kernels.s \
-	    -Rpass-analysis=kernel-resource-usage 2> $(ROOT)build/resource_usage.txt || true
+	for k in integrate_kernels track_kernels; do $(HIPCC) $(HIPFLAGS) -x hip -c $(CSRC)/$$k.hip --cuda-device-only -S -o $(ROOT)build/$$k.s \
+	    -Rpass-analysis=kernel-resource-usage 2> $(ROOT)build/$$k.resource_usage.txt || true; done
 
 clean:
 	rm -f $(LIB) $(HSACO)
 	$(MAKE) -C $(ROOT)oracle clean
-.PHONY: all oracle asm clean
+.PHONY: all lib oracle asm clean
 
 # C++ example of the drop-in shim (include/sdf_3d_reconstruction/hotpath.hpp): plain g++, links the C ABI only
 shim_demo: $(LIB)

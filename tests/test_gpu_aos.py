@@ -185,7 +185,7 @@ def test_staging_threads_chunks_and_sets_do_not_change_the_result():
             "D, W = s.download(); print(float(D.sum()), float(W.sum()), int((W > 0).sum()), t.trans.tolist())\n")
     outs = []
     for knobs in ({"TSDF_HOST_THREADS": "1"}, {"TSDF_HOST_THREADS": "3"}, {"TSDF_HOST_THREADS": "7", "TSDF_STAGE_CHUNKS": "4"},
-                  {"TSDF_STAGE_CHUNKS": "3", "TSDF_STAGE_SETS": "1"}, {"TSDF_SAMPLES_FIRST": "0"}, {"TSDF_SAMPLES_FIRST": "0", "TSDF_HOST_THREADS": "2"}):
+                  {"TSDF_STAGE_CHUNKS": "3"}, {"TSDF_SAMPLES_FIRST": "0"}, {"TSDF_SAMPLES_FIRST": "0", "TSDF_HOST_THREADS": "2"}):
         env = dict(os.environ, **knobs)
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                                    cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip())

@@ -1,8 +1,8 @@
-"""Gauss-Newton passes >= 1 through the library's own AQL queue (csrc/aql_queue.cpp).
+"""Gauss-Newton passes >= 1 through the library's own AQL queue (csrc/aql_queue.cpp).  Opt-in since round 6.
 
-The queue is a submission path, not an algorithm: with it (default on a GPU box: tsdf_kernels.hsaco lies next to the
-library) and without it (TSDF_AQL=0, read by tsdf_create) every pose, every voxel and every pass count must be the same
-bits.  The first test also fails when the queue is silently NOT in use on a box where it should be."""
+The queue is a submission path, not an algorithm: with it (TSDF_AQL=1, read by tsdf_create; lib/tsdf_track.hsaco lies next
+to the library and carries the library's build id) and without it (the default) every pose, every voxel and every pass
+count must be the same bits.  The first test also fails when the queue is silently NOT in use although it was asked for."""
 import numpy as np
 import pytest
 
@@ -47,9 +47,9 @@ def run(monkeypatch, aql, device_frames):
 
 @pytest.mark.parametrize("device_frames", [False, True])
 def test_passes_through_the_own_queue_give_the_same_bits_as_through_the_stream(monkeypatch, device_frames):
-    on = run(monkeypatch, None, device_frames)
-    off = run(monkeypatch, "0", device_frames)
-    # the queue really carried the later passes (every pass but the first of each tracked frame) -- and none with TSDF_AQL=0
+    on = run(monkeypatch, "1", device_frames)
+    off = run(monkeypatch, None, device_frames)
+    # the queue really carried the later passes (every pass but the first of each tracked frame) -- and none by default
     assert off[2]["track_passes_own_queue"] == 0
     later = on[2]["track_iterations"] - on[2]["track_calls"]
     assert later > 0 and on[2]["track_passes_own_queue"] == later, on[2]
@@ -66,8 +66,7 @@ def test_passes_through_the_own_queue_give_the_same_bits_as_through_the_stream(m
 def test_two_handles_keep_their_own_queues_apart(monkeypatch):
     """two trackers alternating frame by frame (two AQL queues, two kernarg rings, one device): each equals a run alone"""
     import tracking_sdf_amd as ts
-    monkeypatch.delenv("TSDF_AQL", raising=False)
-    alone = run(monkeypatch, None, False)
+    alone = run(monkeypatch, "1", False)
     seqs = [synth.Sequence(n_frames=N, width=W, height=H, noise=True, holes=0.02, step=4) for _ in range(2)]
     ss = [ts.SDF(M, with_color=True) for _ in range(2)]
     tt = [ts.CameraTracking(sdf=s) for s in ss]

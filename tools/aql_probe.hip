@@ -16,7 +16,7 @@
 
 // the kernel: no blockDim / gridDim (code-object-v5 kernels read those from hidden arguments the probe does not fill)
 struct ProbeArgs { unsigned* counter; unsigned long long* host_word; unsigned long long seq; unsigned n_wg; unsigned pad; };
-extern "C" __global__ __launch_bounds__(384) void probe_kernel(ProbeArgs a) {
+extern "C" __global__ __launch_bounds__(1024) void probe_kernel(ProbeArgs a) {
     __shared__ int last;
     // a little of what a tracker workgroup does before it arrives: a dependent load and a barrier
     if (threadIdx.x == 0) {
@@ -74,7 +74,11 @@ static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); ret
 int main(int argc, char** argv) {
     const char* hsaco = argc > 1 ? argv[1] : "build/aql_probe_kernel.hsaco";
     const int n = argc > 2 ? std::atoi(argv[2]) : 20000;
-    const unsigned n_wg = 714, block = 384;
+    // round 6: the shape and where the word goes are arguments (tools/aql_probe_sweep.sh): what part of the 12.3 us floor of a
+    // pass-shaped launch is the grid (workgroups x threads), what part the command processor, what part the PCIe store?
+    const unsigned n_wg = argc > 3 ? (unsigned)std::atoi(argv[3]) : 714u, block = argc > 4 ? (unsigned)std::atoi(argv[4]) : 384u;
+    const bool word_in_bar = argc > 5 && std::strcmp(argv[5], "bar") == 0;   // the word in DEVICE memory, the host polls it through the BAR
+    const bool aql_only = word_in_bar;
     HIP_OK(hipSetDevice(0));
     hipStream_t stream;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -95,7 +99,7 @@ int main(int argc, char** argv) {
 
     // ---- hip: <<<>>> on a stream
     std::vector<double> hip_call, hip_trip;
-    for (int i = 0; i < n + 200; ++i) {
+    for (int i = 0; i < n + 200 && !aql_only; ++i) {
         ProbeArgs a{counter, word, ++seq, n_wg, 0};
         const auto t0 = clk::now();
         probe_kernel<<<dim3(n_wg), dim3(block), 0, stream>>>(a);
@@ -143,6 +147,7 @@ int main(int argc, char** argv) {
     HSA_OK(hsa_amd_memory_pool_allocate(g_dev_pool, 8192, 0, (void**)&karg));
     HSA_OK(hsa_amd_agents_allow_access(1, &g_cpu, nullptr, karg));
     std::memset(karg, 0, 8192);
+    if (word_in_bar) { word = reinterpret_cast<unsigned long long*>(karg + 2048); *word = 0; }
     const uint32_t mask = q->size - 1;
     hsa_kernel_dispatch_packet_t* ring = static_cast<hsa_kernel_dispatch_packet_t*>(q->base_address);
     std::vector<double> aql_call, aql_trip;
@@ -172,10 +177,12 @@ int main(int argc, char** argv) {
         if (i >= 200) { aql_call.push_back(us(t0, t1)); aql_trip.push_back(us(t0, t2)); }
     }
     // ---- alternating, the way the library would mix them: pass 0 on the HIP stream, passes 1.. on the queue
-    std::printf("{\"submissions\": %d, \"shape\": \"714 x 384 threads, last workgroup stores a word into pinned host memory\", "
+    if (hip_call.empty()) { hip_call.push_back(0.0); hip_trip.push_back(0.0); }
+    std::printf("{\"submissions\": %d, \"workgroups\": %u, \"threads_per_workgroup\": %u, \"word\": \"%s\", "
                 "\"hip_launch\": {\"call_us_median\": %.2f, \"round_trip_us_median\": %.2f}, "
                 "\"aql_own_queue\": {\"submit_us_median\": %.2f, \"round_trip_us_median\": %.2f}, \"kernarg_segment_bytes\": %u}\n",
-                n, median(hip_call), median(hip_trip), median(aql_call), median(aql_trip), kernarg_size);
+                n, n_wg, block, word_in_bar ? "device memory, host polls through the BAR" : "pinned host memory",
+                median(hip_call), median(hip_trip), median(aql_call), median(aql_trip), kernarg_size);
     hsa_queue_destroy(q);
     return 0;
 }

@@ -9,7 +9,7 @@ for spec in "$@"; do
     name="${spec%%=*}"; flags="${spec#*=}"
     out="$ROOT/build/variants/libtsdf_hip_${name}.so"
     echo "building $name: $flags"
-    make -s -C "$ROOT" LIB="$out" LIBDIR="$ROOT/build/variants" HIPEXTRA="$flags" "$out" &
+    make -s -C "$ROOT" LIB="$out" LIBDIR="$ROOT/build/variants" HIPEXTRA="$flags" lib &
 done
 wait
 ls -la "$ROOT/build/variants"

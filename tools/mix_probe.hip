@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
         if (MODE != 2 && PIPE != 3) {
             u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
             if (live) { d = dw[(size_t)seg * 64 + lane]; c = __builtin_nontemporal_load(&col[(size_t)seg * 64 + lane]); }
-            d.x += acc; c.y ^= d.y;
+            d.x += acc; d.y += acc ^ 1u; c.x += d.x; c.y ^= d.y; c.z += acc; c.w ^= acc + 3u;   /* every component changes: round 4's form let hipcc drop the unchanged ones from loads and stores */
             // MODE 4 (no gathers): the stores go to ANOTHER random segment (copy-like)
             const unsigned wseg = MODE == 4 ? __builtin_amdgcn_readfirstlane((seg * 2654435761u) % nseg) : seg;
             if (MODE != 3 && live) { dw[(size_t)wseg * 64 + lane] = d; __builtin_nontemporal_store(c, &col[(size_t)wseg * 64 + lane]); }
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void mix(const u4* __restrict__ rec, unsigned 
             if (it + 1 < items_per_wave && nlive) { nd = dw[(size_t)seg_next * 64 + lane]; nc = __builtin_nontemporal_load(&col[(size_t)seg_next * 64 + lane]); }
             const bool plive = pfirst != 99u && lane >= pfirst && lane < pfirst + 34u;
             u2 d = pd; u4 c = pc;
-            d.x += acc; c.y ^= d.y;
+            d.x += acc; d.y += acc ^ 1u; c.x += d.x; c.y ^= d.y; c.z += acc; c.w ^= acc + 3u;   /* every component changes: round 4's form let hipcc drop the unchanged ones from loads and stores */
             if (MODE != 3 && plive) { dw[(size_t)pseg * 64 + lane] = d; __builtin_nontemporal_store(c, &col[(size_t)pseg * 64 + lane]); }
             if (MODE == 3) acc ^= d.x + c.y;
             pd = nd; pc = nc; pseg = seg_next; pfirst = it + 1 < items_per_wave ? nfirst : 99u;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void mix2(const u4* __restrict__ rec, unsigned
             }
             u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
             if (live) { d = dw[vox]; c = __builtin_nontemporal_load(&col[vox]); }
-            d.x += acc; c.y ^= d.y;
+            d.x += acc; d.y += acc ^ 1u; c.x += d.x; c.y ^= d.y; c.z += acc; c.w ^= acc + 3u;   /* every component changes: round 4's form let hipcc drop the unchanged ones from loads and stores */
             if (MODE != 3 && live) { dw[vox] = d; __builtin_nontemporal_store(c, &col[vox]); }
             if (MODE == 3) acc ^= d.x + c.y;
         }
@@ -187,14 +187,110 @@ __global__ __launch_bounds__(256) void mix3(const u4* __restrict__ rec, unsigned
             const size_t vox = (size_t)row * 512u + k;
             u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
             if (live) { d = dw[vox]; c = __builtin_nontemporal_load(&col[vox]); }
-            d.x += acc; c.y ^= d.y;
+            d.x += acc; d.y += acc ^ 1u; c.x += d.x; c.y ^= d.y; c.z += acc; c.w ^= acc + 3u;   /* every component changes: round 4's form let hipcc drop the unchanged ones from loads and stores */
             if (live) { dw[vox] = d; __builtin_nontemporal_store(c, &col[vox]); }
         }
     }
     if (acc == 0x12345678u) out[wave] = acc;
 }
 
-int main(int argc, char**) {
+
+// SPAN pattern (round 6, VERDICT r5 item 2a / north_star's "depth tiles staged in LDS"): the 64 records an item gathers lie in
+// ONE contiguous span of the column-major record table (the pixels a 64-voxel k-run projects to: ~96 records = 3 KiB at
+// 1.5 records per voxel).  SRC 0 = what integrate_kernel does today: two paired 64-address gathers (lane l: half l&1 of the
+// record of lane l>>1 / 32 + l>>1) + the un-shuffle through a wave-private LDS buffer.  SRC 1 = the span read COALESCED
+// (SPAN_KB x 1 KiB wave loads, lane-contiguous 16 bytes each: no 64-address work in the texture addresser), written to the
+// wave-private LDS buffer, each lane then reads its own record with two ds_read_b128.  SRC 2 = the same span by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  Same address order, same volume traffic, gathers requested
+// one item ahead in all three (as the kernel's software pipeline does).
+template <int MODE, int SRC, int SPAN_KB>
+__global__ __launch_bounds__(256) void mix4(const u4* __restrict__ rec, unsigned nrec, u2* __restrict__ dw, u4* __restrict__ col,
+                                            unsigned nseg, int items_per_wave, unsigned* __restrict__ out) {
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave = blockIdx.x * 4 + wv;
+    unsigned seed = wave * 2654435761u + 12345u, acc = 0;
+    const unsigned wg_first = (unsigned)(((unsigned long long)blockIdx.x * 2654435761ull) % (nseg / 8u - (unsigned)items_per_wave)) * 8u;
+    auto seg_of = [&](int it) -> unsigned {
+        const unsigned idx = (unsigned)it * 4u + wv;
+        return (wg_first + (idx / 5u) * 8u + 1u + idx % 5u) % nseg;
+    };
+    unsigned wseed = blockIdx.x * 747796405u + 2891336453u;
+    auto pick = [&](int it) -> unsigned {
+        if ((it & 7) == 0) wseed = wseed * 1664525u + 1013904223u;
+        return ((wseed >> 8) % (nrec - 480u) + rnd(seed) % 384u) % (nrec - 64u * SPAN_KB);
+    };
+    // wave-private staging: two buffers of SPAN_KB KiB (the span of item it+1 lands while item it is consumed)
+    __shared__ u4 s_span[4][2][64 * SPAN_KB];
+    const unsigned own = lane + (lane >> 1);                       // own record inside the span (1.5 records per voxel)
+    u4 ga = u4{0, 0, 0, 0}, gb = ga, gc = ga, gd = ga;
+    auto request = [&](unsigned base, int buf) {
+        if (SRC == 0) {
+            const unsigned pa = (lane >> 1), pb = 32u + (lane >> 1);
+            ga = rec[(size_t)(base + pa + (pa >> 1)) * 2 + (lane & 1)];
+            gb = rec[(size_t)(base + pb + (pb >> 1)) * 2 + (lane & 1)];
+        } else if (SRC == 1) {
+            const u4* src = rec + (size_t)base * 2 + lane;
+            ga = src[0]; gb = src[64]; gc = src[128];
+            if (SPAN_KB > 3) gd = src[192];
+        } else {
+            const u4* src = rec + (size_t)base * 2 + lane;
+#pragma unroll
+            for (int q = 0; q < SPAN_KB; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * q),
+                                                 (__attribute__((address_space(3))) void*)(&s_span[wv][buf][64 * q]), 16, 0, 0);
+        }
+    };
+    auto consume = [&](int buf) {
+        u4* st = s_span[wv][buf];
+        u4 P, N;
+        if (SRC == 0) {
+            st[lane] = ga; st[64 + lane] = gb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            P = st[2 * lane]; N = st[2 * lane + 1];
+        } else {
+            if (SRC == 1) {
+                st[lane] = ga; st[64 + lane] = gb; st[128 + lane] = gc;
+                if (SPAN_KB > 3) st[192 + lane] = gd;
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the probe has no other vector-memory operation in flight here)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            P = st[2 * own]; N = st[2 * own + 1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        return (P.x + P.y) ^ (P.z + P.w) ^ (N.x + N.y) ^ (N.z + N.w);          // all 32 bytes of the record are used
+    };
+    if (MODE != 1) request(pick(0), 0);
+    for (int it = 0; it < items_per_wave; ++it) {
+        const unsigned seg = __builtin_amdgcn_readfirstlane(seg_of(it));
+        const unsigned first = __builtin_amdgcn_readfirstlane(rnd(seed) % 30u);
+        if (MODE != 1) {
+            if (SRC == 2) {
+                // LDS-DMA lands in the buffer directly: item it's span must be complete before item it+1's is requested into the
+                // other buffer only in the sense of the counter -- both are vmcnt operations in order, so wait for the older one
+                acc ^= consume(it & 1);
+                if (it + 1 < items_per_wave) request(pick(it + 1), (it + 1) & 1);
+            } else {
+                const u4 a = ga, b = gb, c = gc, d = gd;
+                u4 na = a, nb = b, nc = c, nd = d;
+                if (it + 1 < items_per_wave) { request(pick(it + 1), (it + 1) & 1); na = ga; nb = gb; nc = gc; nd = gd; }
+                ga = a; gb = b; gc = c; gd = d;
+                acc ^= consume(it & 1);
+                ga = na; gb = nb; gc = nc; gd = nd;
+            }
+        }
+        if (MODE != 2) {
+            const bool live = lane >= first && lane < first + 34u;
+            const size_t vox = (size_t)seg * 64 + lane;
+            u2 d = u2{0, 0}; u4 c = u4{0, 0, 0, 0};
+            if (live) { d = dw[vox]; c = __builtin_nontemporal_load(&col[vox]); }
+            d.x += acc; d.y += acc ^ 1u; c.x += d.x; c.y ^= d.y; c.z += acc; c.w ^= acc + 3u;   /* every component changes: round 4's form let hipcc drop the unchanged ones from loads and stores */
+            if (live) { dw[vox] = d; __builtin_nontemporal_store(c, &col[vox]); }
+        }
+    }
+    if (acc == 0x12345678u) out[wave] = acc;
+}
+
+int main(int argc, char** argv) {
     const unsigned nrec = 307200, nseg = 2097152;                  // 512^3 / 64 segments
     u4 *rec, *col; u2* dw; unsigned* out;
     CHECK(hipMalloc(&rec, (size_t)nrec * 32)); CHECK(hipMalloc(&dw, (size_t)nseg * 512)); CHECK(hipMalloc(&col, (size_t)nseg * 1024));
@@ -202,7 +298,8 @@ int main(int argc, char**) {
     CHECK(hipMemset(rec, 1, (size_t)nrec * 32)); CHECK(hipMemset(dw, 0, (size_t)nseg * 512)); CHECK(hipMemset(col, 0, (size_t)nseg * 1024));
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     const char* names[5] = {"all", "no_gathers", "no_volume", "no_stores", "no_gathers_stores_elsewhere"};
-    const bool only_new = argc > 1;     // any argument: only the round-4 sweeps
+    const bool only_span = argc > 1 && argv[1][0] == 's';      // "span": only round 6's span-through-LDS probe
+    const bool only_new = argc > 1;     // any other argument: only the round-4 sweeps
     // grid sweep (199.7k items in all): wavefronts per CU = blocks * 4 / 256
     const int grids[6] = {1280, 256, 512, 768, 1024, 2048};
     for (int gi = 0; gi < (only_new ? 0 : 6); ++gi) {
@@ -233,6 +330,32 @@ int main(int argc, char**) {
             if (rep == 2) printf("{\"gather_window_records\": %u, \"workgroups_sharing_a_window\": %u, \"mode\": \"all\", \"us_per_launch\": %.1f}\n", windows[wi], shares[wi], ms * 100.0);
         }
     }
+    // round 6: the item's pixel records as ONE contiguous span through LDS instead of two 64-address gathers
+    for (int span = 3; span <= 4; ++span)
+        for (int src = 0; src < 3; ++src)
+            for (int mode = 0; mode < 3; ++mode) {
+                if (mode == 1 && (src != 0 || span != 3)) continue;          // no gathers: the same launch whatever the source
+                const int blocks = 1280, ipw = (199680 + blocks * 4 - 1) / (blocks * 4);
+                float best = 1e9f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    CHECK(hipEventRecord(a));
+                    for (int k = 0; k < 10; ++k) {
+#define L4(M, S, K) mix4<M, S, K><<<blocks, 256>>>(rec, nrec, dw, col, nseg, ipw, out)
+#define L4S(M, S) do { if (span == 3) L4(M, S, 3); else L4(M, S, 4); } while (0)
+                        if (src == 0) { if (mode == 0) L4S(0, 0); if (mode == 1) L4S(1, 0); if (mode == 2) L4S(2, 0); }
+                        if (src == 1) { if (mode == 0) L4S(0, 1); if (mode == 2) L4S(2, 1); }
+                        if (src == 2) { if (mode == 0) L4S(0, 2); if (mode == 2) L4S(2, 2); }
+                    }
+                    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+                    if (rep > 0 && ms < best) best = ms;
+                }
+                const char* srcs[3] = {"two paired 64-address gathers + LDS un-shuffle (today)", "contiguous span, coalesced loads -> ds_write -> ds_read",
+                                       "contiguous span by LDS-DMA (global_load_lds_dwordx4) -> ds_read"};
+                printf("{\"probe\": \"mix4\", \"records_from\": \"%s\", \"span_KiB\": %d, \"mode\": \"%s\", \"workgroups\": %d, \"us_per_launch\": %.1f}\n",
+                       srcs[src], span, names[mode], blocks, best * 100.0);
+            }
+    if (only_span) return 0;
     // round 4: dense batches and the kernel's address order
     for (int order = 0; order < 2; ++order)
         for (int dense = 0; dense < 2; ++dense)

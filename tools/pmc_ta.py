@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Texture-addresser (TA) and L1 (TCP) stall counters of integrate_kernel, ONE counter per rocprofv3 --pmc pass and only
-that kernel profiled (--kernel-include-regex; TSDF_INTEGRATE_KERNEL=queue in the environment profiles
-integrate_queue_kernel instead): the four-counter TA group of tools/pmc_memside.py times out on this pool,
+that kernel profiled (--kernel-include-regex): the four-counter TA group of tools/pmc_memside.py times out on this pool,
 single counters on one kernel take seconds.  Workload: tools/bench_kernels.py (fusion-only integrate launches at the
 ground-truth poses).  Run on the GPU box:   python3 tools/pmc_ta.py out.json
 rocprofv3 gets the program itself after `--`; --pmc is never combined with a trace domain."""
@@ -19,7 +18,7 @@ COUNTERS = ["GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_s
             "TA_TOTAL_WAVEFRONTS_sum", "TA_BUFFER_WAVEFRONTS_sum", "TA_BUFFER_READ_WAVEFRONTS_sum", "TA_BUFFER_WRITE_WAVEFRONTS_sum",
             "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_TA_TCP_STATE_READ_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum",
             "TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]
-KERNEL = "tsdf::integrate_queue_kernel" if os.environ.get("TSDF_INTEGRATE_KERNEL") == "queue" else "tsdf::integrate_kernel"
+KERNEL = "tsdf::integrate_kernel"
 CMD = [sys.executable, os.path.join(ROOT, "tools", "bench_kernels.py"), "--frames", "12", "--passes", "2", "--no-track-timing"]
 
 

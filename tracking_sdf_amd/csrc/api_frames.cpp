@@ -1,0 +1,852 @@
+// api_frames.cpp -- how a frame reaches the device: staging of host buffers, the frame queue, device frames with
+// deferred packing, depth pre-processing (see handle.hpp).
+#include "handle.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <new>
+
+using namespace tsdf;
+using namespace tsdf::host;
+using namespace tsdf_api;
+
+namespace tsdf_api {
+
+void free_preproc(tsdf_handle* h) {
+    if (h->pre_z) (void)hipFree(h->pre_z);
+    if (h->pre_zf) (void)hipFree(h->pre_zf);
+    if (h->pre_depth) (void)hipFree(h->pre_depth);
+    if (h->pin_depth) (void)hipHostFree(h->pin_depth);
+    if (h->pre_grid_a) (void)hipFree(h->pre_grid_a);
+    if (h->pre_grid_b) (void)hipFree(h->pre_grid_b);
+    if (h->pre_minmax) (void)hipFree(h->pre_minmax);
+    if (h->pin_minmax) (void)hipHostFree(h->pin_minmax);
+    h->pre_z = h->pre_zf = nullptr; h->pre_depth = h->pin_depth = nullptr; h->pre_cap = 0;
+    h->pre_grid_a = h->pre_grid_b = nullptr; h->pre_grid_cap = 0;
+    h->pre_minmax = h->pin_minmax = nullptr;
+}
+
+
+void free_frame(tsdf_handle* h) {
+    // (xyz | nrm | rgb live in ONE block each: the xyz pointer is the block)
+    if (h->in_xyz) (void)hipFree(h->in_xyz);
+    if (h->pin_xyz) (void)hipHostFree(h->pin_xyz);
+    if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
+    for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
+    h->pin_samples_cap = 0;
+    h->tracked = tsdf_handle::TrackedCloud();
+    h->in_xyz = h->in_nrm = nullptr; h->in_rgb = nullptr;
+    h->pin_xyz = h->pin_nrm = nullptr; h->pin_rgb = nullptr;
+    h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
+    h->stage_recorded[0] = h->stage_recorded[1] = false;
+    h->in_cap = 0;
+}
+
+int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_staging) {
+    const size_t npix = (size_t)w * hh;
+    const int32_t st = h->cfg.pixel_stride;
+    const int32_t ncols = (w + st - 1) / st, nrows = (hh + st - 1) / st;
+    const size_t ns = (size_t)ncols * nrows;
+    if (npix > h->pn_cap || ns > h->samples_cap) {
+        // growing: nothing may still read the old buffers
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->used_valid[0] = h->used_valid[1] = false;
+        h->used_untracked[0] = h->used_untracked[1] = false;
+    }
+    if (npix > h->pn_cap) {
+        for (int b = 0; b < 2; ++b) { if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]); h->pn_buf[b] = nullptr; }
+        h->pn = nullptr; h->pn_cap = 0; h->have_frame = false;
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->pn_buf[b], npix * kPixelRecordBytes));
+        h->pn_cap = npix;
+    }
+    if (ns > h->samples_cap) {
+        for (int b = 0; b < 2; ++b) { if (h->samples_buf[b]) (void)hipFree(h->samples_buf[b]); h->samples_buf[b] = nullptr; }
+        h->samples = nullptr; h->samples_cap = 0; h->have_frame = false;
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void**)&h->samples_buf[b], ns * sizeof(float4)));
+        h->samples_cap = ns;
+    }
+    const size_t nb = track_partials_doubles((int32_t)ns);
+    if (nb > h->partials_cap) {
+        if (h->partials) (void)hipFree(h->partials);
+        h->partials = nullptr; h->partials_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->partials, nb * sizeof(double)));
+        h->partials_cap = nb;
+    }
+    if (need_staging && npix > h->in_cap) {
+        free_frame(h);
+        // the three planes of a frame in ONE block, on the device and in the pinned staging set alike: a staged frame is
+        // then ONE host-to-device copy (measured: the copies of a 640x480 frame are bound by their number, not their
+        // bytes -- 12 copies per frame 3450 frames/s from PCL clouds, 3 copies 4140)
+        const size_t plane = plane_stride_bytes(npix);
+        char* dev = nullptr; char* pin = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&dev, frame_block_bytes(npix)));
+        h->in_xyz = reinterpret_cast<float*>(dev); h->in_nrm = reinterpret_cast<float*>(dev + plane); h->in_rgb = reinterpret_cast<uint8_t*>(dev + 2 * plane);
+        HIP_TRY(h, hipHostMalloc((void**)&pin, frame_block_bytes(npix), hipHostMallocDefault));
+        h->pin_xyz = reinterpret_cast<float*>(pin); h->pin_nrm = reinterpret_cast<float*>(pin + plane); h->pin_rgb = reinterpret_cast<uint8_t*>(pin + 2 * plane);
+        h->in_cap = npix;
+    }
+    h->fw = w; h->fh = hh; h->ncols = ncols; h->nrows = nrows; h->n_samples = (int32_t)ns;
+    return TSDF_OK;
+}
+
+// Record layout for this frame: along one voxel k-row the projection moves by
+// d(u,v)/dk ~ (K row 0 . c, K row 1 . c) with c = third column of rot_inv (evaluated on the optical
+// axis).  If it moves mostly down the image, store the records column-major so that the gather of 64
+// consecutive k reads neighbouring records; otherwise row-major.  Results do not depend on it.
+void pick_pixel_layout(const tsdf_handle* h, int32_t* su, int32_t* sv) {
+    const double* Ri = h->pose.rot_inv;
+    const double du = h->have_K ? h->K[0] * Ri[2] + h->K[1] * Ri[5] : Ri[2];
+    const double dv = h->have_K ? h->K[3] * Ri[2] + h->K[4] * Ri[5] : Ri[5];
+    if (std::fabs(dv) >= std::fabs(du)) { *su = h->fh; *sv = 1; }
+    else { *su = 1; *sv = h->fw; }
+}
+void choose_pixel_layout(tsdf_handle* h) { pick_pixel_layout(h, &h->pix_su, &h->pix_sv); }
+
+// make stream `st` wait until the integration that last read pixel buffer nb is done
+int wait_buffer_free(tsdf_handle* h, int nb, hipStream_t st) {
+    if (h->used_valid[nb]) {
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
+    } else if (h->used_untracked[nb]) {
+        // the buffer was last read by an integration that recorded no event (device-resident frames do not pay
+        // for one): order behind everything queued on the main stream, once
+        HIP_TRY(h, hipEventRecord(h->ev_buf_used[nb], h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
+    }
+    h->used_untracked[nb] = false;
+    return TSDF_OK;
+}
+
+PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t su, int32_t sv, int nb) {
+    PackArgs a;
+    a.xyz = xyz; a.nrm = nrm; a.rgb = rgb;
+    a.width = h->fw; a.height = h->fh; a.stride = h->cfg.pixel_stride;
+    a.pix_su = su; a.pix_sv = sv;
+    a.pn = h->pn_buf[nb]; a.samples = h->samples_buf[nb];
+    a.ncols = h->ncols; a.nrows = h->nrows;
+    a.color_layout = h->cfg.with_color ? 1 : 0;
+    return a;
+}
+
+// ---- borrowed device planes (tsdf_device_frame_released) ---------------------------------------------------------
+// a device frame with this serial has been handed over; nothing has packed it yet
+void borrow_device_frame(tsdf_handle* h, int64_t serial) {
+    try { h->borrowed.push_back({serial, -1, 0ull}); }
+    catch (...) { if (h->borrow_lost < 0) h->borrow_lost = serial; }    // out of memory for 24 bytes: nothing may throw across the C ABI;
+}                                                                        // frames from here on are reported borrowed until tsdf_synchronize
+// the launch that packs frame `serial` is about to be issued on stream index s: the ticket it will publish
+ReleaseWord release_for(tsdf_handle* h, int64_t serial, int s) {
+    ReleaseWord r;
+    r.word = h->release_host + s;
+    r.ticket = ++h->release_ticket[s];
+    for (auto& b : h->borrowed)
+        if (b.serial == serial) { b.stream = s; b.ticket = r.ticket; }
+    return r;
+}
+// frame `serial` will never be packed (replaced while its packing was still deferred; the tracker passes that read its
+// xyz plane are host-synchronous and over): free as soon as the frames before it are
+void abandon_device_frame(tsdf_handle* h, int64_t serial) {
+    for (auto& b : h->borrowed)
+        if (b.serial == serial && b.stream < 0) { b.stream = 0; b.ticket = 0ull; }
+}
+// newest serial S such that no device frame with serial <= S is still read by the library
+int64_t released_serial(tsdf_handle* h) {
+    while (!h->borrowed.empty()) {
+        const tsdf_handle::BorrowedFrame& b = h->borrowed.front();
+        if (b.stream < 0) break;
+        if (b.ticket && __atomic_load_n(h->release_host + b.stream, __ATOMIC_ACQUIRE) < b.ticket) break;
+        h->borrowed.pop_front();
+    }
+    int64_t rel = h->borrowed.empty() ? h->frame_serial + ((h->queued.active && h->queued.device) ? 1 : 0) : h->borrowed.front().serial - 1;
+    if (h->borrow_lost >= 0 && rel >= h->borrow_lost) rel = h->borrow_lost - 1;
+    return rel;
+}
+
+// st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
+// overlaps the running integration like they do.  Device-resident inputs pack on the main stream: measured, a
+// pack_kernel squeezed in beside the persistent integrate_kernel slows that one down by as much as it takes.
+int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st, bool borrowed_planes, bool samples_first) {
+    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
+    choose_pixel_layout(h);
+    const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
+    const bool side = st != h->stream;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first");
+    if (side) { const int rcw = wait_buffer_free(h, nb, st); if (rcw) return rcw; }
+    h->frame_side = side;
+    EventPair* ep;
+    int rc = timed_begin(h, 1, &ep, st);
+    if (rc) return rc;
+    {
+        PackArgs pa = pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb);
+        if (samples_first) pa.samples = nullptr;
+        HIP_TRY(h, launch_pack(st, pa));
+    }
+    if (borrowed_planes) {
+        borrow_device_frame(h, h->frame_serial + 1);
+        HIP_TRY(h, launch_release(st, release_for(h, h->frame_serial + 1, side ? 1 : 0)));
+    }
+    rc = timed_end(h, ep, st);
+    if (rc) return rc;
+    h->records_pending = false;
+    if (side) {
+        HIP_TRY(h, hipEventRecord(h->ev_frame, st));
+        if (samples_first) h->records_pending = true;          // the tracker needs the sample list only (main stream waits for ev_samples)
+        else HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));   // everything queued on `stream` from here on sees the frame
+    }
+    h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
+    h->have_frame = true;
+    h->frame_serial++;
+    h->frame_has_nrm = nrm != nullptr;
+    h->frame_has_rgb = rgb != nullptr;
+    h->deferred = tsdf_handle::DeferredPack();
+    return TSDF_OK;
+}
+
+// Samples first: a frame that arrives in host memory needs 8.3 MB (640x480) on the device before it can be integrated, but the
+// tracker only reads every pixel_stride-th point of every pixel_stride-th row -- 34 240 points, 0.5 MB.  They are gathered
+// from the caller's memory (pixel p at base + p * pixel_bytes + xyz_offset: planes or arrays of structs) by the staging
+// threads, in the reference's visiting order (columns outer, rows inner, camera_tracking.cpp:162-163), copied in front of
+// everything else of the frame, and the main stream waits for THAT copy only: the Gauss-Newton passes run while the planes
+// are still travelling.  Writes the list of the record buffer the frame is about to take (fidx ^ 1).
+int ensure_pin_samples(tsdf_handle* h) {
+    const size_t ns = (size_t)h->n_samples;
+    if (ns <= h->pin_samples_cap) return TSDF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
+    h->pin_samples_cap = 0;
+    for (int b = 0; b < 2; ++b) HIP_TRY(h, hipHostMalloc((void**)&h->pin_samples[b], ns * sizeof(float4), hipHostMallocDefault));
+    h->pin_samples_cap = ns;
+    return TSDF_OK;
+}
+int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width) {
+    int rc = ensure_pin_samples(h);
+    if (rc) return rc;
+    const int nb = h->fidx ^ 1;
+    float4* const ps = h->pin_samples[nb];
+    const int32_t st = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows;
+    const std::function<void(int, int)> gather = [&](int part, int parts) {
+        const int r0 = (int)((long long)nrows * part / parts), r1 = (int)((long long)nrows * (part + 1) / parts);
+        gather_samples(base, pixel_bytes, xyz_offset, width, st, ncols, nrows, r0, r1, reinterpret_cast<float*>(ps));
+    };
+    HostPool* const pool = host_pool(h);
+    if (pool) pool->run(gather); else gather(0, 1);
+    HIP_TRY(h, hipMemcpyAsync(h->samples_buf[nb], ps, (size_t)h->n_samples * sizeof(float4), hipMemcpyHostToDevice, h->fstream));
+    HIP_TRY(h, hipEventRecord(h->ev_samples, h->fstream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_samples, 0));
+    return TSDF_OK;
+}
+
+// A frame handed over in device memory is not packed when it is set: the tracker reads its samples from the xyz plane
+// (TrackParams::xyz_plane) and the pixel records are written inside the integrate launch, by workgroups appended to
+// list_rows_kernel (launch_integrate) -- the packing then hides under that kernel's latency chain instead of being 11 us
+// of its own in front of the first tracker pass.  The planes stay borrowed until that launch has run: tsdf.h asks for them
+// until tsdf_device_frame_released() reaches the frame's serial (or tsdf_synchronize, which packs what is pending).
+// TSDF_DEFER_PACK=0: pack at once, as rounds 1-3 did.
+int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed) {
+    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
+    if (!already_borrowed) borrow_device_frame(h, h->frame_serial + 1);
+    choose_pixel_layout(h);
+    const int nb = h->fidx ^ 1;
+    h->frame_side = false;
+    h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
+    h->have_frame = true;
+    h->frame_serial++;
+    h->frame_has_nrm = nrm != nullptr;
+    h->frame_has_rgb = rgb != nullptr;
+    h->deferred = tsdf_handle::DeferredPack();
+    h->deferred.pending = true; h->deferred.xyz = xyz; h->deferred.nrm = nrm; h->deferred.rgb = rgb;
+    h->records_pending = false;
+    return TSDF_OK;
+}
+
+}  // namespace tsdf_api
+
+namespace {
+// Is this host pointer page-locked memory HIP can copy from directly (hipHostMalloc / hipHostRegister)?
+// true when the whole range [p, p + bytes) is page-locked host memory: both ends are asked (a buffer of which only the
+// first part lies in a hipHostRegister'ed range must go through the staging copy)
+bool is_pinned_host(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    const void* ends[2] = {p, static_cast<const char*>(p) + (bytes - 1)};
+    for (const void* q : ends) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+}  // namespace
+
+namespace tsdf_api {
+HostPool* host_pool(tsdf_handle* h) {
+    if (!h->pool) {
+        // default: the usable cores less two (the caller's thread drives the GPU, one stays free), at most 12;
+        // TSDF_HOST_THREADS overrides (1 = no workers)
+        const int cores = usable_cores();
+        int n = cores - 2 < 12 ? cores - 2 : 12;
+        if (const char* e = std::getenv("TSDF_HOST_THREADS")) n = std::atoi(e);
+        if (n > cores) n = cores;
+        n = n < 1 ? 1 : n > 64 ? 64 : n;
+        h->pool.reset(new (std::nothrow) HostPool(n - 1));
+    }
+    return h->pool.get();
+}
+
+// Pageable frame -> pinned staging -> HBM: the pool's workers fill the pinned planes (fill(i0, i1) writes pixels
+// [i0, i1)), the calling thread issues the H2D copy.  Rounds 2-3 cut the frame into 4 chunks so that the DMA of chunk c
+// ran while chunk c+1 was being filled; round 4 measured what that costs: a 640x480 frame's copies are bound by their
+// NUMBER (~15-20 us each whatever the size), so 12 copies per frame lose more than the overlap wins (PCL clouds through
+// the queue: 8 chunks 2490 frames/s, 4 chunks 3450, 2 chunks 4010, 1 chunk = 3 copies 4140).  Default now: one chunk,
+// and the three planes in one block = ONE copy per frame.  TSDF_STAGE_CHUNKS keeps the pipelined form for large images.
+hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
+                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset) {
+    constexpr int kMaxChunks = 16;
+    // TSDF_STAGE_CHUNKS overrides; otherwise the caller's choice: 1 where only throughput counts (the frame queue), 2 where
+    // the frame's LATENCY to the device is on the critical path (tsdf_track_frame_aos: medians 2570 / 2850 / 2790 / 2760
+    // frames/s with 1 / 2 / 3 / 4 pieces, six alternations)
+    static const int kEnvChunks = [] { const char* e = std::getenv("TSDF_STAGE_CHUNKS"); const int n = e ? std::atoi(e) : 0; return n < 0 ? 0 : n > kMaxChunks ? kMaxChunks : n; }();
+    const int kChunks = kEnvChunks > 0 ? kEnvChunks : (chunks_when_unset < 1 ? 1 : chunks_when_unset > kMaxChunks ? kMaxChunks : chunks_when_unset);
+    std::atomic<int> done[kMaxChunks];
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    hipError_t err = hipSuccess;
+    using clk = std::chrono::steady_clock;
+    const bool prof = h->sp.on;
+    const clk::time_point t_begin = prof ? clk::now() : clk::time_point();
+    std::atomic<long long> fill_ns_max{0};
+    double upload_ns = 0, first_ns = 0;
+    auto chunk_lo = [npix, kChunks](int c) { return npix * (size_t)c / (size_t)kChunks; };
+    auto upload = [&](int c) {
+        const size_t i0 = chunk_lo(c), n = chunk_lo(c + 1) - i0;
+        if (!n || err != hipSuccess) return;
+        const clk::time_point tu = prof ? clk::now() : clk::time_point();
+        if (prof && c == 0) first_ns = std::chrono::duration<double, std::nano>(tu - t_begin).count();
+        struct Tail { const bool on; const clk::time_point t0; double& acc; ~Tail() { if (on) acc += std::chrono::duration<double, std::nano>(clk::now() - t0).count(); } } tail{prof, tu, upload_ns};
+        if (kChunks == 1 && has_xyz && has_nrm) {            // the whole frame: the planes are neighbours in both blocks -> one copy
+            const size_t bytes = has_rgb ? frame_block_bytes(h->in_cap) - (h->in_cap - npix) * 3 : 2 * plane_stride_bytes(h->in_cap);
+            err = hipMemcpyAsync(h->in_xyz, h->pin_xyz, bytes, hipMemcpyHostToDevice, h->fstream);
+            return;
+        }
+        if (has_xyz) err = hipMemcpyAsync(h->in_xyz + 3 * i0, h->pin_xyz + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
+        if (has_nrm && err == hipSuccess) err = hipMemcpyAsync(h->in_nrm + 3 * i0, h->pin_nrm + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
+        if (has_rgb && err == hipSuccess) err = hipMemcpyAsync(h->in_rgb + 3 * i0, h->pin_rgb + 3 * i0, n * 3, hipMemcpyHostToDevice, h->fstream);
+    };
+    HostPool* const pool = host_pool(h);
+    const std::function<void(int, int)> job = [&](int part, int parts) {
+        if (parts == 1) {                                   // no workers: fill and issue in turn (the DMA still overlaps)
+            for (int c = 0; c < kChunks; ++c) { fill(chunk_lo(c), chunk_lo(c + 1)); upload(c); }
+        } else if (part == 0) {                             // the caller: HIP calls only
+            for (int c = 0; c < kChunks; ++c) {
+                while (done[c].load(std::memory_order_acquire) < parts - 1) std::this_thread::yield();
+                upload(c);
+            }
+        } else {
+            const size_t wk = (size_t)(part - 1), nw = (size_t)(parts - 1);
+            long long mine = 0;
+            for (int c = 0; c < kChunks; ++c) {
+                const size_t c0 = chunk_lo(c), n = chunk_lo(c + 1) - c0;
+                const clk::time_point tf = prof ? clk::now() : clk::time_point();
+                fill(c0 + n * wk / nw, c0 + n * (wk + 1) / nw);
+                if (prof) mine += std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tf).count();
+                done[c].fetch_add(1, std::memory_order_release);
+            }
+            if (prof) { long long cur = fill_ns_max.load(); while (mine > cur && !fill_ns_max.compare_exchange_weak(cur, mine)) {} }
+        }
+    };
+    if (pool) pool->run(job); else job(0, 1);
+    if (prof) {
+        h->sp.frames++;
+        h->sp.total += std::chrono::duration<double, std::nano>(clk::now() - t_begin).count();
+        h->sp.fill_max += (double)fill_ns_max.load();
+        h->sp.first_chunk += first_ns;
+        h->sp.upload_calls += upload_ns;
+    }
+    return err;
+}
+}  // namespace tsdf_api
+
+int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
+    if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame: bad argument") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    // Page-locked caller buffers are copied from directly (no staging pass through the library's own pinned buffers:
+    // at 640x480 that memcpy is 8.3 MB per frame, longer than the frame's GPU work); the copies are complete when the
+    // call returns, so the buffers are borrowed for the call only, as for pageable ones.
+    const bool direct = is_pinned_host(xyz, npix * 12) && (!nrm || is_pinned_host(nrm, npix * 12)) && (!rgb || is_pinned_host(rgb, npix * 3));
+    // the pinned staging buffers may still feed the previous frame's async copies (frame stream only: the
+    // integration of the previous frame keeps running on the main stream meanwhile)
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
+    if (!direct) {
+        static const bool samples_first = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
+        if (samples_first) { rc = upload_samples_first(h, xyz, 12, 0, width); if (rc) return rc; }
+        HIP_TRY(h, stage_and_upload(h, npix, true, nrm != nullptr, rgb != nullptr, [&](size_t i0, size_t i1) {
+            std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+            if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+            if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
+        }));
+        h->staged_xyz = true;
+        return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+    h->staged_xyz = true;
+    HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
+    rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventSynchronize(h->ev_copied));      // the caller's buffers have been read
+    return TSDF_OK;
+}
+
+
+// ---- two-deep frame queue ----------------------------------------------------------------------------------------
+namespace tsdf_api {
+void queue_thread_main(tsdf_handle* h) {
+    (void)hipSetDevice(h->device);
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::unique_lock<std::mutex> g(h->qmu);
+            h->qcv.wait(g, [&] { return h->qstop || h->qjob; });
+            if (h->qstop) return;
+            job.swap(h->qjob);
+        }
+        job();
+        { std::lock_guard<std::mutex> g(h->qmu); h->qbusy = false; }
+        h->qcv.notify_all();
+    }
+}
+
+// the second set of pinned staging planes (the frame queue and tsdf_track_aos alternate between two sets)
+int ensure_second_staging_set(tsdf_handle* h, size_t npix) {
+    if (h->alt_cap >= npix) return TSDF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
+    h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
+    // the same block layout as the first set and the device block: sized like them (in_cap pixels)
+    const size_t plane = plane_stride_bytes(h->in_cap);
+    char* pin = nullptr;
+    HIP_TRY(h, hipHostMalloc((void**)&pin, frame_block_bytes(h->in_cap), hipHostMallocDefault));
+    h->alt_xyz = reinterpret_cast<float*>(pin); h->alt_nrm = reinterpret_cast<float*>(pin + plane); h->alt_rgb = reinterpret_cast<uint8_t*>(pin + 2 * plane);
+    h->alt_cap = h->in_cap;
+    h->stage_recorded[0] = h->stage_recorded[1] = false;
+    return TSDF_OK;
+}
+}  // namespace tsdf_api
+
+namespace {
+// what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
+int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
+                       bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
+    if (h->have_frame && (h->fw != width || h->fh != height))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    tsdf_handle::Queued& q = h->queued;
+    q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess; q.rc = TSDF_OK;
+    h->staged_xyz = false;                   // in_xyz / in_nrm / in_rgb are about to hold the QUEUED frame, not the current one
+    pick_pixel_layout(h, &q.su, &q.sv);      // from the pose of this moment: only the order of the records depends on it
+    rc = wait_buffer_free(h, q.nb, h->fstream);
+    if (rc) return rc;
+    const PackArgs pa = pack_args(h, h->in_xyz, has_nrm ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, q.su, q.sv, q.nb);
+    if (q.direct) {
+        HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+        HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
+        HIP_TRY(h, launch_pack(h->fstream, pa));
+        HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
+        q.active = true;
+        return TSDF_OK;
+    }
+    // pageable buffers: a library thread fills pinned staging planes (with the staging pool) and issues copies and pack
+    // while the caller goes on.  Two sets of staging planes alternate: the one that is filled now last fed the copies of
+    // the frame before the current one, and the library thread, not the caller, waits for those if it has to.
+    rc = ensure_second_staging_set(h, npix);
+    if (rc) return rc;
+    const auto t_queued = std::chrono::steady_clock::now();
+    if (!h->qthread.joinable()) {
+        try { h->qthread = std::thread(queue_thread_main, h); }
+        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_frame: cannot start the staging thread"); }
+    }
+    {
+        std::lock_guard<std::mutex> g(h->qmu);
+        h->qbusy = true;
+        h->qjob = [h, npix, has_nrm, has_rgb, fill, pa, t_queued] {
+            const auto ts0 = std::chrono::steady_clock::now();
+            if (h->sp.on) h->sp.handoff += std::chrono::duration<double, std::nano>(ts0 - t_queued).count();
+            // switch to the other staging set (fill and stage_and_upload read h->pin_* when they run)
+            std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
+            std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
+            hipError_t e = h->stage_recorded[0] ? hipEventSynchronize(h->ev_stage_done[0]) : hipSuccess;
+            if (h->sp.on) h->sp.sync_before += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ts0).count();
+            if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill);
+            if (e == hipSuccess) { e = hipEventRecord(h->ev_stage_done[0], h->fstream); h->stage_recorded[0] = e == hipSuccess; }
+            if (e == hipSuccess) e = launch_pack(h->fstream, pa);
+            if (e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
+            h->queued.err = e;
+        };
+    }
+    h->qcv.notify_all();
+    q.active = true;
+    return TSDF_OK;
+}
+}  // namespace
+
+int tsdf_queue_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
+    if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_queue_frame: bad argument") : TSDF_E_BADARG;
+    const size_t npix = (size_t)width * height;
+    const bool direct = is_pinned_host(xyz, npix * 12) && (!nrm || is_pinned_host(nrm, npix * 12)) && (!rgb || is_pinned_host(rgb, npix * 3));
+    std::function<void(size_t, size_t)> fill;
+    if (!direct) fill = [h, xyz, nrm, rgb](size_t i0, size_t i1) {
+        std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+        if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
+        if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
+    };
+    return queue_frame_common(h, xyz, nrm, rgb, width, height, nrm != nullptr, rgb != nullptr, fill);
+}
+
+int tsdf_queue_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height) {
+    if (!h || !L || !points || width <= 0 || height <= 0)
+        return h ? fail(h, TSDF_E_BADARG, "tsdf_queue_frame_aos: bad argument (the points are required)") : TSDF_E_BADARG;
+    const bool color = L->r_offset >= 0 && L->g_offset >= 0 && L->b_offset >= 0;
+    if (L->point_stride < 12 || L->xyz_offset < 0 || L->xyz_offset + 12 > L->point_stride ||
+        (color && (L->r_offset >= L->point_stride || L->g_offset >= L->point_stride || L->b_offset >= L->point_stride)))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame_aos: point layout (stride %d, xyz at %d) does not hold three floats and the colour bytes",
+                    L->point_stride, L->xyz_offset);
+    if (normals && (L->normal_stride < 12 || L->normal_offset < 0 || L->normal_offset + 12 > L->normal_stride))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame_aos: normal layout (stride %d, normal at %d) does not hold three floats",
+                    L->normal_stride, L->normal_offset);
+    const tsdf_aos_layout lay = *L;
+    std::function<void(size_t, size_t)> fill = [h, points, normals, lay, color](size_t i0, size_t i1) {
+        repack_aos(lay, points, normals, color, h->pin_xyz, h->pin_nrm, h->pin_rgb, i0, i1);
+    };
+    return queue_frame_common(h, nullptr, nullptr, nullptr, width, height, normals != nullptr, color, fill);
+}
+
+int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
+    if (!h || !d_xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_queue_frame_device: bad argument") : TSDF_E_BADARG;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
+    if (h->have_frame && (h->fw != width || h->fh != height))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    rc = ensure_frame_buffers(h, width, height, false);
+    if (rc) return rc;
+    tsdf_handle::Queued& q = h->queued;
+    q.nb = h->fidx ^ 1; q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true; q.err = hipSuccess; q.rc = TSDF_OK;
+    q.deferred = q.packed = false;
+    if (h->defer_device_pack) {
+        // no launch now: the integrate launch of the CURRENT frame packs this one in workgroups appended to its
+        // list_rows_kernel (tsdf_integrate), on the main stream, i.e. behind the last reader of the record buffer
+        q.deferred = true; q.d_xyz = d_xyz; q.d_nrm = d_nrm; q.d_rgb = d_rgb;
+        q.active = true;
+        borrow_device_frame(h, h->frame_serial + 1);
+        return TSDF_OK;
+    }
+    pick_pixel_layout(h, &q.su, &q.sv);
+    // the record buffer of the frame before the current one: free once that frame's integration is done -- from then
+    // on the pack runs on the frame stream, next to the current frame's tracker passes
+    rc = wait_buffer_free(h, q.nb, h->fstream);
+    if (rc) return rc;
+    HIP_TRY(h, launch_pack(h->fstream, pack_args(h, d_xyz, d_nrm, d_rgb, q.su, q.sv, q.nb)));
+    borrow_device_frame(h, h->frame_serial + 1);
+    HIP_TRY(h, launch_release(h->fstream, release_for(h, h->frame_serial + 1, 1)));
+    HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
+    q.active = true;
+    return TSDF_OK;
+}
+
+int tsdf_next_frame(tsdf_handle* h) {
+    if (!h) return TSDF_E_BADARG;
+    tsdf_handle::Queued& q = h->queued;
+    if (!q.active) return fail(h, TSDF_E_NO_FRAME, "tsdf_next_frame: no frame is queued");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    q.active = false;
+    const bool from_device = q.device;
+    q.device = false;
+    if (from_device && q.deferred) {
+        q.deferred = false;
+        h->staged_xyz = false;
+        if (!q.packed) return defer_pack(h, q.d_xyz, q.d_nrm, q.d_rgb, true);      // no integrate launch came by: as tsdf_set_frame_device
+        // packed inside the previous frame's integrate launch, on the main stream: nothing to wait for
+        if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);
+        h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
+        h->deferred = tsdf_handle::DeferredPack();
+        h->pix_su = q.su; h->pix_sv = q.sv;
+        h->frame_side = false;
+        h->have_frame = true;
+        h->frame_serial++;
+        h->frame_has_nrm = q.has_nrm;
+        h->frame_has_rgb = q.has_rgb;
+        return TSDF_OK;
+    }
+    if (from_device) {
+        // nothing to wait for on the host: device buffers stay borrowed as tsdf_set_frame_device's do
+    } else if (q.direct) {
+        HIP_TRY(h, hipEventSynchronize(h->ev_copied));       // the caller's buffers have been read
+    } else {
+        const auto tw0 = std::chrono::steady_clock::now();
+        std::unique_lock<std::mutex> g(h->qmu);
+        h->qcv.wait(g, [&] { return !h->qbusy; });           // the staging thread is done with the caller's buffers
+        if (h->sp.on) h->sp.next_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
+        if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; h->err = q.msg; return r; }
+        if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
+    }
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
+    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);     // the frame this one replaces was never packed
+    h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
+    h->deferred = tsdf_handle::DeferredPack();
+    h->pix_su = q.su; h->pix_sv = q.sv;
+    h->frame_side = true;
+    h->have_frame = true;
+    h->staged_xyz = !from_device;
+    h->frame_serial++;
+    h->frame_has_nrm = q.has_nrm;
+    h->frame_has_rgb = q.has_rgb;
+    return TSDF_OK;
+}
+
+int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
+    if (!h || !d_xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_device: bad argument") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_device");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, false);
+    if (rc) return rc;
+    h->staged_xyz = false;
+    if (h->defer_device_pack) return defer_pack(h, d_xyz, d_nrm, d_rgb);
+    return run_pack(h, d_xyz, d_nrm, d_rgb, h->stream, true);
+}
+
+int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L,
+                       int32_t width, int32_t height) {
+    if (!h || !L || (!points && !normals) || width <= 0 || height <= 0)
+        return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: bad argument") : TSDF_E_BADARG;
+    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_aos");
+    const bool color = points && L->r_offset >= 0 && L->g_offset >= 0 && L->b_offset >= 0;
+    if (points && (L->point_stride < 12 || L->xyz_offset < 0 || L->xyz_offset + 12 > L->point_stride ||
+                   (color && (L->r_offset >= L->point_stride || L->g_offset >= L->point_stride || L->b_offset >= L->point_stride))))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: point layout (stride %d, xyz at %d) does not hold three floats and the colour bytes",
+                    L->point_stride, L->xyz_offset);
+    if (normals && (L->normal_stride < 12 || L->normal_offset < 0 || L->normal_offset + 12 > L->normal_stride))
+        return fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: normal layout (stride %d, normal at %d) does not hold three floats",
+                    L->normal_stride, L->normal_offset);
+    if (!points && !(h->have_frame && h->staged_xyz && h->fw == width && h->fh == height))
+        return fail(h, TSDF_E_NO_FRAME, "tsdf_set_frame_aos: normals alone complete the CURRENT host frame of the same size; there is none");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));          // the pinned staging buffers may still feed the previous frame
+    const bool had_rgb = h->frame_has_rgb;
+    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
+    float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
+    const tsdf_aos_layout lay = *L;
+    // a new cloud: its tracker samples go up first (the passes of a following tsdf_track run under the planes' copy)
+    static const bool samples_first_on = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
+    const bool samples_first = samples_first_on && points != nullptr;
+    if (samples_first) { rc = upload_samples_first(h, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset, width); if (rc) return rc; }
+    HIP_TRY(h, stage_and_upload(h, npix, points != nullptr, normals != nullptr, color, [&](size_t i0, size_t i1) {
+        repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
+    }));
+    const bool has_rgb = points ? color : had_rgb;
+    h->staged_xyz = true;
+    return run_pack(h, h->in_xyz, normals ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
+}
+
+
+// ---- depth pre-processing (optional stage in front of the hot path) -------------------------------------------
+
+namespace {
+// argument checks and buffers shared by tsdf_set_depth_frame / tsdf_queue_depth_frame (caller's thread)
+int depth_frame_prepare(tsdf_handle* h, const char* who, bool queued, const uint16_t* depth16, const float* depthf, int32_t width,
+                        int32_t height, const tsdf_preproc_params* params, tsdf_preproc_params* pp_out) {
+    if (!h || (!depth16 == !depthf) || width <= 0 || height <= 0)
+        return h ? fail(h, TSDF_E_BADARG, "%s: exactly one of depth16 / depthf, positive size", who) : TSDF_E_BADARG;
+    if (!h->have_K) return fail(h, TSDF_E_NO_INTRINSICS, "%s needs the intrinsics for the back-projection", who);
+    tsdf_preproc_params pp;
+    if (params) pp = *params; else tsdf_default_preproc(&pp);
+    if (pp.radius < 0 || pp.radius > 32 || pp.normal_radius < 1 || pp.normal_radius > 8 || !(pp.sigma_s > 0) || !(pp.sigma_r > 0))
+        return fail(h, TSDF_E_BADARG, "%s: bad parameters (radius %d, normal_radius %d)", who, pp.radius, pp.normal_radius);
+    const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
+    if (use_grid && !(pp.sigma_s >= 1.0f && pp.sigma_s <= 30.0f))
+        return fail(h, TSDF_E_BADARG, "%s: the bilateral grid takes sigma_s in [1, 30] pixels, not %g", who, (double)pp.sigma_s);
+    if (depth16 && !(pp.depth_scale > 0))
+        return fail(h, TSDF_E_BADARG, "%s: depth_scale must be positive", who);
+    if (h->queued.active)
+        return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", who);
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if (queued && h->have_frame && (h->fw != width || h->fh != height))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    rc = ensure_frame_buffers(h, width, height, true);
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    if (npix > h->pre_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        free_preproc(h);
+        HIP_TRY(h, hipMalloc((void**)&h->pre_z, npix * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->pre_zf, npix * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->pre_depth, npix * sizeof(float)));
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_depth, npix * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc((void**)&h->pre_minmax, 2 * sizeof(unsigned)));
+        HIP_TRY(h, hipHostMalloc((void**)&h->pin_minmax, 2 * sizeof(unsigned), hipHostMallocDefault));
+        h->pre_cap = npix;
+    }
+    *pp_out = pp;
+    return TSDF_OK;
+}
+
+// Upload, back-projection, filter and normals of a depth frame on the frame stream; in_xyz / in_nrm / in_rgb hold the
+// frame afterwards.  Runs on the caller's thread (tsdf_set_depth_frame) or on the queue's library thread
+// (tsdf_queue_depth_frame): the bilateral grid's depth extent is the one host round trip of this path.
+int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
+                     int32_t width, int32_t height, const tsdf_preproc_params& pp, bool* direct_out) {
+    const size_t npix = (size_t)width * height;
+    const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));          // pinned staging may still feed the previous frame
+    const size_t dbytes = npix * (depth16 ? sizeof(uint16_t) : sizeof(float));
+    const void* dsrc = depth16 ? (const void*)depth16 : (const void*)depthf;
+    // page-locked caller buffers are copied from directly, as in tsdf_set_frame
+    const bool direct = is_pinned_host(dsrc, dbytes) && (!rgb || is_pinned_host(rgb, npix * 3));
+    *direct_out = direct;
+    if (!direct) std::memcpy(h->pin_depth, dsrc, dbytes);
+    HIP_TRY(h, hipMemcpyAsync(h->pre_depth, direct ? dsrc : h->pin_depth, dbytes, hipMemcpyHostToDevice, h->fstream));
+    HIP_TRY(h, launch_depth_to_z(h->fstream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
+                                 depth16 ? nullptr : (const float*)h->pre_depth, pp.depth_scale, (int)npix, h->pre_z,
+                                 use_grid ? h->pre_minmax : nullptr));
+    if (use_grid)
+        HIP_TRY(h, hipMemcpyAsync(h->pin_minmax, h->pre_minmax, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->fstream));
+    if (rgb) {
+        if (!direct) std::memcpy(h->pin_rgb, rgb, npix * 3);
+        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, direct ? rgb : h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+    }
+    if (direct && !use_grid) HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
+    // The grid's depth extent follows the frame's depth range: the one host round trip of this path (8 bytes).
+    BilateralGrid bg;
+    bool grid_on = false;
+    if (use_grid) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        if (h->pin_minmax[0] != 0xffffffffu) {             // else no valid pixel at all: nothing to filter
+            float zmin, zmax;
+            const unsigned lo = h->pin_minmax[0], hi = ~h->pin_minmax[1];
+            std::memcpy(&zmin, &lo, 4); std::memcpy(&zmax, &hi, 4);
+            if (!bilateral_grid_plan(width, height, pp.sigma_s, pp.sigma_r, zmin, zmax, &bg))
+                return fail(h, TSDF_E_BADARG, "%s: depth range [%g, %g] m is not a usable bilateral grid at sigma_r %g", who,
+                            (double)zmin, (double)zmax, (double)pp.sigma_r);
+            const size_t cells = (size_t)bg.gx * bg.gy * bg.gz;
+            if (cells > ((size_t)1 << 26))
+                return fail(h, TSDF_E_BADARG, "%s: bilateral grid of %d x %d x %d cells is too large (sigma_s %g, sigma_r %g)", who,
+                            bg.gx, bg.gy, bg.gz, (double)pp.sigma_s, (double)pp.sigma_r);
+            if (cells > h->pre_grid_cap) {
+                if (h->pre_grid_a) (void)hipFree(h->pre_grid_a);
+                if (h->pre_grid_b) (void)hipFree(h->pre_grid_b);
+                h->pre_grid_a = h->pre_grid_b = nullptr; h->pre_grid_cap = 0;
+                const size_t cap = cells + cells / 2;      // the range moves from frame to frame: head-room
+                HIP_TRY(h, hipMalloc((void**)&h->pre_grid_a, cap * sizeof(float2)));
+                HIP_TRY(h, hipMalloc((void**)&h->pre_grid_b, cap * sizeof(float2)));
+                h->pre_grid_cap = cap;
+            }
+            grid_on = true;
+        }
+    }
+    const float Kf[4] = {(float)h->K[0], (float)h->K[4], (float)h->K[2], (float)h->K[5]};
+    HIP_TRY(h, launch_preproc(h->fstream, width, height, Kf, use_grid && !grid_on ? 0 : pp.radius, pp.sigma_s, pp.sigma_r,
+                              pp.normal_radius, pp.max_depth_change, grid_on ? &bg : nullptr, h->pre_grid_a, h->pre_grid_b,
+                              h->pre_z, h->pre_zf, h->in_xyz, h->in_nrm));
+    return TSDF_OK;
+}
+}  // namespace
+
+int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
+                         int32_t width, int32_t height, const tsdf_preproc_params* params) {
+    tsdf_preproc_params pp;
+    int rc = depth_frame_prepare(h, "tsdf_set_depth_frame", false, depth16, depthf, width, height, params, &pp);
+    if (rc) return rc;
+    h->staged_xyz = false;                                 // until this frame's planes are complete on the device
+    bool direct = false;
+    rc = depth_frame_work(h, "tsdf_set_depth_frame", depth16, depthf, rgb, width, height, pp, &direct);
+    if (rc) return rc;
+    h->staged_xyz = true;
+    rc = run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
+    if (rc) return rc;
+    const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
+    if (direct && !use_grid) HIP_TRY(h, hipEventSynchronize(h->ev_copied));   // (the grid path has synchronised already)
+    return TSDF_OK;
+}
+
+// The two-deep queue for raw depth frames: upload, pre-processing (with its one host round trip for the bilateral grid's
+// depth range) and packing of frame k+1 run on the library thread + frame stream while the caller drives frame k's
+// Gauss-Newton passes; the buffers are borrowed until tsdf_next_frame returns.
+int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
+                           int32_t width, int32_t height, const tsdf_preproc_params* params) {
+    tsdf_preproc_params pp;
+    int rc = depth_frame_prepare(h, "tsdf_queue_depth_frame", true, depth16, depthf, width, height, params, &pp);
+    if (rc) return rc;
+    tsdf_handle::Queued& q = h->queued;
+    q.nb = h->fidx ^ 1; q.has_nrm = true; q.has_rgb = rgb != nullptr; q.direct = false; q.device = false; q.err = hipSuccess;
+    q.deferred = q.packed = false; q.rc = TSDF_OK;
+    h->staged_xyz = false;                   // in_xyz / in_nrm / in_rgb are about to hold the QUEUED frame, not the current one
+    pick_pixel_layout(h, &q.su, &q.sv);
+    rc = wait_buffer_free(h, q.nb, h->fstream);
+    if (rc) return rc;
+    const PackArgs pa = pack_args(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, q.su, q.sv, q.nb);
+    if (!h->qthread.joinable()) {
+        try { h->qthread = std::thread(queue_thread_main, h); }
+        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_depth_frame: cannot start the staging thread"); }
+    }
+    {
+        std::lock_guard<std::mutex> g(h->qmu);
+        h->qbusy = true;
+        h->qjob = [h, depth16, depthf, rgb, width, height, pp, pa] {
+            bool direct = false;
+            t_err_sink = &h->queued.msg;
+            int r = depth_frame_work(h, "tsdf_queue_depth_frame", depth16, depthf, rgb, width, height, pp, &direct);
+            t_err_sink = nullptr;
+            hipError_t e = hipSuccess;
+            if (r == TSDF_OK) e = launch_pack(h->fstream, pa);
+            if (r == TSDF_OK && e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
+            const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
+            if (r == TSDF_OK && e == hipSuccess && direct && !use_grid) e = hipEventSynchronize(h->ev_copied);   // the caller's buffers have been read
+            h->queued.rc = r;
+            h->queued.err = e;
+        };
+    }
+    h->qcv.notify_all();
+    q.active = true;
+    return TSDF_OK;
+}
+
+int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!h->in_xyz || h->in_cap < (size_t)h->fw * h->fh) return fail(h, TSDF_E_NO_FRAME, "no pre-processed frame held");
+    // the staging planes hold the CURRENT frame only until the next frame is queued (tsdf_queue_frame / _aos /
+    // tsdf_queue_depth_frame fill them with frame k+1, on the library thread and the frame stream, while frame k is current)
+    if (!h->staged_xyz)
+        return fail(h, TSDF_E_NO_FRAME, "tsdf_get_preprocessed: the planes of the current frame are no longer held (a frame is queued behind "
+                                        "it, or the frame came from device memory): read them before queueing the next frame");
+    const size_t bytes = (size_t)h->fw * h->fh * 3 * sizeof(float);
+    if (xyz) HIP_TRY(h, hipMemcpyAsync(xyz, h->in_xyz, bytes, hipMemcpyDeviceToHost, h->fstream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(nrm, h->in_nrm, bytes, hipMemcpyDeviceToHost, h->fstream));
+    HIP_TRY(h, hipStreamSynchronize(h->fstream));
+    return TSDF_OK;
+}

@@ -72,8 +72,13 @@ constexpr size_t kKernargRing = 16;
 
 }  // namespace
 
-bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_prefix, size_t explicit_bytes, std::string* err) {
+void AqlQueue::on_queue_error(int /*status*/, void* /*queue*/, void* self) {
+    if (self) static_cast<AqlQueue*>(self)->dead_ = true;      // the next submit() refuses, wait_idle() reports it
+}
+
+bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_prefix, size_t explicit_bytes, const char* build_id, std::string* err) {
     destroy();
+    dead_ = false;
     hsa_status_t st = hsa_init();              // reference-counted: HIP has it up already
     if (st != HSA_STATUS_SUCCESS) return set_err(err, "hsa_init", st);
     hsa_up_ = true;
@@ -113,6 +118,24 @@ bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_p
     st = hsa_executable_load_agent_code_object(exe, ap.gpu, reader, nullptr, nullptr);
     if (st == HSA_STATUS_SUCCESS) st = hsa_executable_freeze(exe, nullptr);
     if (st != HSA_STATUS_SUCCESS) { set_err(err, "loading the code object", st); destroy(); return false; }
+    // the code object must be THIS build's: it carries the hash of the tracker's sources and flags in a device variable
+    {
+        hsa_executable_symbol_t idsym;
+        uint64_t addr = 0;
+        uint32_t size = 0;
+        char got[64] = {0};
+        const size_t want_len = build_id ? std::strlen(build_id) : 0;
+        st = hsa_executable_get_symbol_by_name(exe, "tsdf_track_build_id", &ap.gpu, &idsym);
+        if (st == HSA_STATUS_SUCCESS) st = hsa_executable_symbol_get_info(idsym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_ADDRESS, &addr);
+        if (st == HSA_STATUS_SUCCESS) st = hsa_executable_symbol_get_info(idsym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_SIZE, &size);
+        if (st == HSA_STATUS_SUCCESS && addr && size > 0 && size < sizeof got) st = hsa_memory_copy(got, reinterpret_cast<const void*>(addr), size);
+        else if (st == HSA_STATUS_SUCCESS) st = HSA_STATUS_ERROR_INVALID_SYMBOL_NAME;
+        if (st != HSA_STATUS_SUCCESS || !want_len || std::strncmp(got, build_id, sizeof got) != 0) {
+            if (err) *err = std::string("the code object ") + hsaco_path + " is not this library's build (id '" + got + "', wanted '" + (build_id ? build_id : "") + "')";
+            destroy();
+            return false;
+        }
+    }
     SymbolPick sp{symbol_prefix, {}, false};
     st = hsa_executable_iterate_agent_symbols(exe, ap.gpu, pick_symbol, &sp);
     if (st != HSA_STATUS_SUCCESS || !sp.have) { if (err) *err = std::string("no kernel ") + symbol_prefix + "* in the code object"; destroy(); return false; }
@@ -146,18 +169,23 @@ bool AqlQueue::init(int hip_device, const char* hsaco_path, const char* symbol_p
     if (st != HSA_STATUS_SUCCESS) { set_err(err, "hsa_signal_create", st); destroy(); return false; }
     signal_ = sig.handle;
     hsa_queue_t* q = nullptr;
-    st = hsa_queue_create(ap.gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q);
+    st = hsa_queue_create(ap.gpu, 64, HSA_QUEUE_TYPE_SINGLE,
+                          [](hsa_status_t s, hsa_queue_t* qq, void* self) { AqlQueue::on_queue_error((int)s, qq, self); }, this, UINT32_MAX, UINT32_MAX, &q);
     if (st != HSA_STATUS_SUCCESS) { set_err(err, "hsa_queue_create", st); destroy(); return false; }
     queue_ = q;
-    { const char* ev = std::getenv("TSDF_AQL_READBACK"); readback_ = !(ev && std::atoi(ev) == 0); }   // 0: measurement only
     return true;
 }
 
 bool AqlQueue::submit(const void* explicit_args, uint32_t workgroups, uint32_t block) {
     hsa_queue_t* q = static_cast<hsa_queue_t*>(queue_);
-    if (!q) return false;
+    if (!q || dead_) return false;
     const uint64_t idx = hsa_queue_load_write_index_relaxed(q);
     if (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) return false;       // ring full
+    {   // an argument buffer comes round again after kKernargRing submissions: never while its packet may still be waiting
+        hsa_signal_t sig; sig.handle = signal_;
+        const uint64_t completed = (uint64_t)(kSignalStart - hsa_signal_load_relaxed(sig));
+        if (submitted_ - completed >= kKernargRing) return false;
+    }
     char* ka = kernarg_ + (size_t)(submitted_ % kKernargRing) * kernarg_stride_;
     std::memcpy(ka, explicit_args, explicit_bytes_);
     // code object v5 hidden arguments (tsdf_kernels.hip uses gridDim.x; blockDim is a compile-time constant there)
@@ -177,7 +205,7 @@ bool AqlQueue::submit(const void* explicit_args, uint32_t workgroups, uint32_t b
 #else
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
 #endif
-    if (readback_) {
+    {
         const volatile unsigned char* last = reinterpret_cast<const volatile unsigned char*>(hid + 65);
         readback_sink_ += *last;
     }
@@ -202,18 +230,27 @@ bool AqlQueue::submit(const void* explicit_args, uint32_t workgroups, uint32_t b
     return true;
 }
 
-void AqlQueue::wait_idle() {
-    if (!queue_ || !submitted_) return;
+bool AqlQueue::wait_idle() {
+    if (!queue_ || !submitted_) return !dead_;
     hsa_signal_t sig; sig.handle = signal_;
     // bounded: a pass is tens of microseconds; give up after 2 s rather than hang the caller
     const hsa_signal_value_t idle = kSignalStart - (hsa_signal_value_t)submitted_;
-    for (int i = 0; i < 200; ++i)          // 200 x 10 ms (the hint is in 100 MHz timestamp ticks)
-        if (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, idle + 1, 1000000ull, HSA_WAIT_STATE_BLOCKED) <= idle) return;
+    for (int i = 0; i < 200 && !dead_; ++i)          // 200 x 10 ms (the hint is in 100 MHz timestamp ticks)
+        if (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, idle + 1, 1000000ull, HSA_WAIT_STATE_BLOCKED) <= idle) return !dead_;
+    dead_ = true;                                    // a packet that never completed (or a queue fault): no further submissions
+    return false;
 }
 
 void AqlQueue::destroy() {
-    if (queue_) { wait_idle(); hsa_queue_destroy(static_cast<hsa_queue_t*>(queue_)); queue_ = nullptr; }
+    // A packet that never completed may still run: stop the queue from fetching, then LEAK what such a packet could touch
+    // (argument ring, code object) rather than free it under a running kernel.
+    const bool stuck = queue_ && !wait_idle();
+    if (queue_) {
+        if (stuck) hsa_queue_inactivate(static_cast<hsa_queue_t*>(queue_));
+        hsa_queue_destroy(static_cast<hsa_queue_t*>(queue_)); queue_ = nullptr;
+    }
     if (signal_) { hsa_signal_t s; s.handle = signal_; hsa_signal_destroy(s); signal_ = 0; }
+    if (stuck) { kernarg_ = nullptr; executable_ = 0; reader_ = 0; }
     if (kernarg_) { hsa_amd_memory_pool_free(kernarg_); kernarg_ = nullptr; }
     if (executable_) { hsa_executable_t e; e.handle = executable_; hsa_executable_destroy(e); executable_ = 0; }
     if (reader_) { hsa_code_object_reader_t r; r.handle = reader_; hsa_code_object_reader_destroy(r); reader_ = 0; }

@@ -1,5 +1,5 @@
-// tsdf_device.h -- parameter blocks and launch entry points shared by the HIP kernels
-// (tsdf_kernels.hip) and the C-ABI host side (tsdf_api.cpp).  gfx950 only.
+// tsdf_device.h -- parameter blocks and launch entry points shared by the HIP kernels (integrate_kernels.hip,
+// track_kernels.hip, volume_kernels.hip, preproc_kernels.hip, mesh_kernels.hip) and the C-ABI host side (api_*.cpp).  gfx950 only.
 #pragma once
 
 #include <hip/hip_runtime_api.h>
@@ -21,16 +21,9 @@ constexpr int kRedAllreduce = 30;   // the leading part that is summed over rank
 // d <= 3 and r*J[q] for d = 4, then counters
 constexpr int kPartTerms = 30, kPartViol = 31, kPartOk = 32, kPartInOwned = 33, kPartOog = 34, kPartNan = 35,
               kPartSamples = 36, kPartWidth = 40;
-#ifndef TSDF_TRACK_BLOCK
-#define TSDF_TRACK_BLOCK 384   // 640x480: 714 workgroups = 2.8 per CU (256 threads: 4.2 per CU, i.e. a fifth one on some); measured 13.5 -> 13.1 us, fold 4.8 -> 4.2 us
-#endif
-constexpr int kTrackBlock = TSDF_TRACK_BLOCK;    // threads per tracker workgroup
-#ifndef TSDF_INTEGRATE_BLOCK
-#define TSDF_INTEGRATE_BLOCK 256
-#endif
-constexpr int kIntegrateBlock = TSDF_INTEGRATE_BLOCK;   // threads per integrate workgroup
+constexpr int kTrackBlock = 384;                 // threads per tracker workgroup (640x480: 714 workgroups = 2.8 per CU; 512 threads lost a resident workgroup per CU)
+constexpr int kIntegrateBlock = 256;             // threads per integrate workgroup
 constexpr int kTrackShards = 8;                  // fan-in shards of the in-launch fold (blockIdx % 8: one per XCD)
-constexpr int kTrackStampBlocks = 4096;          // TSDF_TRACK_STAMPS: workgroups that have a slot in the stamp buffer (the others write none)
 constexpr int kShardSlotDoubles = 80;            // pinned host slot of a shard row: 40 {value, pass word} pairs of 16 bytes -- a value
                                                  // and the word that validates it arrive in ONE store, so no fence separates them
 
@@ -79,7 +72,6 @@ struct IntegrateParams {
     int32_t width, height;
     int32_t pix_su, pix_sv;  // record index of pixel (col,row) = col*pix_su + row*pix_sv
     int32_t with_color;
-    int32_t debug;           // 0 in production; bit 0 / bit 1 = timing experiments (see integrate_kernel)
 };
 
 struct TrackParams {
@@ -106,10 +98,10 @@ struct PackArgs {
     const float* xyz = nullptr; const float* nrm = nullptr; const uint8_t* rgb = nullptr;
     int32_t width = 0, height = 0, stride = 1;
     int32_t pix_su = 0, pix_sv = 0;       // record index of pixel (col,row) = col*pix_su + row*pix_sv
-    float4* pn = nullptr;                 // kPixelBufferBytes per pixel
+    float4* pn = nullptr;                 // kPixelRecordBytes per pixel
     float4* samples = nullptr;            // ncols x nrows tracker samples (null: not written)
     int32_t ncols = 0, nrows = 0;
-    int32_t color_layout = 0;             // 0: 24-byte {P,N} records; 1: 32-byte records (volume with colour); 2: + the f64 cosine plane (integrate_queue_kernel)
+    int32_t color_layout = 0;             // 0: 24-byte {P,N} records; 1: 32-byte records (volume with colour)
 };
 
 // mesh extraction (mesh_kernels.hip): cubes with base voxel layer i in [ci0, ci1), j,k in [1, m-2]
@@ -139,15 +131,12 @@ size_t integrate_worklist_entries(const Grid& g);
 size_t integrate_band_region_entries(const Grid& g);   // entries of the band regions in front of the overflow region
 size_t integrate_worklist_bytes(const Grid& g);      // 32-byte item descriptors: band regions + overflow region
 constexpr size_t kPixelRecordBytes = 32;             // per pixel: two float4 records (24 of them used when the volume has no colour)
-constexpr size_t kPixelBufferBytes = 40;             // what a frame's pixel buffer holds per pixel: the record + the f64 cosine (colour volumes)
 size_t integrate_bookkeeping_words();
-// queue = the round-4 kernel that updates dense batches of queued voxels (integrate_queue_kernel), otherwise round 3's item-at-a-time integrate_kernel
-int integrate_blocks_per_cu(bool queue);
-bool integrate_queue_fits(const Grid& g);
+int integrate_blocks_per_cu();
 hipError_t launch_integrate(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                             const float4* pn, unsigned long long* counters,
                             void* worklist, unsigned* work_count, int n_blocks,
-                            unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */, bool queue,
+                            unsigned launch_parity, unsigned long long* wg_counts /* 2 per workgroup, zero at start */,
                             const PackArgs* pack = nullptr /* the frame's records are still to be packed: done inside this launch */,
                             const ReleaseWord* release = nullptr /* with pack of borrowed planes: told to the host once they are read */);
 // the two halves of launch_integrate, for a caller that can issue the list before the frame's records are complete
@@ -156,7 +145,7 @@ hipError_t launch_integrate_list(hipStream_t s, const IntegrateParams& p, void* 
 hipError_t launch_integrate_items(hipStream_t s, const IntegrateParams& p, float2* dw, float4* crgb,
                                   const float4* pn, unsigned long long* counters,
                                   void* worklist, unsigned* work_count, int n_blocks,
-                                  unsigned launch_parity, unsigned long long* wg_counts, bool queue, const ReleaseWord* release = nullptr);
+                                  unsigned launch_parity, unsigned long long* wg_counts, const ReleaseWord* release = nullptr);
 // One tracker pass = one launch.  partials: track_partials_doubles(n_samples) doubles (per-workgroup rows + shard rows);
 // ctr: track_fold_counter_words() unsigned, zero before the first pass; red_dev (may be null): kRedWidth doubles for an
 // in-stream all-reduce; host_row (pinned or a registered shared segment, may be null): kRedWidth doubles + one 64-bit
@@ -180,12 +169,13 @@ class AqlQueue;   // aql_queue.hpp
 hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2* dw, const float4* samples,
                                double* partials, unsigned* ctr, double* red_dev, double* host_row, double* host_shards,
                                unsigned long long word, unsigned long long pass, const PeerExchange* peers = nullptr,
-                               unsigned long long* stamps = nullptr /* diagnosis: 8 words per workgroup */,
                                AqlQueue* aql = nullptr /* dispatch through the library's own queue instead of the stream (falls
-                                                          back to the stream when the queue refuses) */);
+                                                          back to the stream when the queue refuses) */,
+                               bool* went_through_queue = nullptr /* out: the queue took the dispatch */);
 // what AqlQueue::init needs to know about track_kernel: the size of its explicit arguments and how its symbol begins
 size_t track_kernel_explicit_arg_bytes();
 const char* track_kernel_symbol_prefix();
+const char* track_kernel_build_id();       // TSDF_BUILD_ID of this build: the stand-alone code object must carry the same
 // the same exchange for a row that is already in red_dev (tsdf_allreduce): one wavefront; n_sum leading entries are added
 hipError_t launch_peer_exchange(hipStream_t s, const PeerExchange& px, double* red_dev, int n_sum, double* host_row,
                                 unsigned long long host_word);
