@@ -183,20 +183,20 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(args, K, frames, m, width, height, ts=None, dev_index=0):
-    """The reference's CPU path (the oracle restatement: same loop structure, 24 B/voxel
-    global_coords table, AoS clouds, OpenMP) timed on this box's host cores on a bounded sample.
-    With `ts` (the HIP binding) the SAME frames then go through the HIP path at the SAME size, free-running from the same
-    initial pose with the reference's thread-local carry state for the same thread count, and the two runs are compared
-    frame by frame: `parity_full_size` (the oracle is the checker here, after the timed region; it is never the product)."""
-    import oracle as orc
-    cores = usable_cores()
-    n = max(1, min(args.cpu_baseline_frames, len(frames) - 1))
-    oo = orc.SDF(m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025, with_global_coords=True)
+def free_run_compare(args, ts, orc, K, frames, m, width, height, n, track_threads, update_threads, dev_index, with_global_coords,
+                     time_limit_s=20.0):
+    """The oracle (the reference's CPU path restated) and the HIP path on the SAME frames, both free-running from the
+    reference's initial pose (every pose feeds the next integration), compared frame by frame and, at the end, voxel by
+    voxel.  track_threads = the OpenMP thread count of the oracle's tracker = carry_threads of the HIP handle (the
+    reference's carry state is thread-local, camera_tracking.cpp:148-159; 1 = SURVEY 8a8' canonical order).  Returns
+    (timing of the oracle run, parity record).  The oracle is the checker here, after the timed region; never the product."""
+    color = not args.no_color
+    oo = orc.SDF(m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025, with_global_coords=with_global_coords)
+    oo.track_exp_band()                      # which voxels took the exp() weight: the only ones allowed to differ (DESIGN section 5)
     ot = orc.CameraTracking(oo)
     ot.set_K(K)
     xyz, nrm, rgb = frames[0]
-    n_upd = [oo.update(ot, orc.Cloud(xyz, nrm, rgb), with_color=not args.no_color, threads=cores)]
+    n_upd = [oo.update(ot, orc.Cloud(xyz, nrm, rgb), with_color=color, threads=update_threads)]
     iters, stops, poses = [], [], [ot.trans.copy()]
     t_track = t_upd = 0.0
     done = 0
@@ -205,17 +205,86 @@ def cpu_baseline(args, K, frames, m, width, height, ts=None, dev_index=0):
         xyz, nrm, rgb = frames[k]
         cloud = orc.Cloud(xyz, nrm, rgb)
         t0 = time.perf_counter()
-        so = ot.estimate_new_position(oo, cloud, threads=cores, stale_carry=True)
+        so = ot.estimate_new_position(oo, cloud, threads=track_threads, stale_carry=True)
         t1 = time.perf_counter()
-        n_upd.append(oo.update(ot, cloud, with_color=not args.no_color, threads=cores))
+        n_upd.append(oo.update(ot, cloud, with_color=color, threads=update_threads))
         t2 = time.perf_counter()
         t_track += t1 - t0
         t_upd += t2 - t1
         iters.append(so["iterations"]); stops.append(bool(so["stopped"])); poses.append(ot.trans.copy())
         done += 1
-        if time.perf_counter() - t_all > 20.0:
+        if time.perf_counter() - t_all > time_limit_s:
             break
-    total = t_track + t_upd
+    timing = {"frames": done, "track_s": t_track, "update_s": t_upd}
+    # the same frames through the C ABI (host planes)
+    gs = ts.SDF(m, with_color=color, device=dev_index, carry_threads=track_threads)
+    gt = ts.CameraTracking(sdf=gs)
+    gt.set_K(K)
+    try:
+        col = (lambda f: f) if color else (lambda f: (f[0], f[1], None))
+        g_upd = [gs.update(gt, *col(frames[0]))["n_updated"]]
+        g_iters, g_stops, gaps = [], [], []
+        for k in range(1, done + 1):
+            sg = gt.estimate_new_position(gs, frames[k][0])
+            g_upd.append(gs.update(gt, *col(frames[k]))["n_updated"])
+            g_iters.append(int(sg["iterations"])); g_stops.append(bool(sg["stopped"]))
+            gaps.append(float(np.max(np.abs(gt.trans - poses[k]))))
+        # the volumes at the end of the sample, every array, bit for bit
+        D, W = gs.download()
+        mask = oo.exp_mask
+
+        def differing(got, want):
+            idx = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+            if idx.size:                                     # +0 / -0 and NaN payloads are not differences
+                a, b = got[idx], want[idx]
+                idx = idx[~(((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b)))]
+            if not idx.size:
+                return {"voxels": 0, "max_ulp": 0, "max_abs": 0.0, "outside_the_exp_band": 0}
+            a, b = got[idx], want[idx]
+            ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+            ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia); ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+            return {"voxels": int(idx.size), "max_ulp": int(np.max(np.abs(ia - ib))),
+                    "max_abs": float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))),
+                    "outside_the_exp_band": int((mask[idx] == 0).sum())}
+        arrays = {"W": differing(W, oo.W), "D": differing(D, oo.D)}
+        del D, W
+        if color:
+            for name, got, want in zip(("Color_W", "R", "G", "B"), gs.download_color(), (oo.Color_W, oo.R, oo.G, oo.B)):
+                arrays[name] = differing(got, want)
+        parity = {"frames": done + 1, "m": m, "image": [width, height], "carry_threads": track_threads,
+                  "iterations_equal": g_iters == iters, "stop_flags_equal": g_stops == stops,
+                  "n_updated_equal": g_upd == n_upd[:done + 1],
+                  "iteration_mismatches": int(sum(a != b for a, b in zip(g_iters, iters))),
+                  "n_updated_mismatches": int(sum(a != b for a, b in zip(g_upd, n_upd))),
+                  "max_pose_gap_m": max(gaps) if gaps else 0.0,
+                  "pose_gap_bar_m": 1e-5 if done <= 10 else 1e-4,
+                  "voxels": int(oo.W.size), "voxels_that_took_the_exp_weight": int(mask.sum()),
+                  "arrays": arrays,
+                  "voxels_with_other_W_bits": arrays["W"]["voxels"], "max_W_ulp": arrays["W"]["max_ulp"],
+                  "voxels_with_other_D_bits": arrays["D"]["voxels"], "max_D_ulp": arrays["D"]["max_ulp"], "max_abs_D_m": arrays["D"]["max_abs"],
+                  "differences_outside_the_exp_band": int(sum(v["outside_the_exp_band"] for v in arrays.values())),
+                  "bars": "iterations, stop flags, n_updated equal per frame; pose gap <= pose_gap_bar_m; every array bit-identical "
+                          "except in voxels that took the exp() weight (W <= 1 ulp, D and colour <= 4 ulp there; SURVEY 8c: D abs <= 2e-6 m)"}
+        parity["ok"] = bool(parity["iterations_equal"] and parity["stop_flags_equal"] and parity["n_updated_equal"]
+                            and parity["max_pose_gap_m"] <= parity["pose_gap_bar_m"] and parity["differences_outside_the_exp_band"] == 0
+                            and arrays["W"]["max_ulp"] <= 1 and all(v["max_ulp"] <= 4 for v in arrays.values()) and arrays["D"]["max_abs"] <= 2e-6)
+    finally:
+        gs.close()
+    return timing, parity
+
+
+def cpu_baseline(args, K, frames, m, width, height, ts=None, dev_index=0):
+    """The reference's CPU path (the oracle restatement: same loop structure, 24 B/voxel
+    global_coords table, AoS clouds, OpenMP) timed on this box's host cores on a bounded sample.
+    With `ts` (the HIP binding) the SAME frames also go through the HIP path at the SAME size, free-running, and the two runs
+    are compared frame by frame and voxel by voxel (free_run_compare): `parity_full_size` at the oracle's timed thread count,
+    `parity_canonical_order` with one tracker thread (SURVEY 8a8': the canonical carry order), `parity_config2` at 256^3."""
+    import oracle as orc
+    cores = usable_cores()
+    n = max(1, min(args.cpu_baseline_frames, len(frames) - 1))
+    timing, parity = free_run_compare(args, ts, orc, K, frames, m, width, height, n, cores, cores, dev_index, True)
+    done = timing["frames"]
+    total = timing["track_s"] + timing["update_s"]
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -228,44 +297,20 @@ def cpu_baseline(args, K, frames, m, width, height, ts=None, dev_index=0):
     out = {"value": done / total, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": f"{done} frames (track + update) of the same {width}x{height} stream at "
                      f"{m}^3 after 1 fused frame; OpenMP on all {cores} host threads",
-           "track_ms_per_frame": 1e3 * t_track / done, "update_ms_per_frame": 1e3 * t_upd / done,
+           "track_ms_per_frame": 1e3 * timing["track_s"] / done, "update_ms_per_frame": 1e3 * timing["update_s"] / done,
            "cpu_model": model}
-    parity = None
-    if ts is not None:
-        # the same frames, free-running, through the C ABI (host planes; carry_threads = the oracle's OpenMP thread count)
-        gs = ts.SDF(m, with_color=not args.no_color, device=dev_index, carry_threads=cores)
-        gt = ts.CameraTracking(sdf=gs)
-        gt.set_K(K)
-        try:
-            col = (lambda f: f) if not args.no_color else (lambda f: (f[0], f[1], None))
-            g_upd = [gs.update(gt, *col(frames[0]))["n_updated"]]
-            g_iters, g_stops, gaps = [], [], []
-            for k in range(1, done + 1):
-                sg = gt.estimate_new_position(gs, frames[k][0])
-                g_upd.append(gs.update(gt, *col(frames[k]))["n_updated"])
-                g_iters.append(int(sg["iterations"])); g_stops.append(bool(sg["stopped"]))
-                gaps.append(float(np.max(np.abs(gt.trans - poses[k]))))
-            # the volumes at the end of the sample, bit for bit (exp() band: <= 1 ulp of W -- DESIGN section 5)
-            D, W = gs.download()
-            dW = np.flatnonzero(W.view(np.uint32) != oo.W.view(np.uint32))
-            dD = np.flatnonzero(D.view(np.uint32) != oo.D.view(np.uint32))
-            w_ulp = int(np.max(np.abs(W[dW].view(np.int32).astype(np.int64) - oo.W[dW].view(np.int32).astype(np.int64)))) if dW.size else 0
-            parity = {"frames": done + 1, "m": m, "image": [width, height], "carry_threads": cores,
-                      "iterations_equal": g_iters == iters, "stop_flags_equal": g_stops == stops,
-                      "n_updated_equal": g_upd == n_upd[:done + 1],
-                      "iteration_mismatches": int(sum(a != b for a, b in zip(g_iters, iters))),
-                      "n_updated_mismatches": int(sum(a != b for a, b in zip(g_upd, n_upd))),
-                      "max_pose_gap_m": max(gaps) if gaps else 0.0,
-                      "pose_gap_bar_m": 1e-5 if done <= 10 else 1e-4,
-                      "voxels_with_other_W_bits": int(dW.size), "max_W_ulp": w_ulp,
-                      "voxels_with_other_D_bits": int(dD.size), "voxels": int(W.size),
-                      "note": ("HIP path vs oracle on the cpu_baseline leg's own frames, free-running (every pose feeds the next "
-                               "integration): Gauss-Newton iteration counts, stop flags and updated-voxel counts per frame must be "
-                               "equal; pose gap bar = DESIGN section 5's free-running bar (1e-5 m over 10 frames, 1e-4 m over 24); "
-                               "W may differ by 1 ulp in voxels whose weight went through exp() (and D / later frames with it)")}
-        finally:
-            gs.close()
-    return out, parity
+    more = {}
+    try:
+        # the canonical order: ONE tracker thread (the carry never resets inside a pass); the update keeps all cores -- its
+        # result does not depend on the thread count
+        _, more["parity_canonical_order"] = free_run_compare(args, ts, orc, K, frames, m, width, height, min(8, n), 1, cores, dev_index, False,
+                                                             time_limit_s=15.0)
+        if m != 256:       # BASELINE config 2's size on the same stream
+            _, more["parity_config2"] = free_run_compare(args, ts, orc, K, frames, 256, width, height, n, cores, cores, dev_index, False,
+                                                         time_limit_s=15.0)
+    except Exception as e:      # noqa: BLE001  (an extra comparison must not take the result line with it)
+        more["parity_extra_error"] = f"{type(e).__name__}: {e}"
+    return out, parity, more
 
 
 PMC_GROUPS = (("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum"), ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
@@ -1042,7 +1087,8 @@ def run(args):
         if world == 1 and not args.no_cpu_baseline:
             d_frames = None
             torch.cuda.empty_cache()
-            out["cpu_baseline"], out["parity_full_size"] = cpu_baseline(args, seq.K, host_frames, m, width, height, ts, dev_index)
+            out["cpu_baseline"], out["parity_full_size"], more = cpu_baseline(args, seq.K, host_frames, m, width, height, ts, dev_index)
+            out.update(more)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -40,7 +40,7 @@ class _Sdf(C.Structure):
                 ("D", C.POINTER(C.c_float)), ("W", C.POINTER(C.c_float)),
                 ("Color_W", C.POINTER(C.c_float)), ("R", C.POINTER(C.c_float)),
                 ("G", C.POINTER(C.c_float)), ("B", C.POINTER(C.c_float)),
-                ("global_coords", C.POINTER(C.c_double))]
+                ("global_coords", C.POINTER(C.c_double)), ("exp_mask", C.POINTER(C.c_uint8))]
 
 
 class _Tracker(C.Structure):
@@ -80,6 +80,8 @@ def lib():
     L.orc_sdf_create.restype = C.POINTER(_Sdf)
     L.orc_sdf_create.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, dp, C.c_float, C.c_float, C.c_int32]
     L.orc_sdf_destroy.argtypes = [C.POINTER(_Sdf)]
+    L.orc_sdf_track_exp_band.restype = C.c_int32
+    L.orc_sdf_track_exp_band.argtypes = [C.POINTER(_Sdf)]
     L.orc_get_array_index.restype = C.c_int64
     L.orc_get_array_index.argtypes = [C.POINTER(_Sdf), ip]
     L.orc_get_voxel_coordinates_idx.argtypes = [C.POINTER(_Sdf), C.c_int64, ip]
@@ -184,9 +186,17 @@ class SDF:
     def c(self):
         return self._p.contents
 
+    def track_exp_band(self):
+        """From now on self.exp_mask[idx] = 1 for every voxel whose weight goes through exp() (sdf.cpp:277-279): the
+        voxels in which a second correctly rounded-to-an-ulp exp() may differ in the last bit.  A checker's annotation."""
+        if lib().orc_sdf_track_exp_band(self._p) != 0:
+            raise MemoryError("orc_sdf_track_exp_band failed")
+        self.exp_mask = np.ctypeslib.as_array(self._p.contents.exp_mask, shape=(self.m ** 3,))
+        return self.exp_mask
+
     def __del__(self):
         if getattr(self, "_p", None):
-            for k in ("D", "W", "Color_W", "R", "G", "B"):
+            for k in ("D", "W", "Color_W", "R", "G", "B", "exp_mask"):
                 self.__dict__.pop(k, None)
             lib().orc_sdf_destroy(self._p)
             self._p = None

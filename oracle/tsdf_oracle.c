@@ -203,7 +203,13 @@ void orc_sdf_destroy(orc_sdf *s) {
     if (!s) return;
     free(s->D); free(s->W); free(s->Color_W); free(s->R); free(s->G); free(s->B);
     free(s->global_coords);
+    free(s->exp_mask);
     free(s);
+}
+int32_t orc_sdf_track_exp_band(orc_sdf *s) {
+    if (!s) return -1;
+    if (!s->exp_mask) s->exp_mask = (uint8_t *)calloc((size_t)s->number_of_voxels, 1);
+    return s->exp_mask ? 0 : -1;
 }
 
 /* sdf.cpp:100-126 */
@@ -398,6 +404,7 @@ int64_t orc_update(orc_sdf *s, const orc_tracker *t, const orc_cloud *c,
         w_new = 1.0;
         if (d_new >= s->distance_epsilon && d_new <= s->distance_delta) {
             w_new = exp(-0.5 * (d_new - s->distance_epsilon) * (d_new - s->distance_epsilon));
+            if (s->exp_mask) s->exp_mask[idx] = 1;               /* (checker's annotation, not the reference's) */
         }
         if (d_new > s->distance_delta) continue;                 /* sdf.cpp:280-283 */
         if (d_new < -s->distance_delta) d_new = -s->distance_delta;

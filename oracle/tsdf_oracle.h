@@ -51,6 +51,9 @@ typedef struct orc_sdf {
     int64_t number_of_voxels;        /* sdf.h:56 is int; widened so m>1290 does not wrap */
     float *D, *W, *Color_W, *R, *G, *B;   /* sdf.h:41-55 */
     double *global_coords;           /* sdf.h:45  Vector3d[m^3] = 24 B/voxel */
+    uint8_t *exp_mask;               /* NOT in the reference: a checker's annotation (orc_sdf_track_exp_band), NULL unless asked
+                                        for -- 1 for every voxel whose weight went through exp() (sdf.cpp:277-279) at least once,
+                                        i.e. the voxels in which another correctly working exp() may legitimately differ by an ulp */
 } orc_sdf;
 
 /* ---- camera tracker state (class CameraTracking, camera_tracking.h:12-105) ---- */
@@ -98,6 +101,8 @@ orc_sdf *orc_sdf_create(int32_t m, float width, float height, float depth,
                         const double origin[3], float delta, float epsilon,
                         int32_t with_global_coords);
 void orc_sdf_destroy(orc_sdf *s);
+/* start recording the exp() band into s->exp_mask (m^3 bytes, zeroed); 0 on success */
+int32_t orc_sdf_track_exp_band(orc_sdf *s);
 
 /* sdf.h:113-127, 132-136, 143-147, 153-157 */
 int64_t orc_get_array_index(const orc_sdf *s, const int32_t vox[3]);

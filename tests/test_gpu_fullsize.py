@@ -222,6 +222,7 @@ def test_hip_path_equals_the_oracle_at_baseline_size(m, w, h, K, need_gb):
              (seq.R[2] @ Rz, seq.t[2], synth.render_frame(seq.R[2] @ Rz, seq.t[2], seq.K, w, h, noise=True, holes=0.02,
                                                           rng=np.random.default_rng(5)))]
     oo = orc.SDF(m, 6.0, 6.0, 3.5, (-3.0, -3.0, -0.5), 0.3, 0.025, with_global_coords=(m <= 512))
+    oo.track_exp_band()              # m^3 bytes: which voxels took the exp() weight (the only ones allowed to differ, util.py)
     ot = orc.CameraTracking(oo)
     ot.set_K(seq.K)
     go = ts.SDF(m, with_color=True, carry_threads=CARRY_THREADS)

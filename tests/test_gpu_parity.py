@@ -16,7 +16,7 @@ import pytest
 
 import oracle as orc
 from tracking_sdf_amd import synth
-from util import VOL, make_gpu, make_oracle, scaled_K, sym_rel_err, ulp_diff
+from util import VOL, assert_volume_equal_at_size, make_gpu, make_oracle, scaled_K, sym_rel_err, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -29,20 +29,10 @@ def frames(n, noise=False, holes=0.0, width=W_, height=H_, step=4):
 
 
 def assert_volume_equal(go, oo, m, color=True, max_exp_ulp=1):
-    D, W = go.download()
-    uD, uW = ulp_diff(D, oo.D), ulp_diff(W, oo.W)
-    assert uW.max() <= max_exp_ulp, f"W differs by {uW.max()} ulp"
-    # where W is identical, D must be identical too
-    assert uD[uW == 0].max() == 0
-    frac = float((uW > 0).mean())
-    assert frac < 1e-4, f"{frac:.2e} of the voxels differ in W (expected only rare exp() last-bit cases)"
-    assert uD.max() <= 4
-    if color:
-        cw, r, g, b = go.download_color()
-        for got, want in ((cw, oo.Color_W), (r, oo.R), (g, oo.G), (b, oo.B)):
-            u = ulp_diff(got, want)
-            assert u[uW == 0].max() == 0 and u.max() <= 4
-    return frac
+    """bit-exact, except voxels whose weight went through exp() (recorded by the oracle): W <= 1 ulp,
+    D / colour <= 4 ulp there, < 1e-4 of the voxels in all (tests/util.py: the same bar at every size)."""
+    n_bad = assert_volume_equal_at_size(go, oo, color=color, max_exp_ulp=max_exp_ulp)
+    return n_bad / float(m ** 3)
 
 
 @pytest.mark.parametrize("m", [32, 48, 64])

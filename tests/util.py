@@ -15,6 +15,7 @@ def scaled_K(width, height):
 
 def make_oracle(m, K, vol=VOL, gn=(20, 0.001, 1.0, 0.01)):
     s = orc.SDF(m, vol["width"], vol["height"], vol["depth"], vol["origin"], vol["delta"], vol["epsilon"])
+    s.track_exp_band()       # the checker's annotation: which voxels ever took the exp() weight (assert_volume_equal*)
     t = orc.CameraTracking(s, *gn)
     t.set_K(K)
     return s, t
@@ -81,19 +82,29 @@ def volume_mismatch(got, want, chunk=1 << 24):
 
 
 def assert_volume_equal_at_size(go, oo, color=True, max_exp_ulp=1, max_frac=1e-4):
-    """test_gpu_parity.assert_volume_equal's bar for volumes of BASELINE size: W bit-exact except
-    the rare voxels whose weight went through exp() (<= 1 ulp), D and the colour lanes identical wherever W is."""
+    """DESIGN section 5's bar for volumes of any size: every array bit-exact, EXCEPT in voxels whose weight went through
+    exp() at least once (sdf.cpp:277-279; the oracle records them: SDF.track_exp_band) -- there W may differ by 1 ulp and
+    D / the colour lanes by <= 4 ulp (a 1-ulp weight can round away in W + w and still show in the quotient: D-only
+    differences are legitimate there), and all such voxels together stay below max_frac of the volume."""
+    mask = getattr(oo, "exp_mask", None)
+    assert mask is not None, "make the oracle with util.make_oracle (it records the exp() band)"
     D, W = go.download()
     n = W.size
     uW, nW, iW = volume_mismatch(W, oo.W)
     assert uW <= max_exp_ulp, f"W differs by {uW} ulp"
-    assert nW / n < max_frac, f"{nW} of {n} voxels differ in W (expected only rare exp() last-bit cases)"
+    assert mask[iW].all(), f"W differs in {int((mask[iW] == 0).sum())} voxels that never took the exp() weight"
     uD, nD, iD = volume_mismatch(D, oo.D)
-    assert uD <= 4 and np.isin(iD, iW).all(), f"D differs in {nD} voxels (max {uD} ulp), W in {nW}"
+    assert uD <= 4, f"D differs by {uD} ulp"
+    assert mask[iD].all(), f"D differs in {int((mask[iD] == 0).sum())} voxels that never took the exp() weight"
+    bad = [iW, iD]
     del D, W
     if color:
         got = go.download_color()
-        for g, want in zip(got, (oo.Color_W, oo.R, oo.G, oo.B)):
+        for name, g, want in zip(("Color_W", "R", "G", "B"), got, (oo.Color_W, oo.R, oo.G, oo.B)):
             u, k, i = volume_mismatch(g, want)
-            assert u <= 4 and np.isin(i, iW).all(), f"a colour lane differs in {k} voxels (max {u} ulp), W in {nW}"
-    return nW
+            assert u <= 4, f"{name} differs by {u} ulp"
+            assert mask[i].all(), f"{name} differs in {int((mask[i] == 0).sum())} voxels that never took the exp() weight"
+            bad.append(i)
+    n_bad = int(np.unique(np.concatenate(bad)).size)
+    assert n_bad / n < max_frac, f"{n_bad} of {n} voxels differ (expected only rare exp() last-bit cases)"
+    return n_bad
