@@ -64,9 +64,12 @@ def parse(argv=None):
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--frame-step", type=int, default=1, help="use every n-th 30 Hz pose")
     ap.add_argument("--max-range", type=float, default=6.0, help="metres; sizes the slab halo")
-    ap.add_argument("--slabs", default="balanced", choices=["balanced", "uniform"],
-                    help="N > 1: balanced = x-slabs of equal expected WORK (tsdf_slab_range_weighted on the view frustum of the reference's "
-                         "initial pose, camera_tracking.cpp:5-7: thin slabs where the camera looks); uniform = equal thickness (tsdf_slab_range)")
+    ap.add_argument("--slabs", default="auto", choices=["auto", "path", "balanced", "uniform"],
+                    help="N > 1: path = x-slabs of equal expected WORK over the PLANNED camera path (tsdf_slab_range_weighted on view-frustum "
+                         "weights accumulated over the poses this run will visit: thin slabs where the camera looks, along the whole path); "
+                         "auto (default) = path when the path is known (it is here: the ground-truth trajectory), uniform otherwise; "
+                         "balanced = the weights of the reference's initial pose only (camera_tracking.cpp:5-7; round 5's default: good "
+                         "for the first ~100 frames, worse than uniform 480 frames down the path); uniform = equal thickness (tsdf_slab_range)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -197,7 +200,7 @@ def free_run_compare(args, ts, orc, K, frames, m, width, height, n, track_thread
     ot.set_K(K)
     xyz, nrm, rgb = frames[0]
     n_upd = [oo.update(ot, orc.Cloud(xyz, nrm, rgb), with_color=color, threads=update_threads)]
-    iters, stops, poses = [], [], [ot.trans.copy()]
+    iters, stops, poses, rots = [], [], [ot.trans.copy()], [ot.rot.copy()]
     t_track = t_upd = 0.0
     done = 0
     t_all = time.perf_counter()
@@ -211,17 +214,51 @@ def free_run_compare(args, ts, orc, K, frames, m, width, height, n, track_thread
         t2 = time.perf_counter()
         t_track += t1 - t0
         t_upd += t2 - t1
-        iters.append(so["iterations"]); stops.append(bool(so["stopped"])); poses.append(ot.trans.copy())
+        iters.append(so["iterations"]); stops.append(bool(so["stopped"])); poses.append(ot.trans.copy()); rots.append(ot.rot.copy())
         done += 1
         if time.perf_counter() - t_all > time_limit_s:
             break
     timing = {"frames": done, "track_s": t_track, "update_s": t_upd}
-    # the same frames through the C ABI (host planes)
+    # the same frames through the C ABI (host planes), twice:
+    #   free-running   every pose the HIP tracker estimates feeds its next integration, as in production.  The poses drift
+    #                  apart by ~1e-13 m (another summation order of the normal equations), which now and then flips the f32
+    #                  rounding of a voxel's distance: D may differ by an ulp of that distance ANYWHERE (bar: SURVEY 8c's
+    #                  2e-6 m), W and the colour weights do not depend on the distance's last bit.
+    #   teacher-forced every frame is tracked from the ORACLE's previous pose and integrated at the ORACLE's new pose: same
+    #                  inputs to every kernel call, so every array must be bit-identical except in voxels that took the
+    #                  exp() weight (the oracle records them), and every tracked pose within 1e-9 of the oracle's.
+    mask = oo.exp_mask
+
+    def differing(got, want):
+        idx = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+        if idx.size:                                     # +0 / -0 and NaN payloads are not differences
+            a, b = got[idx], want[idx]
+            idx = idx[~(((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b)))]
+        if not idx.size:
+            return {"voxels": 0, "max_ulp": 0, "max_abs": 0.0, "outside_the_exp_band": 0}
+        a, b = got[idx], want[idx]
+        ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+        ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia); ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+        return {"voxels": int(idx.size), "max_ulp": int(np.max(np.abs(ia - ib))),
+                "max_abs": float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))),
+                "outside_the_exp_band": int((mask[idx] == 0).sum())}
+
+    def compare_volume(gs):
+        D, W = gs.download()
+        arrays = {"W": differing(W, oo.W), "D": differing(D, oo.D)}
+        del D, W
+        if color:
+            for name, got, want in zip(("Color_W", "R", "G", "B"), gs.download_color(), (oo.Color_W, oo.R, oo.G, oo.B)):
+                arrays[name] = differing(got, want)
+        return arrays
+    col = (lambda f: f) if color else (lambda f: (f[0], f[1], None))
+    parity = {"frames": done + 1, "m": m, "image": [width, height], "carry_threads": track_threads,
+              "voxels": int(oo.W.size), "voxels_that_took_the_exp_weight": int(mask.sum())}
+    # ---- free-running
     gs = ts.SDF(m, with_color=color, device=dev_index, carry_threads=track_threads)
     gt = ts.CameraTracking(sdf=gs)
     gt.set_K(K)
     try:
-        col = (lambda f: f) if color else (lambda f: (f[0], f[1], None))
         g_upd = [gs.update(gt, *col(frames[0]))["n_updated"]]
         g_iters, g_stops, gaps = [], [], []
         for k in range(1, done + 1):
@@ -229,47 +266,52 @@ def free_run_compare(args, ts, orc, K, frames, m, width, height, n, track_thread
             g_upd.append(gs.update(gt, *col(frames[k]))["n_updated"])
             g_iters.append(int(sg["iterations"])); g_stops.append(bool(sg["stopped"]))
             gaps.append(float(np.max(np.abs(gt.trans - poses[k]))))
-        # the volumes at the end of the sample, every array, bit for bit
-        D, W = gs.download()
-        mask = oo.exp_mask
-
-        def differing(got, want):
-            idx = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
-            if idx.size:                                     # +0 / -0 and NaN payloads are not differences
-                a, b = got[idx], want[idx]
-                idx = idx[~(((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b)))]
-            if not idx.size:
-                return {"voxels": 0, "max_ulp": 0, "max_abs": 0.0, "outside_the_exp_band": 0}
-            a, b = got[idx], want[idx]
-            ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
-            ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia); ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
-            return {"voxels": int(idx.size), "max_ulp": int(np.max(np.abs(ia - ib))),
-                    "max_abs": float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))),
-                    "outside_the_exp_band": int((mask[idx] == 0).sum())}
-        arrays = {"W": differing(W, oo.W), "D": differing(D, oo.D)}
-        del D, W
-        if color:
-            for name, got, want in zip(("Color_W", "R", "G", "B"), gs.download_color(), (oo.Color_W, oo.R, oo.G, oo.B)):
-                arrays[name] = differing(got, want)
-        parity = {"frames": done + 1, "m": m, "image": [width, height], "carry_threads": track_threads,
-                  "iterations_equal": g_iters == iters, "stop_flags_equal": g_stops == stops,
-                  "n_updated_equal": g_upd == n_upd[:done + 1],
-                  "iteration_mismatches": int(sum(a != b for a, b in zip(g_iters, iters))),
-                  "n_updated_mismatches": int(sum(a != b for a, b in zip(g_upd, n_upd))),
-                  "max_pose_gap_m": max(gaps) if gaps else 0.0,
-                  "pose_gap_bar_m": 1e-5 if done <= 10 else 1e-4,
-                  "voxels": int(oo.W.size), "voxels_that_took_the_exp_weight": int(mask.sum()),
-                  "arrays": arrays,
-                  "voxels_with_other_W_bits": arrays["W"]["voxels"], "max_W_ulp": arrays["W"]["max_ulp"],
-                  "voxels_with_other_D_bits": arrays["D"]["voxels"], "max_D_ulp": arrays["D"]["max_ulp"], "max_abs_D_m": arrays["D"]["max_abs"],
-                  "differences_outside_the_exp_band": int(sum(v["outside_the_exp_band"] for v in arrays.values())),
-                  "bars": "iterations, stop flags, n_updated equal per frame; pose gap <= pose_gap_bar_m; every array bit-identical "
-                          "except in voxels that took the exp() weight (W <= 1 ulp, D and colour <= 4 ulp there; SURVEY 8c: D abs <= 2e-6 m)"}
-        parity["ok"] = bool(parity["iterations_equal"] and parity["stop_flags_equal"] and parity["n_updated_equal"]
-                            and parity["max_pose_gap_m"] <= parity["pose_gap_bar_m"] and parity["differences_outside_the_exp_band"] == 0
-                            and arrays["W"]["max_ulp"] <= 1 and all(v["max_ulp"] <= 4 for v in arrays.values()) and arrays["D"]["max_abs"] <= 2e-6)
+        arrays = compare_volume(gs)
     finally:
         gs.close()
+    n_vox = float(oo.W.size)
+    free = {"iterations_equal": g_iters == iters, "stop_flags_equal": g_stops == stops, "n_updated_equal": g_upd == n_upd[:done + 1],
+            "iteration_mismatches": int(sum(a != b for a, b in zip(g_iters, iters))),
+            "n_updated_mismatches": int(sum(a != b for a, b in zip(g_upd, n_upd))),
+            "max_pose_gap_m": max(gaps) if gaps else 0.0, "pose_gap_bar_m": 1e-5 if done <= 10 else 1e-4, "arrays": arrays,
+            "bars": "iterations, stop flags, n_updated equal per frame; pose gap <= pose_gap_bar_m; W <= 1 ulp; D abs <= 2e-6 m (SURVEY 8c); "
+                    "colour lanes <= 4 ulp; fewer than 1e-5 of the voxels differ in any array"}
+    free["ok"] = bool(free["iterations_equal"] and free["stop_flags_equal"] and free["n_updated_equal"]
+                      and free["max_pose_gap_m"] <= free["pose_gap_bar_m"] and arrays["W"]["max_ulp"] <= 1 and arrays["D"]["max_abs"] <= 2e-6
+                      and all(arrays[k]["max_ulp"] <= 4 for k in arrays if k not in ("D", "W"))
+                      and all(v["voxels"] / n_vox < 1e-5 for v in arrays.values()))
+    parity["free_running"] = free
+    # ---- teacher-forced (the oracle's run is replayed: its poses are the inputs)
+    gs = ts.SDF(m, with_color=color, device=dev_index, carry_threads=track_threads)
+    gt = ts.CameraTracking(sdf=gs)
+    gt.set_K(K)
+    try:
+        t_upd = [gs.update(gt, *col(frames[0]))["n_updated"]]
+        t_iters, t_gaps = [], []
+        for k in range(1, done + 1):
+            gt.set_camera_transformation(rots[k - 1], poses[k - 1])
+            sg = gt.estimate_new_position(gs, frames[k][0])
+            t_iters.append(int(sg["iterations"]))
+            t_gaps.append(float(max(np.max(np.abs(gt.trans - poses[k])), np.max(np.abs(gt.rot - rots[k])))))
+            gt.set_camera_transformation(rots[k], poses[k])
+            t_upd.append(gs.update(gt, *col(frames[k]))["n_updated"])
+        arrays_t = compare_volume(gs)
+    finally:
+        gs.close()
+    forced = {"iterations_equal": t_iters == iters, "n_updated_equal": t_upd == n_upd[:done + 1], "max_pose_gap_one_call": max(t_gaps) if t_gaps else 0.0,
+              "pose_gap_bar": 1e-9, "arrays": arrays_t,
+              "differences_outside_the_exp_band": int(sum(v["outside_the_exp_band"] for v in arrays_t.values())),
+              "bars": "every estimate_new_position from the oracle's pose: same iterations, pose and rotation <= 1e-9; every update at the oracle's "
+                      "pose: n_updated equal, every array bit-identical except in voxels that took the exp() weight (W <= 1 ulp, D and colour <= 4 ulp there)"}
+    forced["ok"] = bool(forced["iterations_equal"] and forced["n_updated_equal"] and forced["max_pose_gap_one_call"] <= 1e-9
+                        and forced["differences_outside_the_exp_band"] == 0 and arrays_t["W"]["max_ulp"] <= 1
+                        and all(v["max_ulp"] <= 4 for v in arrays_t.values()))
+    parity["teacher_forced"] = forced
+    parity["ok"] = bool(free["ok"] and forced["ok"])
+    # (the flat fields round 5's line carried, from the free-running run)
+    parity.update({"iterations_equal": free["iterations_equal"], "stop_flags_equal": free["stop_flags_equal"], "n_updated_equal": free["n_updated_equal"],
+                   "max_pose_gap_m": free["max_pose_gap_m"], "voxels_with_other_W_bits": arrays["W"]["voxels"], "max_W_ulp": arrays["W"]["max_ulp"],
+                   "voxels_with_other_D_bits": arrays["D"]["voxels"], "max_D_ulp": arrays["D"]["max_ulp"], "max_abs_D_m": arrays["D"]["max_abs"]})
     return timing, parity
 
 
@@ -445,16 +487,22 @@ def run(args):
     class Leg:
         """One volume (this rank's slab) + the frame loop of sdf_reconstruction.cpp:69-74 over a list of frames."""
 
-        def __init__(self, m, w, h, K):
+        def __init__(self, m, w, h, K, path=None):
             self.m, self.w, self.h = m, w, h
             cfg0 = ts.default_config(m=m)
             self.halo = ts.halo_for(cfg0, args.max_range) if world > 1 else 0
-            if world > 1 and args.slabs == "balanced":
-                # every rank computes the same cuts: frustum of the reference's initial pose, up to the sensor's 5 m
+            policy = args.slabs if args.slabs != "auto" else ("path" if path is not None else "uniform")
+            if world > 1 and policy == "path" and path is not None:
+                # every rank computes the same cuts: the frusta of the poses this run will visit, up to the sensor's 5 m;
+                # boundaries that minimise the path-average of the busiest rank (tracking_sdf_amd.slab_cuts_for_path)
+                cuts = ts.slab_cuts_for_path(cfg0, K, w, h, path[0], path[1], world, self.halo, 5.0)
+                x0, x1 = cuts[rank], cuts[rank + 1]
+            elif world > 1 and policy == "balanced":
                 wts = ts.frustum_layer_weights(cfg0, K, w, h, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1], 5.0)
                 x0, x1 = ts.slab_range_weighted(m, world, rank, self.halo, wts)
             else:
                 x0, x1 = ts.slab_range(m, world, rank)
+            self.slab_policy = policy if world > 1 else None
             self.slab = (x0, x1)
             self.sdf = ts.SDF(m, with_color=not args.no_color, slab=(x0, x1), halo=self.halo, device=dev_index)
             self.trk = ts.CameraTracking(sdf=self.sdf)
@@ -493,6 +541,36 @@ def run(args):
                 self.sdf_has_queued = k + 1 < len(fr)
                 if self.sdf_has_queued:
                     q(k + 1)
+            elif mode == "caller_copies":
+                # What a caller with page-locked frames can do with the DEVICE-frame entry point today: copy frames k+1 and k+2
+                # itself, on a stream of its own, into a ring of device buffers while frame k is processed, and hand each over with
+                # tsdf_set_frame_device once its copy is complete (host = the pinned tensors).  A ring slot is reused only after
+                # tsdf_device_frame_released() says the library has packed the frame that was in it.
+                st = getattr(self, "_cc", None)
+                if st is None or st["host"] is not host:
+                    n_slot = 4
+                    st = self._cc = {"host": host, "stream": torch.cuda.Stream(device=dev), "ev": [torch.cuda.Event() for _ in range(n_slot)],
+                                     "ring": [tuple(torch.empty_like(t, device=dev) for t in host[0]) for _ in range(n_slot)],
+                                     "serial": [0] * n_slot, "issued": -1, "n": n_slot}
+                def issue(i):
+                    slot = i % st["n"]
+                    while st["serial"][slot] and L.tsdf_device_frame_released(self.sdf._h) < st["serial"][slot]:
+                        pass
+                    with torch.cuda.stream(st["stream"]):
+                        for dst, src in zip(st["ring"][slot], host[i]):
+                            dst.copy_(src, non_blocking=True)
+                        st["ev"][slot].record(st["stream"])
+                    st["issued"] = i
+                if k == 0:
+                    st["issued"] = -1
+                    st["serial"] = [0] * st["n"]
+                for i in range(st["issued"] + 1, min(k + 3, len(host))):
+                    issue(i)
+                slot = k % st["n"]
+                st["ev"][slot].synchronize()
+                dx, dn, dc = st["ring"][slot]
+                self.sdf._check(f_set(self.sdf._h, C.c_void_p(dx.data_ptr()), C.c_void_p(dn.data_ptr()), C.c_void_p(dc.data_ptr()), self.w, self.h))
+                st["serial"][slot] = int(L.tsdf_frame_serial(self.sdf._h))
             elif mode == "host":
                 self.sdf.set_frame(*host[k])
             elif mode == "aos":
@@ -585,8 +663,9 @@ def run(args):
     n_frames = 1 + args.warmup + args.steps
     seq, d_frames = render_frames(width, height, n_frames, args.frame_step,
                                   np.array(FR3_K) if args.config == 4 and (width, height) == (640, 480) else None)
-    leg = Leg(m, width, height, seq.K)
+    leg = Leg(m, width, height, seq.K, (seq.R[:n_frames], seq.t[:n_frames]))
     leg_slab0 = leg.slab
+    leg_slab_policy = leg.slab_policy
     sdf = leg.sdf
     halo_main = leg.halo
 
@@ -789,6 +868,10 @@ def run(args):
         extras["h2d_inclusive_note"] = ("best of two repetitions; xyz + normals + rgb (27 B/pixel) handed over as HOST buffers every frame through "
                                         "tsdf_set_frame, one frame at a time: the tracker's 34 240 samples are copied first and its passes run "
                                         "under the planes' copy (round 5); staging copy + H2D + pack on the frame side stream")
+        extras["value_h2d_inclusive_caller_side_copies"] = args.steps / best_of_two("caller_copies", pinned_keep)
+        extras["caller_side_copies_note"] = ("page-locked frames copied by the CALLER on a stream of its own, two frames ahead, into a ring of four device "
+                                             "buffers, each handed over with tsdf_set_frame_device when its copy is complete and reused once "
+                                             "tsdf_device_frame_released reports it packed: the PCIe copy is in the loop, the library sees device frames")
         e2p = best_of_two("host", pinned_frames)
         extras["value_h2d_inclusive_pinned_buffers"] = args.steps / e2p
         extras["h2d_inclusive_pinned_note"] = ("the same with the caller's buffers page-locked: tsdf_set_frame copies from them "
@@ -947,7 +1030,7 @@ def run(args):
         leg5 = None
         try:
             seq5, fr5 = render_frames(w5, h5, 1 + args.warmup + args.steps, 1)
-            leg5 = Leg(m5, w5, h5, seq5.K)
+            leg5 = Leg(m5, w5, h5, seq5.K, (seq5.R[:len(fr5)], seq5.t[:len(fr5)]))
             if world > 1:
                 k = state["kind"]
                 setup_exchange(leg5.sdf, {v: k2 for k2, v in KIND.items()}.get(k, "torch"))
@@ -1010,10 +1093,10 @@ def run(args):
                                    f"pillars/domes/furniture), {width}x{height} depth with Kinect noise + 2% holes, "
                                    f"{m}^3 voxels, 6x6x3.5 m volume, colour lanes {'off' if args.no_color else 'on'}; "
                                    f"TUM images are not available on the box",
-                       "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}" + (f" ({args.slabs} slabs, rank 0 owns layers [{leg_slab0[0]}, {leg_slab0[1]}))" if world > 1 else ""),
+                       "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}" + (f" ({leg_slab_policy} slabs, rank 0 owns layers [{leg_slab0[0]}, {leg_slab0[1]}))" if world > 1 else ""),
                        "halo": halo_main,
                        "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us,
-                       "exchange_trial_frames_per_s": exchange_trial, "slabs": args.slabs if world > 1 else None},
+                       "exchange_trial_frames_per_s": exchange_trial, "slabs": leg_slab_policy},
             "ate_rmse_m": ate, "ate_frames": len(est_main) - 1, "abs_trajectory_rmse_m": raw,
             "gn_iterations_per_frame": cn["track_iterations"] / max(1, cn["track_calls"]),
             "stage_ms_per_frame": {"track_wall": 1e3 * track_wall_main / args.steps,

@@ -40,9 +40,11 @@ def main():
     ap.add_argument("--frame-step", type=int, default=2)
     ap.add_argument("--passes", type=int, default=60)
     ap.add_argument("--max-range", type=float, default=6.0)
-    ap.add_argument("--slabs", default="uniform", choices=["uniform", "balanced"],
+    ap.add_argument("--slabs", default="uniform", choices=["uniform", "balanced", "path"],
                     help="uniform: tsdf_slab_range (equal thickness); balanced: tsdf_slab_range_weighted on the frustum weights of the "
-                         "reference's initial pose (what bench.py --slabs balanced does)")
+                         "reference's initial pose; path: on the weights accumulated over the WHOLE fr1/plant path (what bench.py's "
+                         "default --slabs auto does with the path it is going to run)")
+    ap.add_argument("--start-frame", type=int, default=0, help="where on the fr1/plant path the fused frames start (0, 480, 1000 ...)")
     ap.add_argument("--passes-per-frame", type=float, default=3.1, help="Gauss-Newton passes per frame of the bench stream (driver line)")
     ap.add_argument("--exchange-us", type=float, nargs="*", default=[0.0, 4.0, 10.0, 25.0],
                     help="exchange step per pass to evaluate the model at (us): 0 = none, ~4 = host fan-in through shared memory, "
@@ -56,11 +58,17 @@ def main():
     m8, weak, w, h = SHAPES[args.shape]
     dev = torch.device("cuda", 0)
     K = np.array(FR3_K) if args.shape == "config4" else None
-    seq = synth.Sequence(n_frames=args.frames, width=w, height=h, noise=True, holes=0.02, step=args.frame_step, K=K)
-    d = [seq.frame_torch(k, dev) for k in range(args.frames)]
+    full = synth.Sequence(n_frames=None, width=w, height=h, noise=True, holes=0.02, K=K)           # the whole 1246-pose path
+    n_need = args.start_frame + args.frames * args.frame_step
+    if n_need > len(full):
+        raise SystemExit(f"--start-frame {args.start_frame}: the path has {len(full)} poses")
+    seq = full
+    pick = [args.start_frame + k * args.frame_step for k in range(args.frames)]
+    seq_R = [full.R[i] for i in pick]; seq_t = [full.t[i] for i in pick]
+    d = [full.frame_torch(i, dev) for i in pick]
     torch.cuda.synchronize()
     out = {"what": __doc__.split("\n\n")[0], "shape": args.shape, "image": [w, h], "frames_fused": args.frames,
-           "passes_timed": args.passes, "colour": True, "slabs": args.slabs, "by_ranks": {}}
+           "passes_timed": args.passes, "colour": True, "slabs": args.slabs, "start_frame": args.start_frame, "by_ranks": {}}
     for n in args.ranks:
         m = m8 if not weak else int(round(m8 * (n / 8.0) ** (1.0 / 3.0) / 2.0)) * 2
         halo = ts.halo_for(ts.default_config(m=m), args.max_range) if n > 1 else 0
@@ -68,8 +76,11 @@ def main():
         weights = None
         if args.slabs == "balanced" and n > 1:
             weights = ts.frustum_layer_weights(ts.default_config(m=m), seq.K, w, h, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1])
+        cuts = None
+        if args.slabs == "path" and n > 1:
+            cuts = ts.slab_cuts_for_path(ts.default_config(m=m), seq.K, w, h, full.R, full.t, n, halo)
         for r in range(n):
-            x0, x1 = ts.slab_range(m, n, r) if weights is None else ts.slab_range_weighted(m, n, r, halo, weights)
+            x0, x1 = (cuts[r], cuts[r + 1]) if cuts is not None else ts.slab_range(m, n, r) if weights is None else ts.slab_range_weighted(m, n, r, halo, weights)
             sdf = ts.SDF(m, with_color=True, slab=(x0, x1), halo=halo)
             trk = ts.CameraTracking(sdf=sdf)
             trk.set_K(seq.K)
@@ -79,7 +90,7 @@ def main():
                 sdf.read_counters(reset=True)
                 per_frame = []
                 for k in range(args.frames):
-                    trk.set_camera_transformation(seq.R[k], seq.t[k])
+                    trk.set_camera_transformation(seq_R[k], seq_t[k])
                     sdf.set_frame_device(d[k][0].data_ptr(), d[k][1].data_ptr(), d[k][2].data_ptr(), w, h)
                     t0 = time.perf_counter()
                     sdf.update(want_stats=False)
@@ -89,7 +100,7 @@ def main():
                 tm, cn = sdf.read_timing(), sdf.read_counters()
             sdf.set_timing(False)
             k = args.frames - 1
-            trk.set_camera_transformation(seq.R[k], seq.t[k] + np.array([0.004, -0.003, 0.002]))
+            trk.set_camera_transformation(seq_R[k], seq_t[k] + np.array([0.004, -0.003, 0.002]))
             sdf.set_frame_device(d[k][0].data_ptr(), d[k][1].data_ptr(), d[k][2].data_ptr(), w, h)
             for _ in range(5):
                 trk.accumulate()

@@ -467,13 +467,18 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         const bool actA = owned && q < 7, actB = owned && q < 6;
         Vol V{dw, p.g.m, p.g.xs, p.g.xe};
         double ax = sg.vx, ay = sg.vy, az = sg.vz;
-        if (q >= 1 && q < 7) {
-            const int a = (q - 1) >> 1;
-            const double step = ((q - 1) & 1) ? -(double)p.v_h : (double)p.v_h;
+#ifdef TSDF_TRACK_DUP      // EXPERIMENT (round 6): lanes without a look-up repeat the address of a NEIGHBOURING lane of their quad
+        const int qA = q < 7 ? q : 6, qB = q < 6 ? q : 5;
+#else
+        const int qA = q < 7 ? q : 0, qB = q < 6 ? q : 0;
+#endif
+        if (qA >= 1) {
+            const int a = (qA - 1) >> 1;
+            const double step = ((qA - 1) & 1) ? -(double)p.v_h : (double)p.v_h;
             ax += (a == 0) ? step : 0.0; ay += (a == 1) ? step : 0.0; az += (a == 2) ? step : 0.0;
         }
         double bx, by, bz;
-        voxel_of(p, &s_rpm[9 * (q < 6 ? q : 0)], sg, bx, by, bz);
+        voxel_of(p, &s_rpm[9 * qB], sg, bx, by, bz);
         Lookup LA, LB;
         unsigned violA = 0u, violB = 0u;
         lookup_issue(V, ax, ay, az, LA, violA);
