@@ -191,30 +191,10 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
         }                                                                                             \
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
-    {
-        // EXPERIMENT (round 6): how the frame-side stream (uploads' pack kernels, depth pre-processing) shares the chip with the
-        // main stream's latency-bound tracker passes.  TSDF_FRAME_STREAM = prio: main stream at the highest, frame stream at the
-        // lowest queue priority; mask:<n>: the frame stream's kernels are confined to every n-th CU (hipExtStreamCreateWithCUMask).
-        const char* fs = std::getenv("TSDF_FRAME_STREAM");
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (fs && std::strncmp(fs, "prio", 4) == 0) {
-            CREATE_TRY(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi));
-            CREATE_TRY(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, lo));
-        } else if (fs && std::strncmp(fs, "mask:", 5) == 0) {
-            const int every = std::atoi(fs + 5) > 1 ? std::atoi(fs + 5) : 4;
-            hipDeviceProp_t prop;
-            CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
-            const int ncu = prop.multiProcessorCount;
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            for (int i = 0; i < ncu; ++i) if (((i % 8) + (i / 8)) % every == 0) mask[(size_t)i / 32] |= 1u << (i % 32);
-            CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-            CREATE_TRY(hipExtStreamCreateWithCUMask(&h->fstream, (uint32_t)mask.size(), mask.data()));
-        } else {
-            CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-            CREATE_TRY(hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking));
-        }
-    }
+    // (Stream priorities -- main stream highest, frame stream lowest -- and a CU mask on the frame stream were measured in
+    // round 6: no gain / a loss for every host-frame path, profiles/r06_frame_stream_policies.json.)
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_samples, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
@@ -345,6 +325,7 @@ void tsdf_destroy(tsdf_handle* h) {
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
     if (h->ev_samples) (void)hipEventDestroy(h->ev_samples);
     if (h->ev_queued) (void)hipEventDestroy(h->ev_queued);
+    for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) if (h->ev_qblk[b]) (void)hipEventDestroy(h->ev_qblk[b]);
     for (int b = 0; b < 2; ++b) if (h->ev_stage_done[b]) (void)hipEventDestroy(h->ev_stage_done[b]);
     if (h->partials) (void)hipFree(h->partials);
     if (h->red_dev) (void)hipFree(h->red_dev);

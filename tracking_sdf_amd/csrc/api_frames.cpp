@@ -42,6 +42,9 @@ void free_frame(tsdf_handle* h) {
     for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
     h->pin_samples_cap = 0;
     h->tracked = tsdf_handle::TrackedCloud();
+    for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) { if (h->qblk[b]) (void)hipFree(h->qblk[b]); h->qblk[b] = nullptr; h->qblk_serial[b] = 0; }
+    h->qblk_cap = 0;
+    h->staged_planes[0] = h->staged_planes[1] = nullptr;
     h->in_xyz = h->in_nrm = nullptr; h->in_rgb = nullptr;
     h->pin_xyz = h->pin_nrm = nullptr; h->pin_rgb = nullptr;
     h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
@@ -306,8 +309,9 @@ HostPool* host_pool(tsdf_handle* h) {
 // the queue: 8 chunks 2490 frames/s, 4 chunks 3450, 2 chunks 4010, 1 chunk = 3 copies 4140).  Default now: one chunk,
 // and the three planes in one block = ONE copy per frame.  TSDF_STAGE_CHUNKS keeps the pipelined form for large images.
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
-                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset) {
+                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset, const DevPlanes* dst) {
     constexpr int kMaxChunks = 16;
+    float* const d_xyz = dst ? dst->xyz : h->in_xyz; float* const d_nrm = dst ? dst->nrm : h->in_nrm; uint8_t* const d_rgb = dst ? dst->rgb : h->in_rgb;
     // TSDF_STAGE_CHUNKS overrides; otherwise the caller's choice: 1 where only throughput counts (the frame queue), 2 where
     // the frame's LATENCY to the device is on the critical path (tsdf_track_frame_aos: medians 2570 / 2850 / 2790 / 2760
     // frames/s with 1 / 2 / 3 / 4 pieces, six alternations)
@@ -330,12 +334,12 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
         struct Tail { const bool on; const clk::time_point t0; double& acc; ~Tail() { if (on) acc += std::chrono::duration<double, std::nano>(clk::now() - t0).count(); } } tail{prof, tu, upload_ns};
         if (kChunks == 1 && has_xyz && has_nrm) {            // the whole frame: the planes are neighbours in both blocks -> one copy
             const size_t bytes = has_rgb ? frame_block_bytes(h->in_cap) - (h->in_cap - npix) * 3 : 2 * plane_stride_bytes(h->in_cap);
-            err = hipMemcpyAsync(h->in_xyz, h->pin_xyz, bytes, hipMemcpyHostToDevice, h->fstream);
+            err = hipMemcpyAsync(d_xyz, h->pin_xyz, bytes, hipMemcpyHostToDevice, h->fstream);
             return;
         }
-        if (has_xyz) err = hipMemcpyAsync(h->in_xyz + 3 * i0, h->pin_xyz + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
-        if (has_nrm && err == hipSuccess) err = hipMemcpyAsync(h->in_nrm + 3 * i0, h->pin_nrm + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
-        if (has_rgb && err == hipSuccess) err = hipMemcpyAsync(h->in_rgb + 3 * i0, h->pin_rgb + 3 * i0, n * 3, hipMemcpyHostToDevice, h->fstream);
+        if (has_xyz) err = hipMemcpyAsync(d_xyz + 3 * i0, h->pin_xyz + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
+        if (has_nrm && err == hipSuccess) err = hipMemcpyAsync(d_nrm + 3 * i0, h->pin_nrm + 3 * i0, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream);
+        if (has_rgb && err == hipSuccess) err = hipMemcpyAsync(d_rgb + 3 * i0, h->pin_rgb + 3 * i0, n * 3, hipMemcpyHostToDevice, h->fstream);
     };
     HostPool* const pool = host_pool(h);
     const std::function<void(int, int)> job = [&](int part, int parts) {
@@ -395,13 +399,13 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
             if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
         }));
-        h->staged_xyz = true;
+        h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
         return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
     }
     HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
     if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
-    h->staged_xyz = true;
+    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
     HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
     rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
     if (rc) return rc;
@@ -446,6 +450,41 @@ int ensure_second_staging_set(tsdf_handle* h, size_t npix) {
 }  // namespace tsdf_api
 
 namespace {
+// A block of the queue's ring for the frame that is being queued: allocated on first use (same layout as the in_xyz | in_nrm |
+// in_rgb block), free of the frame it held before -- that frame's planes were packed by its own integrate launch, which
+// publishes a release ticket (tsdf_device_frame_released's mechanism); two frames later it has long run, so the wait below
+// is a formality, bounded and backed by a real synchronisation.
+int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes) {
+    if (h->qblk_cap != h->in_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) { if (h->qblk[b]) (void)hipFree(h->qblk[b]); h->qblk[b] = nullptr; h->qblk_serial[b] = 0; }
+        h->qblk_cap = 0;
+        for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) {
+            HIP_TRY(h, hipMalloc((void**)&h->qblk[b], frame_block_bytes(h->in_cap)));
+            if (!h->ev_qblk[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_qblk[b], hipEventDisableTiming));
+        }
+        h->qblk_cap = h->in_cap;
+    }
+    const int b = h->qblk_next;
+    h->qblk_next = (b + 1) % tsdf_handle::kQueueBlocks;
+    if (h->qblk_serial[b]) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; released_serial(h) < h->qblk_serial[b]; ++spins)
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));      // (a frame that was never integrated keeps its block until here)
+                break;
+            }
+        h->qblk_serial[b] = 0;
+    }
+    const size_t plane = plane_stride_bytes(h->in_cap);
+    planes->xyz = reinterpret_cast<float*>(h->qblk[b]);
+    planes->nrm = reinterpret_cast<float*>(h->qblk[b] + plane);
+    planes->rgb = reinterpret_cast<uint8_t*>(h->qblk[b] + 2 * plane);
+    *blk = b;
+    return TSDF_OK;
+}
+
 // what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
 int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
                        bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
@@ -459,18 +498,18 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     const size_t npix = (size_t)width * height;
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess; q.rc = TSDF_OK;
-    h->staged_xyz = false;                   // in_xyz / in_nrm / in_rgb are about to hold the QUEUED frame, not the current one
-    pick_pixel_layout(h, &q.su, &q.sv);      // from the pose of this moment: only the order of the records depends on it
-    rc = wait_buffer_free(h, q.nb, h->fstream);
+    q.deferred = q.packed = false;
+    // The frame's planes go into a block of the queue's ring and stay there, unpacked, until the frame is current: its own
+    // integrate launch packs them (tsdf_next_frame -> defer_pack).  Nothing but the copy runs on the frame stream.
+    DevPlanes dst;
+    rc = acquire_queue_block(h, &q.blk, &dst);
     if (rc) return rc;
-    const PackArgs pa = pack_args(h, h->in_xyz, has_nrm ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, q.su, q.sv, q.nb);
+    const int blk = q.blk;
     if (q.direct) {
-        HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
-        if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
-        if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
-        HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
-        HIP_TRY(h, launch_pack(h->fstream, pa));
-        HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
+        HIP_TRY(h, hipMemcpyAsync(dst.xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        if (nrm) HIP_TRY(h, hipMemcpyAsync(dst.nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+        if (rgb) HIP_TRY(h, hipMemcpyAsync(dst.rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+        HIP_TRY(h, hipEventRecord(h->ev_qblk[blk], h->fstream));
         q.active = true;
         return TSDF_OK;
     }
@@ -487,7 +526,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     {
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
-        h->qjob = [h, npix, has_nrm, has_rgb, fill, pa, t_queued] {
+        h->qjob = [h, npix, has_nrm, has_rgb, fill, dst, blk, t_queued] {
             const auto ts0 = std::chrono::steady_clock::now();
             if (h->sp.on) h->sp.handoff += std::chrono::duration<double, std::nano>(ts0 - t_queued).count();
             // switch to the other staging set (fill and stage_and_upload read h->pin_* when they run)
@@ -495,10 +534,9 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
             std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
             hipError_t e = h->stage_recorded[0] ? hipEventSynchronize(h->ev_stage_done[0]) : hipSuccess;
             if (h->sp.on) h->sp.sync_before += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ts0).count();
-            if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill);
+            if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill, 1, &dst);
             if (e == hipSuccess) { e = hipEventRecord(h->ev_stage_done[0], h->fstream); h->stage_recorded[0] = e == hipSuccess; }
-            if (e == hipSuccess) e = launch_pack(h->fstream, pa);
-            if (e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
+            if (e == hipSuccess) e = hipEventRecord(h->ev_qblk[blk], h->fstream);
             h->queued.err = e;
         };
     }
@@ -597,6 +635,33 @@ int tsdf_next_frame(tsdf_handle* h) {
         h->frame_has_rgb = q.has_rgb;
         return TSDF_OK;
     }
+    if (!from_device && q.blk >= 0) {
+        // a host / depth frame whose planes sit in a block of the queue's ring: it becomes current the way a frame handed
+        // over in device memory does (deferred packing), once the caller's buffers have been read
+        const int blk = q.blk;
+        q.blk = -1;
+        if (q.direct) {
+            HIP_TRY(h, hipEventSynchronize(h->ev_qblk[blk]));
+        } else {
+            const auto tw0 = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> g(h->qmu);
+            h->qcv.wait(g, [&] { return !h->qbusy; });       // the staging thread is done with the caller's buffers
+            if (h->sp.on) h->sp.next_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
+            if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; h->err = q.msg; return r; }
+            if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
+        }
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_qblk[blk], 0));   // the first tracker pass and the integrate launch read the planes
+        const size_t plane = plane_stride_bytes(h->in_cap);
+        const float* const bx = reinterpret_cast<const float*>(h->qblk[blk]);
+        const float* const bn = reinterpret_cast<const float*>(h->qblk[blk] + plane);
+        const uint8_t* const bc = reinterpret_cast<const uint8_t*>(h->qblk[blk] + 2 * plane);
+        rc = h->defer_device_pack ? defer_pack(h, bx, q.has_nrm ? bn : nullptr, q.has_rgb ? bc : nullptr)
+                                  : run_pack(h, bx, q.has_nrm ? bn : nullptr, q.has_rgb ? bc : nullptr, h->stream, true);
+        if (rc) return rc;
+        h->qblk_serial[blk] = h->frame_serial;               // the block is this frame's until the launch that packs it has run
+        h->staged_xyz = true; h->staged_planes[0] = bx; h->staged_planes[1] = bn;
+        return TSDF_OK;
+    }
     if (from_device) {
         // nothing to wait for on the host: device buffers stay borrowed as tsdf_set_frame_device's do
     } else if (q.direct) {
@@ -648,7 +713,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
     if (normals && (L->normal_stride < 12 || L->normal_offset < 0 || L->normal_offset + 12 > L->normal_stride))
         return fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: normal layout (stride %d, normal at %d) does not hold three floats",
                     L->normal_stride, L->normal_offset);
-    if (!points && !(h->have_frame && h->staged_xyz && h->fw == width && h->fh == height))
+    if (!points && !(h->have_frame && h->staged_xyz && h->staged_planes[0] == h->in_xyz && h->fw == width && h->fh == height))
         return fail(h, TSDF_E_NO_FRAME, "tsdf_set_frame_aos: normals alone complete the CURRENT host frame of the same size; there is none");
     int rc = bind_device(h);
     if (rc) return rc;
@@ -668,7 +733,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
         repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
     }));
     const bool has_rgb = points ? color : had_rgb;
-    h->staged_xyz = true;
+    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
     return run_pack(h, h->in_xyz, normals ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
 }
 
@@ -719,7 +784,7 @@ int depth_frame_prepare(tsdf_handle* h, const char* who, bool queued, const uint
 // frame afterwards.  Runs on the caller's thread (tsdf_set_depth_frame) or on the queue's library thread
 // (tsdf_queue_depth_frame): the bilateral grid's depth extent is the one host round trip of this path.
 int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
-                     int32_t width, int32_t height, const tsdf_preproc_params& pp, bool* direct_out) {
+                     int32_t width, int32_t height, const tsdf_preproc_params& pp, bool* direct_out, const DevPlanes& out) {
     const size_t npix = (size_t)width * height;
     const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
     HIP_TRY(h, hipStreamSynchronize(h->fstream));          // pinned staging may still feed the previous frame
@@ -737,7 +802,7 @@ int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, c
         HIP_TRY(h, hipMemcpyAsync(h->pin_minmax, h->pre_minmax, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->fstream));
     if (rgb) {
         if (!direct) std::memcpy(h->pin_rgb, rgb, npix * 3);
-        HIP_TRY(h, hipMemcpyAsync(h->in_rgb, direct ? rgb : h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
+        HIP_TRY(h, hipMemcpyAsync(out.rgb, direct ? rgb : h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
     }
     if (direct && !use_grid) HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
     // The grid's depth extent follows the frame's depth range: the one host round trip of this path (8 bytes).
@@ -771,7 +836,7 @@ int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, c
     const float Kf[4] = {(float)h->K[0], (float)h->K[4], (float)h->K[2], (float)h->K[5]};
     HIP_TRY(h, launch_preproc(h->fstream, width, height, Kf, use_grid && !grid_on ? 0 : pp.radius, pp.sigma_s, pp.sigma_r,
                               pp.normal_radius, pp.max_depth_change, grid_on ? &bg : nullptr, h->pre_grid_a, h->pre_grid_b,
-                              h->pre_z, h->pre_zf, h->in_xyz, h->in_nrm));
+                              h->pre_z, h->pre_zf, out.xyz, out.nrm));
     return TSDF_OK;
 }
 }  // namespace
@@ -783,9 +848,10 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
     if (rc) return rc;
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     bool direct = false;
-    rc = depth_frame_work(h, "tsdf_set_depth_frame", depth16, depthf, rgb, width, height, pp, &direct);
+    const DevPlanes own{h->in_xyz, h->in_nrm, h->in_rgb};
+    rc = depth_frame_work(h, "tsdf_set_depth_frame", depth16, depthf, rgb, width, height, pp, &direct, own);
     if (rc) return rc;
-    h->staged_xyz = true;
+    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
     rc = run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
     if (rc) return rc;
     const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
@@ -804,11 +870,11 @@ int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float*
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = true; q.has_rgb = rgb != nullptr; q.direct = false; q.device = false; q.err = hipSuccess;
     q.deferred = q.packed = false; q.rc = TSDF_OK;
-    h->staged_xyz = false;                   // in_xyz / in_nrm / in_rgb are about to hold the QUEUED frame, not the current one
-    pick_pixel_layout(h, &q.su, &q.sv);
-    rc = wait_buffer_free(h, q.nb, h->fstream);
+    // the pre-processed planes go into a block of the queue's ring and are packed by the frame's own integrate launch
+    DevPlanes dst;
+    rc = acquire_queue_block(h, &q.blk, &dst);
     if (rc) return rc;
-    const PackArgs pa = pack_args(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, q.su, q.sv, q.nb);
+    const int blk = q.blk;
     if (!h->qthread.joinable()) {
         try { h->qthread = std::thread(queue_thread_main, h); }
         catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_depth_frame: cannot start the staging thread"); }
@@ -816,14 +882,13 @@ int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float*
     {
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
-        h->qjob = [h, depth16, depthf, rgb, width, height, pp, pa] {
+        h->qjob = [h, depth16, depthf, rgb, width, height, pp, dst, blk] {
             bool direct = false;
             t_err_sink = &h->queued.msg;
-            int r = depth_frame_work(h, "tsdf_queue_depth_frame", depth16, depthf, rgb, width, height, pp, &direct);
+            int r = depth_frame_work(h, "tsdf_queue_depth_frame", depth16, depthf, rgb, width, height, pp, &direct, dst);
             t_err_sink = nullptr;
             hipError_t e = hipSuccess;
-            if (r == TSDF_OK) e = launch_pack(h->fstream, pa);
-            if (r == TSDF_OK && e == hipSuccess) e = hipEventRecord(h->ev_queued, h->fstream);
+            if (r == TSDF_OK) e = hipEventRecord(h->ev_qblk[blk], h->fstream);
             const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
             if (r == TSDF_OK && e == hipSuccess && direct && !use_grid) e = hipEventSynchronize(h->ev_copied);   // the caller's buffers have been read
             h->queued.rc = r;
@@ -839,14 +904,12 @@ int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {
     int rc = check_ready(h, true);
     if (rc) return rc;
     if (!h->in_xyz || h->in_cap < (size_t)h->fw * h->fh) return fail(h, TSDF_E_NO_FRAME, "no pre-processed frame held");
-    // the staging planes hold the CURRENT frame only until the next frame is queued (tsdf_queue_frame / _aos /
-    // tsdf_queue_depth_frame fill them with frame k+1, on the library thread and the frame stream, while frame k is current)
-    if (!h->staged_xyz)
-        return fail(h, TSDF_E_NO_FRAME, "tsdf_get_preprocessed: the planes of the current frame are no longer held (a frame is queued behind "
-                                        "it, or the frame came from device memory): read them before queueing the next frame");
+    // (a frame queued behind the current one goes into a block of its own since round 6: the current frame's planes stay)
+    if (!h->staged_xyz || !h->staged_planes[0] || !h->staged_planes[1])
+        return fail(h, TSDF_E_NO_FRAME, "tsdf_get_preprocessed: the library does not hold the planes of the current frame (it came from device memory)");
     const size_t bytes = (size_t)h->fw * h->fh * 3 * sizeof(float);
-    if (xyz) HIP_TRY(h, hipMemcpyAsync(xyz, h->in_xyz, bytes, hipMemcpyDeviceToHost, h->fstream));
-    if (nrm) HIP_TRY(h, hipMemcpyAsync(nrm, h->in_nrm, bytes, hipMemcpyDeviceToHost, h->fstream));
+    if (xyz) HIP_TRY(h, hipMemcpyAsync(xyz, h->staged_planes[0], bytes, hipMemcpyDeviceToHost, h->fstream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(nrm, h->staged_planes[1], bytes, hipMemcpyDeviceToHost, h->fstream));
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     return TSDF_OK;
 }

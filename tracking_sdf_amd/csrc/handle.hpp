@@ -57,6 +57,7 @@ struct tsdf_handle {
     // buffer the current frame does not use while the current one is tracked and integrated
     struct Queued {
         bool active = false, direct = false, device = false, has_nrm = false, has_rgb = false;
+        int blk = -1;                      // >= 0: a host / depth frame whose planes are (being) put into qblk[blk]
         // device frames with deferred packing: nothing is launched when the frame is queued; the current frame's integrate
         // launch packs it (packed = true), or it becomes current unpacked like a frame of tsdf_set_frame_device
         bool deferred = false, packed = false;
@@ -99,7 +100,20 @@ struct tsdf_handle {
     hipEvent_t ev_stage_done[2] = {nullptr, nullptr};   // [0]: the copies out of the set in use have been issued up to here; [1]: the other set's
     bool stage_recorded[2] = {false, false};
     size_t in_cap = 0;             // pixels the staging buffers hold
-    bool staged_xyz = false;       // in_xyz (and in_rgb, if frame_has_rgb) hold the CURRENT frame (host / AoS / depth frames)
+    bool staged_xyz = false;       // the library holds the planes of the CURRENT frame on the device (host / AoS / depth frames) ...
+    const float* staged_planes[2] = {nullptr, nullptr};   // ... here: xyz, nrm (in_xyz / in_nrm, or a block of the queue's ring)
+    // Frames that come through the QUEUE from host memory or as raw depth (round 6): their planes land in one of three
+    // device blocks (same layout as in_xyz | in_nrm | in_rgb) and are packed like a frame handed over in device memory --
+    // by workgroups appended to the frame's OWN integrate launch, the first tracker pass reading its samples from the xyz
+    // plane -- instead of by a pack_kernel of their own on the frame stream, which ran next to the current frame's
+    // latency-bound tracker passes (profiles/r06_host_queue.json: 4270-4470 -> 4900+ frames/s).  A block is reused once
+    // the launch that packed its frame has run (the release tickets of tsdf_device_frame_released).
+    static constexpr int kQueueBlocks = 3;
+    char* qblk[kQueueBlocks] = {nullptr, nullptr, nullptr};
+    size_t qblk_cap = 0;                                   // pixels a block holds
+    int64_t qblk_serial[kQueueBlocks] = {0, 0, 0};         // serial of the frame whose planes the block holds unpacked (0: none)
+    hipEvent_t ev_qblk[kQueueBlocks] = {nullptr, nullptr, nullptr};   // frame stream: the block's planes are complete
+    int qblk_next = 0;
     std::unique_ptr<tsdf_api::HostPool> pool;   // staging threads, started by the first pageable frame (TSDF_HOST_THREADS, default: usable cores - 2, at most 12)
     float* pre_z = nullptr; float* pre_zf = nullptr; void* pre_depth = nullptr; void* pin_depth = nullptr;   // pre-processing scratch
     size_t pre_cap = 0;
@@ -255,6 +269,7 @@ constexpr size_t kVolumePadFront = 16;   // voxels of {0,0} padding in front of 
     } while (0)
 
 // ---- api_frames.cpp
+struct DevPlanes { float* xyz = nullptr; float* nrm = nullptr; uint8_t* rgb = nullptr; };   // where a staged frame is copied to
 void free_preproc(tsdf_handle* h);
 void free_frame(tsdf_handle* h);
 int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_staging);
@@ -274,7 +289,8 @@ int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, s
 int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false);
 HostPool* host_pool(tsdf_handle* h);        // the staging threads, started by the first pageable frame
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
-                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset = 1);
+                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset = 1,
+                            const struct DevPlanes* dst = nullptr /* default: in_xyz | in_nrm | in_rgb */);
 void queue_thread_main(tsdf_handle* h);
 int ensure_second_staging_set(tsdf_handle* h, size_t npix);
 

@@ -467,11 +467,9 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         const bool actA = owned && q < 7, actB = owned && q < 6;
         Vol V{dw, p.g.m, p.g.xs, p.g.xe};
         double ax = sg.vx, ay = sg.vy, az = sg.vz;
-#ifdef TSDF_TRACK_DUP      // EXPERIMENT (round 6): lanes without a look-up repeat the address of a NEIGHBOURING lane of their quad
-        const int qA = q < 7 ? q : 6, qB = q < 6 ? q : 5;
-#else
+        // (lanes without a look-up repeating the address of a NEIGHBOURING lane of their quad instead of the centre's:
+        // measured in round 6, no difference -- profiles/r06_track_duplicate_addresses.json)
         const int qA = q < 7 ? q : 0, qB = q < 6 ? q : 0;
-#endif
         if (qA >= 1) {
             const int a = (qA - 1) >> 1;
             const double step = ((qA - 1) & 1) ? -(double)p.v_h : (double)p.v_h;
