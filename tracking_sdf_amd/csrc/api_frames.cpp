@@ -375,6 +375,62 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
 }
 }  // namespace tsdf_api
 
+namespace {
+// A block of the ring of device blocks for a frame that arrives from host memory (or as raw depth): allocated on first use (same layout as the in_xyz | in_nrm |
+// in_rgb block), free of the frame it held before -- that frame's planes were packed by its own integrate launch, which
+// publishes a release ticket (tsdf_device_frame_released's mechanism); two frames later it has long run, so the wait below
+// is a formality, bounded and backed by a real synchronisation.
+int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes) {
+    if (h->qblk_cap != h->in_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->fstream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) { if (h->qblk[b]) (void)hipFree(h->qblk[b]); h->qblk[b] = nullptr; h->qblk_serial[b] = 0; }
+        h->qblk_cap = 0;
+        for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) {
+            HIP_TRY(h, hipMalloc((void**)&h->qblk[b], frame_block_bytes(h->in_cap)));
+            if (!h->ev_qblk[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_qblk[b], hipEventDisableTiming));
+        }
+        h->qblk_cap = h->in_cap;
+    }
+    const int b = h->qblk_next;
+    h->qblk_next = (b + 1) % tsdf_handle::kQueueBlocks;
+    if (h->qblk_serial[b]) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; released_serial(h) < h->qblk_serial[b]; ++spins)
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));      // (a frame that was never integrated keeps its block until here)
+                break;
+            }
+        h->qblk_serial[b] = 0;
+    }
+    const size_t plane = plane_stride_bytes(h->in_cap);
+    planes->xyz = reinterpret_cast<float*>(h->qblk[b]);
+    planes->nrm = reinterpret_cast<float*>(h->qblk[b] + plane);
+    planes->rgb = reinterpret_cast<uint8_t*>(h->qblk[b] + 2 * plane);
+    *blk = b;
+    return TSDF_OK;
+}
+
+// The frame whose planes are (being) written into ring block `blk` becomes the current frame with its packing deferred
+// to its own integrate launch (defer_pack).  samples_listed: the tracker's sample list went up ahead (upload_samples_first),
+// the passes do not touch the planes.  travelling: the planes are still being produced on the frame stream (ev_frame is
+// recorded behind them here): with the samples listed only tsdf_integrate waits for them (records_pending), otherwise the
+// main stream does at once -- the first tracker pass reads its samples from the xyz plane.
+int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nrm, bool has_rgb, bool samples_listed, bool travelling) {
+    if (travelling) HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
+    const int rc = defer_pack(h, p.xyz, has_nrm ? p.nrm : nullptr, has_rgb ? p.rgb : nullptr);
+    if (rc) return rc;
+    h->deferred.samples_listed = samples_listed;
+    if (travelling) {
+        if (samples_listed) h->records_pending = true;
+        else HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
+    }
+    h->qblk_serial[blk] = h->frame_serial;               // the block is this frame's until the launch that packs it has run
+    h->staged_xyz = true; h->staged_planes[0] = p.xyz; h->staged_planes[1] = p.nrm; h->staged_blk = blk;
+    return TSDF_OK;
+}
+}  // namespace
+
 int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
     if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame: bad argument") : TSDF_E_BADARG;
     if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame");
@@ -391,6 +447,12 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     // integration of the previous frame keeps running on the main stream meanwhile)
     HIP_TRY(h, hipStreamSynchronize(h->fstream));
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
+    // The planes go into a block of the ring and are packed by the frame's own integrate launch (as a frame handed over in
+    // device memory is; round 6: no pack_kernel on the frame stream).
+    int blk = -1;
+    DevPlanes dst;
+    rc = acquire_queue_block(h, &blk, &dst);
+    if (rc) return rc;
     if (!direct) {
         static const bool samples_first = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
         if (samples_first) { rc = upload_samples_first(h, xyz, 12, 0, width); if (rc) return rc; }
@@ -398,19 +460,15 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
             std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
-        }));
-        h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
-        return run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
+        }, 1, &dst));
+        return block_frame_current(h, blk, dst, nrm != nullptr, rgb != nullptr, samples_first, true);
     }
-    HIP_TRY(h, hipMemcpyAsync(h->in_xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
-    if (nrm) HIP_TRY(h, hipMemcpyAsync(h->in_nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
-    if (rgb) HIP_TRY(h, hipMemcpyAsync(h->in_rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
-    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
+    HIP_TRY(h, hipMemcpyAsync(dst.xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (nrm) HIP_TRY(h, hipMemcpyAsync(dst.nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+    if (rgb) HIP_TRY(h, hipMemcpyAsync(dst.rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
     HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
-    rc = run_pack(h, h->in_xyz, nrm ? h->in_nrm : nullptr, rgb ? h->in_rgb : nullptr, h->fstream);
-    if (rc) return rc;
-    HIP_TRY(h, hipEventSynchronize(h->ev_copied));      // the caller's buffers have been read
-    return TSDF_OK;
+    HIP_TRY(h, hipEventSynchronize(h->ev_copied));      // the caller's buffers have been read -- and the planes are complete
+    return block_frame_current(h, blk, dst, nrm != nullptr, rgb != nullptr, false, false);
 }
 
 
@@ -450,41 +508,6 @@ int ensure_second_staging_set(tsdf_handle* h, size_t npix) {
 }  // namespace tsdf_api
 
 namespace {
-// A block of the queue's ring for the frame that is being queued: allocated on first use (same layout as the in_xyz | in_nrm |
-// in_rgb block), free of the frame it held before -- that frame's planes were packed by its own integrate launch, which
-// publishes a release ticket (tsdf_device_frame_released's mechanism); two frames later it has long run, so the wait below
-// is a formality, bounded and backed by a real synchronisation.
-int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes) {
-    if (h->qblk_cap != h->in_cap) {
-        HIP_TRY(h, hipStreamSynchronize(h->fstream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) { if (h->qblk[b]) (void)hipFree(h->qblk[b]); h->qblk[b] = nullptr; h->qblk_serial[b] = 0; }
-        h->qblk_cap = 0;
-        for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) {
-            HIP_TRY(h, hipMalloc((void**)&h->qblk[b], frame_block_bytes(h->in_cap)));
-            if (!h->ev_qblk[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_qblk[b], hipEventDisableTiming));
-        }
-        h->qblk_cap = h->in_cap;
-    }
-    const int b = h->qblk_next;
-    h->qblk_next = (b + 1) % tsdf_handle::kQueueBlocks;
-    if (h->qblk_serial[b]) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0; released_serial(h) < h->qblk_serial[b]; ++spins)
-            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
-                HIP_TRY(h, hipStreamSynchronize(h->stream));      // (a frame that was never integrated keeps its block until here)
-                break;
-            }
-        h->qblk_serial[b] = 0;
-    }
-    const size_t plane = plane_stride_bytes(h->in_cap);
-    planes->xyz = reinterpret_cast<float*>(h->qblk[b]);
-    planes->nrm = reinterpret_cast<float*>(h->qblk[b] + plane);
-    planes->rgb = reinterpret_cast<uint8_t*>(h->qblk[b] + 2 * plane);
-    *blk = b;
-    return TSDF_OK;
-}
-
 // what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
 int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
                        bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
@@ -659,7 +682,7 @@ int tsdf_next_frame(tsdf_handle* h) {
                                   : run_pack(h, bx, q.has_nrm ? bn : nullptr, q.has_rgb ? bc : nullptr, h->stream, true);
         if (rc) return rc;
         h->qblk_serial[blk] = h->frame_serial;               // the block is this frame's until the launch that packs it has run
-        h->staged_xyz = true; h->staged_planes[0] = bx; h->staged_planes[1] = bn;
+        h->staged_xyz = true; h->staged_planes[0] = bx; h->staged_planes[1] = bn; h->staged_blk = blk;
         return TSDF_OK;
     }
     if (from_device) {
@@ -713,7 +736,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
     if (normals && (L->normal_stride < 12 || L->normal_offset < 0 || L->normal_offset + 12 > L->normal_stride))
         return fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: normal layout (stride %d, normal at %d) does not hold three floats",
                     L->normal_stride, L->normal_offset);
-    if (!points && !(h->have_frame && h->staged_xyz && h->staged_planes[0] == h->in_xyz && h->fw == width && h->fh == height))
+    if (!points && !(h->have_frame && h->staged_xyz && h->fw == width && h->fh == height))
         return fail(h, TSDF_E_NO_FRAME, "tsdf_set_frame_aos: normals alone complete the CURRENT host frame of the same size; there is none");
     int rc = bind_device(h);
     if (rc) return rc;
@@ -728,13 +751,49 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
     // a new cloud: its tracker samples go up first (the passes of a following tsdf_track run under the planes' copy)
     static const bool samples_first_on = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
     const bool samples_first = samples_first_on && points != nullptr;
-    if (samples_first) { rc = upload_samples_first(h, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset, width); if (rc) return rc; }
-    HIP_TRY(h, stage_and_upload(h, npix, points != nullptr, normals != nullptr, color, [&](size_t i0, size_t i1) {
-        repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
+    if (points) {
+        // a whole new frame: its planes go into a block of the ring and are packed by its own integrate launch (round 6)
+        int blk = -1;
+        DevPlanes dst;
+        rc = acquire_queue_block(h, &blk, &dst);
+        if (rc) return rc;
+        if (samples_first) { rc = upload_samples_first(h, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset, width); if (rc) return rc; }
+        HIP_TRY(h, stage_and_upload(h, npix, true, normals != nullptr, color, [&](size_t i0, size_t i1) {
+            repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
+        }, 1, &dst));
+        return block_frame_current(h, blk, dst, normals != nullptr, color, samples_first, true);
+    }
+    if (h->staged_blk >= 0) {
+        // the normals of the CURRENT frame, whose points sit in a block of the ring: into that block's normal plane; the
+        // frame's integrate launch packs them (for a frame that was packed already: once more, with the normals)
+        const int blk = h->staged_blk;
+        const size_t plane = plane_stride_bytes(h->in_cap);
+        DevPlanes dst;
+        dst.xyz = reinterpret_cast<float*>(h->qblk[blk]); dst.nrm = reinterpret_cast<float*>(h->qblk[blk] + plane);
+        dst.rgb = reinterpret_cast<uint8_t*>(h->qblk[blk] + 2 * plane);
+        HIP_TRY(h, stage_and_upload(h, npix, false, true, false, [&](size_t i0, size_t i1) {
+            repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
+        }, 1, &dst));
+        HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
+        if (!h->deferred.pending) {
+            borrow_device_frame(h, h->frame_serial);
+            h->deferred = tsdf_handle::DeferredPack();
+            h->deferred.pending = true; h->deferred.samples_listed = true;     // the sample list of this frame exists
+            h->deferred.xyz = dst.xyz; h->deferred.rgb = had_rgb ? dst.rgb : nullptr;
+            h->qblk_serial[blk] = h->frame_serial;
+        }
+        h->deferred.nrm = dst.nrm;
+        h->frame_has_nrm = true;
+        h->records_pending = true;                        // tsdf_integrate waits for ev_frame
+        h->staged_xyz = true;
+        return TSDF_OK;
+    }
+    HIP_TRY(h, stage_and_upload(h, npix, false, true, false, [&](size_t i0, size_t i1) {
+        repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
     }));
-    const bool has_rgb = points ? color : had_rgb;
-    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
-    return run_pack(h, h->in_xyz, normals ? h->in_nrm : nullptr, has_rgb ? h->in_rgb : nullptr, h->fstream, false, samples_first);
+    const bool has_rgb = had_rgb;
+    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm; h->staged_blk = -1;
+    return run_pack(h, h->in_xyz, h->in_nrm, has_rgb ? h->in_rgb : nullptr, h->fstream, false, false);
 }
 
 
@@ -783,6 +842,19 @@ int depth_frame_prepare(tsdf_handle* h, const char* who, bool queued, const uint
 // Upload, back-projection, filter and normals of a depth frame on the frame stream; in_xyz / in_nrm / in_rgb hold the
 // frame afterwards.  Runs on the caller's thread (tsdf_set_depth_frame) or on the queue's library thread
 // (tsdf_queue_depth_frame): the bilateral grid's depth extent is the one host round trip of this path.
+// a pageable buffer into pinned staging memory, on the staging threads (the depth + rgb of a 640x480 frame are 1.5 MB:
+// ~150 us on ONE thread, most of a frame's time on the queue's library thread -- round 6)
+void pooled_copy(tsdf_handle* h, void* dst, const void* src, size_t bytes) {
+    HostPool* const pool = bytes >= ((size_t)1 << 17) ? host_pool(h) : nullptr;
+    if (!pool) { std::memcpy(dst, src, bytes); return; }
+    const std::function<void(int, int)> job = [&](int part, int parts) {
+        const size_t a = (bytes * (size_t)part / (size_t)parts) & ~(size_t)63;
+        const size_t b = part + 1 == parts ? bytes : (bytes * (size_t)(part + 1) / (size_t)parts) & ~(size_t)63;
+        if (b > a) std::memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(src) + a, b - a);
+    };
+    pool->run(job);
+}
+
 int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, const float* depthf, const uint8_t* rgb,
                      int32_t width, int32_t height, const tsdf_preproc_params& pp, bool* direct_out, const DevPlanes& out) {
     const size_t npix = (size_t)width * height;
@@ -793,7 +865,7 @@ int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, c
     // page-locked caller buffers are copied from directly, as in tsdf_set_frame
     const bool direct = is_pinned_host(dsrc, dbytes) && (!rgb || is_pinned_host(rgb, npix * 3));
     *direct_out = direct;
-    if (!direct) std::memcpy(h->pin_depth, dsrc, dbytes);
+    if (!direct) pooled_copy(h, h->pin_depth, dsrc, dbytes);
     HIP_TRY(h, hipMemcpyAsync(h->pre_depth, direct ? dsrc : h->pin_depth, dbytes, hipMemcpyHostToDevice, h->fstream));
     HIP_TRY(h, launch_depth_to_z(h->fstream, depth16 ? (const uint16_t*)h->pre_depth : nullptr,
                                  depth16 ? nullptr : (const float*)h->pre_depth, pp.depth_scale, (int)npix, h->pre_z,
@@ -801,7 +873,7 @@ int depth_frame_work(tsdf_handle* h, const char* who, const uint16_t* depth16, c
     if (use_grid)
         HIP_TRY(h, hipMemcpyAsync(h->pin_minmax, h->pre_minmax, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->fstream));
     if (rgb) {
-        if (!direct) std::memcpy(h->pin_rgb, rgb, npix * 3);
+        if (!direct) pooled_copy(h, h->pin_rgb, rgb, npix * 3);
         HIP_TRY(h, hipMemcpyAsync(out.rgb, direct ? rgb : h->pin_rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
     }
     if (direct && !use_grid) HIP_TRY(h, hipEventRecord(h->ev_copied, h->fstream));
@@ -848,11 +920,14 @@ int tsdf_set_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float* d
     if (rc) return rc;
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     bool direct = false;
-    const DevPlanes own{h->in_xyz, h->in_nrm, h->in_rgb};
-    rc = depth_frame_work(h, "tsdf_set_depth_frame", depth16, depthf, rgb, width, height, pp, &direct, own);
+    // the pre-processed planes go into a block of the ring and are packed by the frame's own integrate launch (round 6)
+    int blk = -1;
+    DevPlanes dst;
+    rc = acquire_queue_block(h, &blk, &dst);
     if (rc) return rc;
-    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
-    rc = run_pack(h, h->in_xyz, h->in_nrm, rgb ? h->in_rgb : nullptr, h->fstream);
+    rc = depth_frame_work(h, "tsdf_set_depth_frame", depth16, depthf, rgb, width, height, pp, &direct, dst);
+    if (rc) return rc;
+    rc = block_frame_current(h, blk, dst, true, rgb != nullptr, false, true);
     if (rc) return rc;
     const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
     if (direct && !use_grid) HIP_TRY(h, hipEventSynchronize(h->ev_copied));   // (the grid path has synchronised already)

@@ -534,7 +534,7 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
     if (h->queued.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_track_aos: staging the cloud failed: %s", hipGetErrorString(h->queued.err));
     HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));      // the copies out of this set of planes, so far
     h->stage_recorded[0] = true;
-    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm;
+    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm; h->staged_blk = -1;
     h->tracked.valid = true; h->tracked.color = color; h->tracked.points = points; h->tracked.w = width; h->tracked.h = height;
     h->tracked.serial = h->frame_serial; h->tracked.lay = *L;
     h->tracked.normals = normals;

@@ -101,7 +101,8 @@ struct tsdf_handle {
     bool stage_recorded[2] = {false, false};
     size_t in_cap = 0;             // pixels the staging buffers hold
     bool staged_xyz = false;       // the library holds the planes of the CURRENT frame on the device (host / AoS / depth frames) ...
-    const float* staged_planes[2] = {nullptr, nullptr};   // ... here: xyz, nrm (in_xyz / in_nrm, or a block of the queue's ring)
+    const float* staged_planes[2] = {nullptr, nullptr};   // ... here: xyz, nrm (in_xyz / in_nrm, or a block of the ring)
+    int staged_blk = -1;           // the ring block that holds them (-1: the in_xyz | in_nrm | in_rgb block)
     // Frames that come through the QUEUE from host memory or as raw depth (round 6): their planes land in one of three
     // device blocks (same layout as in_xyz | in_nrm | in_rgb) and are packed like a frame handed over in device memory --
     // by workgroups appended to the frame's OWN integrate launch, the first tracker pass reading its samples from the xyz
