@@ -48,15 +48,21 @@ def test_sharded_bench_reproduces_single_rank_trajectory(tmp_path, mode, nproc):
 
 def test_uniform_and_balanced_slabs_give_the_single_rank_trajectory(tmp_path):
     """bench.py --slabs: equal-thickness slabs (tsdf_slab_range) and slabs of equal expected work (tsdf_slab_range_weighted on
-    the initial pose's frustum: the default) are two partitions of the same volume -- same trajectory as one rank, and the
+    the initial pose's frustum) are two partitions of the same volume -- same trajectory as one rank, and the
     balanced split really is another one (rank 0 owns more layers than a third of the axis)."""
     j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
     ju, tu = run_bench(["--allreduce", "shm", "--slabs", "uniform"], 3, str(tmp_path / "tu.txt"), 29711)
     jb, tb = run_bench(["--allreduce", "shm", "--slabs", "balanced"], 3, str(tmp_path / "tb.txt"), 29713)
-    assert np.array_equal(t1, tu) and np.array_equal(t1, tb)
+    jp, tp = run_bench(["--allreduce", "shm"], 3, str(tmp_path / "tp.txt"), 29715)          # the default: --slabs auto = path
+    assert np.array_equal(t1, tu) and np.array_equal(t1, tb) and np.array_equal(t1, tp)
     assert "uniform slabs, rank 0 owns layers [0, 43)" in ju["config"]["parallelism"]
     assert "balanced slabs, rank 0 owns layers [0, " in jb["config"]["parallelism"]
     assert int(jb["config"]["parallelism"].split("[0, ")[1].split(")")[0]) > 43
+    # --slabs auto with a known path: cuts that minimise the path-average of the busiest rank (tracking_sdf_amd.slab_cuts_for_path);
+    # the line carries DESIGN 6.1's model prediction next to the measured value
+    assert "path slabs, rank 0 owns layers [0, " in jp["config"]["parallelism"] and jp["config"]["slabs"] == "path"
+    sm = jp["scaling_model"]
+    assert sm["predicted_value"] > 0 and 1.0 / 3.0 <= sm["busiest_share"] <= 1.0 and j1["scaling_model"] is None
 
 
 @pytest.mark.parametrize("mode", ["shm", "peer", "rccl-mock"])

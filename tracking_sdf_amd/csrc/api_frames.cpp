@@ -140,8 +140,8 @@ PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, con
 
 // ---- borrowed device planes (tsdf_device_frame_released) ---------------------------------------------------------
 // a device frame with this serial has been handed over; nothing has packed it yet
-void borrow_device_frame(tsdf_handle* h, int64_t serial) {
-    try { h->borrowed.push_back({serial, -1, 0ull}); }
+void borrow_device_frame(tsdf_handle* h, int64_t serial, bool internal) {
+    try { h->borrowed.push_back({serial, -1, 0ull, internal}); }
     catch (...) { if (h->borrow_lost < 0) h->borrow_lost = serial; }    // out of memory for 24 bytes: nothing may throw across the C ABI;
 }                                                                        // frames from here on are reported borrowed until tsdf_synchronize
 // the launch that packs frame `serial` is about to be issued on stream index s: the ticket it will publish
@@ -159,15 +159,17 @@ void abandon_device_frame(tsdf_handle* h, int64_t serial) {
     for (auto& b : h->borrowed)
         if (b.serial == serial && b.stream < 0) { b.stream = 0; b.ticket = 0ull; }
 }
-// newest serial S such that no device frame with serial <= S is still read by the library
-int64_t released_serial(tsdf_handle* h) {
-    while (!h->borrowed.empty()) {
-        const tsdf_handle::BorrowedFrame& b = h->borrowed.front();
-        if (b.stream < 0) break;
-        if (b.ticket && __atomic_load_n(h->release_host + b.stream, __ATOMIC_ACQUIRE) < b.ticket) break;
-        h->borrowed.pop_front();
-    }
-    int64_t rel = h->borrowed.empty() ? h->frame_serial + ((h->queued.active && h->queued.device) ? 1 : 0) : h->borrowed.front().serial - 1;
+// newest serial S such that no device frame with serial <= S is still read by the library.  The caller's view
+// (tsdf_device_frame_released) counts the planes the CALLER handed over in device memory; own_blocks_too also counts the
+// blocks of the library's own ring, which hold host / depth frames until their integrate launch has packed them.
+int64_t released_serial(tsdf_handle* h, bool own_blocks_too) {
+    auto pending = [h](const tsdf_handle::BorrowedFrame& b) {
+        return b.stream < 0 || (b.ticket && __atomic_load_n(h->release_host + b.stream, __ATOMIC_ACQUIRE) < b.ticket);
+    };
+    while (!h->borrowed.empty() && !pending(h->borrowed.front())) h->borrowed.pop_front();
+    int64_t rel = h->frame_serial + ((h->queued.active && h->queued.device) ? 1 : 0);
+    for (const auto& b : h->borrowed)
+        if ((own_blocks_too || !b.internal) && pending(b)) { rel = b.serial - 1; break; }
     if (h->borrow_lost >= 0 && rel >= h->borrow_lost) rel = h->borrow_lost - 1;
     return rel;
 }
@@ -252,9 +254,9 @@ int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, s
 // of its own in front of the first tracker pass.  The planes stay borrowed until that launch has run: tsdf.h asks for them
 // until tsdf_device_frame_released() reaches the frame's serial (or tsdf_synchronize, which packs what is pending).
 // TSDF_DEFER_PACK=0: pack at once, as rounds 1-3 did.
-int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed) {
+int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed, bool own_block) {
     if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
-    if (!already_borrowed) borrow_device_frame(h, h->frame_serial + 1);
+    if (!already_borrowed) borrow_device_frame(h, h->frame_serial + 1, own_block);
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;
     h->frame_side = false;
@@ -396,7 +398,7 @@ int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes) {
     h->qblk_next = (b + 1) % tsdf_handle::kQueueBlocks;
     if (h->qblk_serial[b]) {
         const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0; released_serial(h) < h->qblk_serial[b]; ++spins)
+        for (unsigned spins = 0; released_serial(h, true) < h->qblk_serial[b]; ++spins)
             if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
                 HIP_TRY(h, hipStreamSynchronize(h->stream));      // (a frame that was never integrated keeps its block until here)
                 break;
@@ -418,7 +420,7 @@ int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes) {
 // main stream does at once -- the first tracker pass reads its samples from the xyz plane.
 int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nrm, bool has_rgb, bool samples_listed, bool travelling) {
     if (travelling) HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
-    const int rc = defer_pack(h, p.xyz, has_nrm ? p.nrm : nullptr, has_rgb ? p.rgb : nullptr);
+    const int rc = defer_pack(h, p.xyz, has_nrm ? p.nrm : nullptr, has_rgb ? p.rgb : nullptr, false, true);
     if (rc) return rc;
     h->deferred.samples_listed = samples_listed;
     if (travelling) {
@@ -678,8 +680,7 @@ int tsdf_next_frame(tsdf_handle* h) {
         const float* const bx = reinterpret_cast<const float*>(h->qblk[blk]);
         const float* const bn = reinterpret_cast<const float*>(h->qblk[blk] + plane);
         const uint8_t* const bc = reinterpret_cast<const uint8_t*>(h->qblk[blk] + 2 * plane);
-        rc = h->defer_device_pack ? defer_pack(h, bx, q.has_nrm ? bn : nullptr, q.has_rgb ? bc : nullptr)
-                                  : run_pack(h, bx, q.has_nrm ? bn : nullptr, q.has_rgb ? bc : nullptr, h->stream, true);
+        rc = defer_pack(h, bx, q.has_nrm ? bn : nullptr, q.has_rgb ? bc : nullptr, false, true);
         if (rc) return rc;
         h->qblk_serial[blk] = h->frame_serial;               // the block is this frame's until the launch that packs it has run
         h->staged_xyz = true; h->staged_planes[0] = bx; h->staged_planes[1] = bn; h->staged_blk = blk;
@@ -776,7 +777,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
         }, 1, &dst));
         HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
         if (!h->deferred.pending) {
-            borrow_device_frame(h, h->frame_serial);
+            borrow_device_frame(h, h->frame_serial, true);
             h->deferred = tsdf_handle::DeferredPack();
             h->deferred.pending = true; h->deferred.samples_listed = true;     // the sample list of this frame exists
             h->deferred.xyz = dst.xyz; h->deferred.rgb = had_rgb ? dst.rgb : nullptr;

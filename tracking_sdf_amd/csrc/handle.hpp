@@ -150,6 +150,7 @@ struct tsdf_handle {
         int64_t serial;                        // tsdf_frame_serial() the frame has (or will have, while it is still queued)
         int stream;                            // -1: not packed yet (and not abandoned): still borrowed, whatever the words say
         unsigned long long ticket;
+        bool internal;                         // the planes are a block of the library's own ring (a host / depth frame): not the caller's business
     };
     std::deque<BorrowedFrame> borrowed;
     int64_t borrow_lost = -1;                      // >= 0: an entry could not be recorded for this serial (see borrow_device_frame)
@@ -278,16 +279,17 @@ void pick_pixel_layout(const tsdf_handle* h, int32_t* su, int32_t* sv);
 void choose_pixel_layout(tsdf_handle* h);
 int wait_buffer_free(tsdf_handle* h, int nb, hipStream_t st);
 PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t su, int32_t sv, int nb);
-void borrow_device_frame(tsdf_handle* h, int64_t serial);
+void borrow_device_frame(tsdf_handle* h, int64_t serial, bool internal = false);
 ReleaseWord release_for(tsdf_handle* h, int64_t serial, int s);
 void abandon_device_frame(tsdf_handle* h, int64_t serial);
-int64_t released_serial(tsdf_handle* h);
+int64_t released_serial(tsdf_handle* h, bool own_blocks_too = false);
 int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st, bool borrowed_planes = false,
              bool samples_first = false /* the sample list of this frame went up ahead (upload_samples_first): the pack writes the
                                            records only and the main stream is NOT made to wait for it here -- tsdf_integrate does */);
 int ensure_pin_samples(tsdf_handle* h);
 int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width);
-int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false);
+int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false,
+               bool own_block = false /* the planes are a block of the library's own ring */);
 HostPool* host_pool(tsdf_handle* h);        // the staging threads, started by the first pageable frame
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
                             const std::function<void(size_t, size_t)>& fill, int chunks_when_unset = 1,
