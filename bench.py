@@ -84,10 +84,11 @@ def parse(argv=None):
                          "in-library RCCL all-reduce (falls back to the shared-memory fan-in only if RCCL fails its self-test); shm = "
                          "host-side fan-in through a POSIX shared segment; peer = device-side exchange through HIP-IPC-mapped buffers "
                          "(tsdf_comm_init_peer)")
-    ap.add_argument("--frame-queue", action="store_true",
-                    help="queue the HBM-resident frame k+1 (tsdf_queue_frame_device) while frame k is processed instead of setting "
-                         "every frame in front of its own tracker passes: frame k+1 is then packed, sample list included, inside frame k's "
-                         "integrate launch")
+    ap.add_argument("--no-frame-queue", dest="frame_queue", action="store_false",
+                    help="set every HBM-resident frame in front of its own tracker passes (tsdf_set_frame_device) instead of queueing frame "
+                         "k+1 (tsdf_queue_frame_device) while frame k is processed.  Default since round 6: the queue -- frame k+1 is then "
+                         "packed, sample list included, inside frame k's integrate launch (+3 % frames/s, same bits)")
+    ap.set_defaults(frame_queue=True)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--timing-period", type=int, default=4, help="HIP events around every n-th integrate/pack launch")
@@ -869,11 +870,14 @@ def run(args):
                 e, _, _ = lg.timed_region(d_frames, mode, host, depth, events=False)
                 best = e if best is None else min(best, e)
             return best
-        if MAIN_MODE == "device":
-            extras["value_device_resident_queued"] = args.steps / best_of_two("device_q", None)
-            extras["device_queued_note"] = ("the same HBM-resident frames through tsdf_queue_frame_device / tsdf_next_frame: frame k+1 is packed, sample "
-                                            "list included, by workgroups appended to frame k's integrate launch (the plain loop packs frame k there "
-                                            "and reads the first pass's samples from the xyz plane)")
+        other = "device_q" if MAIN_MODE == "device" else "device"
+        extras["value_device_resident_queued" if other == "device_q" else "value_device_resident_one_at_a_time"] = args.steps / best_of_two(other, None)
+        if other == "device":
+            extras["value_device_resident_queued"] = args.steps / elapsed
+        extras["device_queued_note"] = ("HBM-resident frames through tsdf_queue_frame_device / tsdf_next_frame (`value` since round 6): frame k+1 is packed, "
+                                        "sample list included, by workgroups appended to frame k's integrate launch; one at a time "
+                                        "(tsdf_set_frame_device, `value` until round 5): the launch packs frame k itself and the first pass reads its "
+                                        "samples from the xyz plane")
         e2 = best_of_two("host", host_frames)
         extras["value_h2d_inclusive"] = args.steps / e2
         extras["h2d_inclusive_note"] = ("best of two repetitions; xyz + normals + rgb (27 B/pixel) handed over as HOST buffers every frame through "
@@ -1097,7 +1101,7 @@ def run(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32/f64",
             "dtype_note": "f32 voxel state and SDF samples, f64 geometry and normal equations (the reference's own mix)",
-            "data": "synthetic (frames resident in HBM before the timed region" + ("" if not args.frame_queue else "; frame k+1 queued with "
+            "data": "synthetic (frames resident in HBM before the timed region" + ("; handed over one at a time with tsdf_set_frame_device" if not args.frame_queue else "; frame k+1 queued with "
                     "tsdf_queue_frame_device while frame k is tracked and integrated") + ")",
             "config": {"workload": f"{wl_label}: fr1/plant ground-truth camera path at 30 Hz (re-based to the reference's "
                                    f"initial pose), analytic scene (plant on a pedestal at the path's focus, room with "

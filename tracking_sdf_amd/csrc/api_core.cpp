@@ -198,11 +198,8 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_samples, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_queued, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[1], hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[0], hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_buf_used[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
     // Padding voxels {D = 0, W = 0} around the volume (16 in front: keeps the 128-byte alignment of the rows; 2 behind).
     // Tracker look-ups read the corner pair (k, k+1) with one 16-byte load at k in [-1, m-1]: at the two ends of a row
@@ -319,12 +316,10 @@ void tsdf_destroy(tsdf_handle* h) {
     for (int b = 0; b < 2; ++b) {
         if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]);
         if (h->samples_buf[b]) (void)hipFree(h->samples_buf[b]);
-        if (h->ev_buf_used[b]) (void)hipEventDestroy(h->ev_buf_used[b]);
     }
     if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
     if (h->ev_samples) (void)hipEventDestroy(h->ev_samples);
-    if (h->ev_queued) (void)hipEventDestroy(h->ev_queued);
     for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) if (h->ev_qblk[b]) (void)hipEventDestroy(h->ev_qblk[b]);
     for (int b = 0; b < 2; ++b) if (h->ev_stage_done[b]) (void)hipEventDestroy(h->ev_stage_done[b]);
     if (h->partials) (void)hipFree(h->partials);
@@ -468,7 +463,7 @@ int tsdf_synchronize(tsdf_handle* h) {
         HIP_TRY(h, launch_pack(h->stream, own));
         h->deferred.pending = false;
     }
-    if (h->queued.active && h->queued.device && h->queued.deferred && !h->queued.packed) {
+    if (h->queued.active && h->queued.device && !h->queued.packed) {      // (deferred or, TSDF_DEFER_PACK=0, waiting for tsdf_next_frame)
         tsdf_handle::Queued& q = h->queued;
         pick_pixel_layout(h, &q.su, &q.sv);
         HIP_TRY(h, launch_pack(h->stream, pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, q.nb)));

@@ -61,8 +61,6 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
         // growing: nothing may still read the old buffers
         HIP_TRY(h, hipStreamSynchronize(h->fstream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        h->used_valid[0] = h->used_valid[1] = false;
-        h->used_untracked[0] = h->used_untracked[1] = false;
     }
     if (npix > h->pn_cap) {
         for (int b = 0; b < 2; ++b) { if (h->pn_buf[b]) (void)hipFree(h->pn_buf[b]); h->pn_buf[b] = nullptr; }
@@ -113,20 +111,6 @@ void pick_pixel_layout(const tsdf_handle* h, int32_t* su, int32_t* sv) {
 }
 void choose_pixel_layout(tsdf_handle* h) { pick_pixel_layout(h, &h->pix_su, &h->pix_sv); }
 
-// make stream `st` wait until the integration that last read pixel buffer nb is done
-int wait_buffer_free(tsdf_handle* h, int nb, hipStream_t st) {
-    if (h->used_valid[nb]) {
-        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
-    } else if (h->used_untracked[nb]) {
-        // the buffer was last read by an integration that recorded no event (device-resident frames do not pay
-        // for one): order behind everything queued on the main stream, once
-        HIP_TRY(h, hipEventRecord(h->ev_buf_used[nb], h->stream));
-        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_buf_used[nb], 0));
-    }
-    h->used_untracked[nb] = false;
-    return TSDF_OK;
-}
-
 PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t su, int32_t sv, int nb) {
     PackArgs a;
     a.xyz = xyz; a.nrm = nrm; a.rgb = rgb;
@@ -174,37 +158,24 @@ int64_t released_serial(tsdf_handle* h, bool own_blocks_too) {
     return rel;
 }
 
-// st = h->fstream when the inputs were produced on the frame stream (host images, pre-processing): the pack then
-// overlaps the running integration like they do.  Device-resident inputs pack on the main stream: measured, a
-// pack_kernel squeezed in beside the persistent integrate_kernel slows that one down by as much as it takes.
-int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st, bool borrowed_planes, bool samples_first) {
+// TSDF_DEFER_PACK=0 only (rounds 1-3's form, kept for same-box comparisons): a frame handed over in DEVICE memory is packed
+// at once, by a pack_kernel launch of its own on the main stream.  (Until round 5 host and depth frames were packed like
+// this on the frame stream; they now go through the ring of device blocks and deferred packing, like everything else.)
+// registered: the frame's entry in the list of borrowed frames exists already (a queued frame).
+int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool registered) {
     if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
-    const bool side = st != h->stream;
     if (h->queued.active) return fail(h, TSDF_E_BADARG, "a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first");
-    if (side) { const int rcw = wait_buffer_free(h, nb, st); if (rcw) return rcw; }
-    h->frame_side = side;
     EventPair* ep;
-    int rc = timed_begin(h, 1, &ep, st);
+    int rc = timed_begin(h, 1, &ep, h->stream);
     if (rc) return rc;
-    {
-        PackArgs pa = pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb);
-        if (samples_first) pa.samples = nullptr;
-        HIP_TRY(h, launch_pack(st, pa));
-    }
-    if (borrowed_planes) {
-        borrow_device_frame(h, h->frame_serial + 1);
-        HIP_TRY(h, launch_release(st, release_for(h, h->frame_serial + 1, side ? 1 : 0)));
-    }
-    rc = timed_end(h, ep, st);
+    HIP_TRY(h, launch_pack(h->stream, pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb)));
+    if (!registered) borrow_device_frame(h, h->frame_serial + 1);
+    HIP_TRY(h, launch_release(h->stream, release_for(h, h->frame_serial + 1, 0)));
+    rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
     h->records_pending = false;
-    if (side) {
-        HIP_TRY(h, hipEventRecord(h->ev_frame, st));
-        if (samples_first) h->records_pending = true;          // the tracker needs the sample list only (main stream waits for ev_samples)
-        else HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));   // everything queued on `stream` from here on sees the frame
-    }
     h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
     h->have_frame = true;
     h->frame_serial++;
@@ -259,7 +230,6 @@ int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t
     if (!already_borrowed) borrow_device_frame(h, h->frame_serial + 1, own_block);
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;
-    h->frame_side = false;
     h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
     h->have_frame = true;
     h->frame_serial++;
@@ -377,7 +347,16 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
 }
 }  // namespace tsdf_api
 
-namespace {
+namespace tsdf_api {
+DevPlanes block_planes(const tsdf_handle* h, int blk) {
+    const size_t plane = plane_stride_bytes(h->in_cap);
+    DevPlanes p;
+    p.xyz = reinterpret_cast<float*>(h->qblk[blk]);
+    p.nrm = reinterpret_cast<float*>(h->qblk[blk] + plane);
+    p.rgb = reinterpret_cast<uint8_t*>(h->qblk[blk] + 2 * plane);
+    return p;
+}
+
 // A block of the ring of device blocks for a frame that arrives from host memory (or as raw depth): allocated on first use (same layout as the in_xyz | in_nrm |
 // in_rgb block), free of the frame it held before -- that frame's planes were packed by its own integrate launch, which
 // publishes a release ticket (tsdf_device_frame_released's mechanism); two frames later it has long run, so the wait below
@@ -405,10 +384,7 @@ int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes) {
             }
         h->qblk_serial[b] = 0;
     }
-    const size_t plane = plane_stride_bytes(h->in_cap);
-    planes->xyz = reinterpret_cast<float*>(h->qblk[b]);
-    planes->nrm = reinterpret_cast<float*>(h->qblk[b] + plane);
-    planes->rgb = reinterpret_cast<uint8_t*>(h->qblk[b] + 2 * plane);
+    *planes = block_planes(h, b);
     *blk = b;
     return TSDF_OK;
 }
@@ -431,7 +407,7 @@ int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nr
     h->staged_xyz = true; h->staged_planes[0] = p.xyz; h->staged_planes[1] = p.nrm; h->staged_blk = blk;
     return TSDF_OK;
 }
-}  // namespace
+}  // namespace tsdf_api
 
 int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
     if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame: bad argument") : TSDF_E_BADARG;
@@ -613,25 +589,13 @@ int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_n
     if (rc) return rc;
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true; q.err = hipSuccess; q.rc = TSDF_OK;
-    q.deferred = q.packed = false;
-    if (h->defer_device_pack) {
-        // no launch now: the integrate launch of the CURRENT frame packs this one in workgroups appended to its
-        // list_rows_kernel (tsdf_integrate), on the main stream, i.e. behind the last reader of the record buffer
-        q.deferred = true; q.d_xyz = d_xyz; q.d_nrm = d_nrm; q.d_rgb = d_rgb;
-        q.active = true;
-        borrow_device_frame(h, h->frame_serial + 1);
-        return TSDF_OK;
-    }
-    pick_pixel_layout(h, &q.su, &q.sv);
-    // the record buffer of the frame before the current one: free once that frame's integration is done -- from then
-    // on the pack runs on the frame stream, next to the current frame's tracker passes
-    rc = wait_buffer_free(h, q.nb, h->fstream);
-    if (rc) return rc;
-    HIP_TRY(h, launch_pack(h->fstream, pack_args(h, d_xyz, d_nrm, d_rgb, q.su, q.sv, q.nb)));
-    borrow_device_frame(h, h->frame_serial + 1);
-    HIP_TRY(h, launch_release(h->fstream, release_for(h, h->frame_serial + 1, 1)));
-    HIP_TRY(h, hipEventRecord(h->ev_queued, h->fstream));
+    // No launch now.  Default: the integrate launch of the CURRENT frame packs this one in workgroups appended to its
+    // list_rows_kernel (tsdf_integrate), on the main stream, i.e. behind the last reader of the record buffer (q.deferred).
+    // TSDF_DEFER_PACK=0: a pack_kernel launch of its own when the frame becomes current (tsdf_next_frame).
+    q.deferred = h->defer_device_pack; q.packed = false;
+    q.d_xyz = d_xyz; q.d_nrm = d_nrm; q.d_rgb = d_rgb;
     q.active = true;
+    borrow_device_frame(h, h->frame_serial + 1);
     return TSDF_OK;
 }
 
@@ -644,23 +608,24 @@ int tsdf_next_frame(tsdf_handle* h) {
     q.active = false;
     const bool from_device = q.device;
     q.device = false;
-    if (from_device && q.deferred) {
+    if (from_device) {
+        const bool deferred = q.deferred;
         q.deferred = false;
         h->staged_xyz = false;
-        if (!q.packed) return defer_pack(h, q.d_xyz, q.d_nrm, q.d_rgb, true);      // no integrate launch came by: as tsdf_set_frame_device
-        // packed inside the previous frame's integrate launch, on the main stream: nothing to wait for
+        if (!q.packed)         // no launch has packed it yet: as tsdf_set_frame_device would (deferred, or a launch of its own: TSDF_DEFER_PACK=0)
+            return deferred ? defer_pack(h, q.d_xyz, q.d_nrm, q.d_rgb, true) : run_pack(h, q.d_xyz, q.d_nrm, q.d_rgb, true);
+        // packed inside the previous frame's integrate launch (or by tsdf_synchronize), on the main stream: nothing to wait for
         if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);
         h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
         h->deferred = tsdf_handle::DeferredPack();
         h->pix_su = q.su; h->pix_sv = q.sv;
-        h->frame_side = false;
         h->have_frame = true;
         h->frame_serial++;
         h->frame_has_nrm = q.has_nrm;
         h->frame_has_rgb = q.has_rgb;
         return TSDF_OK;
     }
-    if (!from_device && q.blk >= 0) {
+    if (q.blk >= 0) {
         // a host / depth frame whose planes sit in a block of the queue's ring: it becomes current the way a frame handed
         // over in device memory does (deferred packing), once the caller's buffers have been read
         const int blk = q.blk;
@@ -686,30 +651,7 @@ int tsdf_next_frame(tsdf_handle* h) {
         h->staged_xyz = true; h->staged_planes[0] = bx; h->staged_planes[1] = bn; h->staged_blk = blk;
         return TSDF_OK;
     }
-    if (from_device) {
-        // nothing to wait for on the host: device buffers stay borrowed as tsdf_set_frame_device's do
-    } else if (q.direct) {
-        HIP_TRY(h, hipEventSynchronize(h->ev_copied));       // the caller's buffers have been read
-    } else {
-        const auto tw0 = std::chrono::steady_clock::now();
-        std::unique_lock<std::mutex> g(h->qmu);
-        h->qcv.wait(g, [&] { return !h->qbusy; });           // the staging thread is done with the caller's buffers
-        if (h->sp.on) h->sp.next_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
-        if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; h->err = q.msg; return r; }
-        if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
-    }
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_queued, 0));   // everything queued on `stream` from here on sees the frame
-    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);     // the frame this one replaces was never packed
-    h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
-    h->deferred = tsdf_handle::DeferredPack();
-    h->pix_su = q.su; h->pix_sv = q.sv;
-    h->frame_side = true;
-    h->have_frame = true;
-    h->staged_xyz = !from_device;
-    h->frame_serial++;
-    h->frame_has_nrm = q.has_nrm;
-    h->frame_has_rgb = q.has_rgb;
-    return TSDF_OK;
+    return fail(h, TSDF_E_BADARG, "tsdf_next_frame: the queued frame has no device block (internal error)");
 }
 
 int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
@@ -721,7 +663,7 @@ int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm
     if (rc) return rc;
     h->staged_xyz = false;
     if (h->defer_device_pack) return defer_pack(h, d_xyz, d_nrm, d_rgb);
-    return run_pack(h, d_xyz, d_nrm, d_rgb, h->stream, true);
+    return run_pack(h, d_xyz, d_nrm, d_rgb, false);
 }
 
 int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L,
@@ -789,12 +731,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
         h->staged_xyz = true;
         return TSDF_OK;
     }
-    HIP_TRY(h, stage_and_upload(h, npix, false, true, false, [&](size_t i0, size_t i1) {
-        repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
-    }));
-    const bool has_rgb = had_rgb;
-    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm; h->staged_blk = -1;
-    return run_pack(h, h->in_xyz, h->in_nrm, has_rgb ? h->in_rgb : nullptr, h->fstream, false, false);
+    return fail(h, TSDF_E_NO_FRAME, "tsdf_set_frame_aos: normals alone complete a host frame the library holds; the current frame came from device memory");
 }
 
 

@@ -303,13 +303,6 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     h->deferred.pending = false;             // records and sample list of the current frame are complete from here on
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
-    if (h->frame_side) {     // the next-but-one pack (on the frame stream) may overwrite this buffer after this launch
-        HIP_TRY(h, hipEventRecord(h->ev_buf_used[h->fidx], h->stream));
-        h->used_valid[h->fidx] = true;
-    } else {                 // frames packed on the main stream are ordered by the stream itself: no event per frame
-        h->used_valid[h->fidx] = false;
-        h->used_untracked[h->fidx] = true;
-    }
     h->cnt.integrate_calls++;
     h->cnt.n_voxels_swept += h->n_stored;
     if (stats) {
@@ -478,44 +471,35 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
     lap(tp, h->sp.a_prep2);
     h->staged_xyz = false;
     h->tracked = tsdf_handle::TrackedCloud();
-    if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
-    h->deferred = tsdf_handle::DeferredPack();
+    // the cloud's planes go into a block of the ring of device blocks; the frame's own integrate launch packs them (round 6)
+    int blk = -1;
+    DevPlanes dst;
+    rc = acquire_queue_block(h, &blk, &dst);
+    if (rc) return rc;
     // 1. the tracker's samples, straight from the cloud, in front of everything else (upload_samples_first)
-    const int nb = h->fidx ^ 1;
     lap(tp, h->sp.a_prep);
     rc = upload_samples_first(h, points, (size_t)L->point_stride, (size_t)L->xyz_offset, width);
     if (rc) return rc;
     lap(tp, h->sp.a_gather);
-    h->records_pending = false;              // (this frame's records are written by tsdf_integrate_aos, which orders them itself)
-    choose_pixel_layout(h);
-    h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
-    h->have_frame = true;
-    h->frame_serial++;
-    h->frame_has_nrm = false;                // the pixel records are written when the normals arrive (tsdf_integrate_aos) ...
-    h->frame_has_rgb = color;
-    h->frame_side = true;
-    // 2. the whole cloud -> pinned planes -> in_xyz / in_rgb, on the library threads and the frame stream, under the passes
-    //    (tsdf_track_frame_aos: the normals as well -- one block, one copy -- and the pixel records behind them: the frame is
-    //    complete when the passes are over and tsdf_integrate only waits for that packing on the device)
+    // the frame is current from here on: sample list on its way, packing deferred, no normals yet (tsdf_integrate_aos brings them)
+    rc = defer_pack(h, dst.xyz, nullptr, color ? dst.rgb : nullptr, false, true);
+    if (rc) return rc;
+    h->deferred.samples_listed = true;
+    h->qblk_serial[blk] = h->frame_serial;
+    // 2. the whole cloud -> pinned planes -> the block, on the library threads and the frame stream, under the passes
+    //    (tsdf_track_frame_aos: the normals as well -- one block, one copy: the frame is complete when the passes are over and
+    //    tsdf_integrate only waits for the copy on the device)
     {
         const tsdf_aos_layout lay = *L;
-        PackArgs pa;
-        if (normals) {
-            rc = wait_buffer_free(h, nb, h->fstream);
-            if (rc) return rc;
-            pa = pack_args(h, h->in_xyz, h->in_nrm, color ? h->in_rgb : nullptr, h->pix_su, h->pix_sv, nb);
-            pa.samples = nullptr;                // uploaded above
-        }
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
         h->queued.err = hipSuccess;
-        h->qjob = [h, npix, points, normals, lay, color, pa] {
+        h->qjob = [h, npix, points, normals, lay, color, dst] {
             float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
             hipError_t e = stage_and_upload(h, npix, true, normals != nullptr, color, [&](size_t i0, size_t i1) {
                 repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
-            }, normals ? 2 : 1);
-            if (e == hipSuccess && normals) e = launch_pack(h->fstream, pa);
-            if (e == hipSuccess && normals) e = hipEventRecord(h->ev_frame, h->fstream);
+            }, normals ? 2 : 1, &dst);
+            if (e == hipSuccess) e = hipEventRecord(h->ev_frame, h->fstream);
             h->queued.err = e;
         };
     }
@@ -534,11 +518,12 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
     if (h->queued.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_track_aos: staging the cloud failed: %s", hipGetErrorString(h->queued.err));
     HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));      // the copies out of this set of planes, so far
     h->stage_recorded[0] = true;
-    h->staged_xyz = true; h->staged_planes[0] = h->in_xyz; h->staged_planes[1] = h->in_nrm; h->staged_blk = -1;
+    h->staged_xyz = true; h->staged_planes[0] = dst.xyz; h->staged_planes[1] = dst.nrm; h->staged_blk = blk;
     h->tracked.valid = true; h->tracked.color = color; h->tracked.points = points; h->tracked.w = width; h->tracked.h = height;
     h->tracked.serial = h->frame_serial; h->tracked.lay = *L;
     h->tracked.normals = normals;
-    if (normals) { h->frame_has_nrm = true; h->records_pending = true; }       // ... or are on their way already (ev_frame)
+    if (normals && h->deferred.pending) { h->deferred.nrm = dst.nrm; h->frame_has_nrm = true; }
+    h->records_pending = true;               // whoever integrates this frame waits for the planes' copy (ev_frame) on the device
     return rc_track;
 }
 }  // namespace
@@ -588,7 +573,7 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
     }
     const tsdf_handle::TrackedCloud& tc = h->tracked;
     // is the frame in the library the cloud estimate_new_position was given?  Identity first (cheap), contents below.
-    const bool candidate = tc.valid && h->have_frame && h->staged_xyz && tc.serial == h->frame_serial && tc.w == width && tc.h == height &&
+    const bool candidate = tc.valid && h->have_frame && h->staged_xyz && h->staged_blk >= 0 && tc.serial == h->frame_serial && tc.w == width && tc.h == height &&
                            (!points || (points == tc.points && color == tc.color && L->point_stride == tc.lay.point_stride && L->xyz_offset == tc.lay.xyz_offset &&
                                         L->r_offset == tc.lay.r_offset && L->g_offset == tc.lay.g_offset && L->b_offset == tc.lay.b_offset));
     if (!candidate) {
@@ -604,9 +589,10 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
     // (Launching the integration's list_rows_kernel here, ahead of the normals -- the list needs the pose only -- was built
     // and measured in round 5: 8 alternations, median 2186 frames/s with it against 2311 without.  The launch call delays
     // the repack of the normals by as much as the kernel would later cost: profiles/r05_entry_points.json.)
-    choose_pixel_layout(h);
     const size_t npix = (size_t)width * height;
     const tsdf_aos_layout lay = *L;
+    const int blk = h->staged_blk;
+    const DevPlanes dst = block_planes(h, blk);
     HostPool* const pool = host_pool(h);
     float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
     auto split = [npix](int part, int parts, size_t* i0, size_t* i1) {
@@ -626,7 +612,7 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
                 repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
             };
             if (pool) pool->run(fill); else fill(0, 1);
-            HIP_TRY(h, hipMemcpyAsync(h->in_nrm + 3 * c0, pnm + 3 * c0, (c1 - c0) * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
+            HIP_TRY(h, hipMemcpyAsync(dst.nrm + 3 * c0, pnm + 3 * c0, (c1 - c0) * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
         }
     }
     lap(tp, h->sp.b_normals);
@@ -647,27 +633,24 @@ int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, 
         h->tracked.valid = false;
         HIP_TRY(h, stage_and_upload(h, npix, true, false, color, [&](size_t i0, size_t i1) {
             repack_aos(lay, points, nullptr, color, px, nullptr, pc, i0, i1);
-        }));
+        }, 1, &dst));
     }
     HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));
     h->stage_recorded[0] = true;
-    // 3. the pixel records (and, for a changed cloud, its sample list), then SDF::update
-    rc = wait_buffer_free(h, h->fidx, h->fstream);
-    if (rc) return rc;
-    {
-        PackArgs pa = pack_args(h, h->in_xyz, h->in_nrm, h->frame_has_rgb ? h->in_rgb : nullptr, h->pix_su, h->pix_sv, h->fidx);
-        if (same) pa.samples = nullptr;          // uploaded by tsdf_track_aos
-        EventPair* ep;
-        rc = timed_begin(h, 1, &ep, h->fstream);
-        if (rc) return rc;
-        HIP_TRY(h, launch_pack(h->fstream, pa));
-        rc = timed_end(h, ep, h->fstream);
-        if (rc) return rc;
-    }
+    // 3. SDF::update: the frame's integrate launch packs the records (cloud + the normals that have just been sent) itself, behind
+    //    the copies (ev_frame); for a changed cloud it rewrites the sample list as well
     HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
+    if (!h->deferred.pending) {                  // (packed once already -- a tsdf_synchronize in between: once more, with the normals)
+        borrow_device_frame(h, h->frame_serial, true);
+        h->deferred = tsdf_handle::DeferredPack();
+        h->deferred.pending = true;
+        h->deferred.xyz = dst.xyz; h->deferred.rgb = h->frame_has_rgb ? dst.rgb : nullptr;
+        h->qblk_serial[blk] = h->frame_serial;
+    }
+    h->deferred.nrm = dst.nrm;
+    h->deferred.samples_listed = same;
     h->frame_has_nrm = true;
-    h->frame_side = true;
+    h->records_pending = true;
     h->tracked.valid = false;                // one-shot: a second update of the same cloud uploads it
     lap(tp, h->sp.b_issue);
     rc = tsdf_integrate(h, stats);

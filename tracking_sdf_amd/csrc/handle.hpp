@@ -68,7 +68,6 @@ struct tsdf_handle {
         int rc = 0;                        // tsdf_queue_depth_frame: what the pre-processing on the staging thread returned
         std::string msg;                   // ... and its message, handed to the handle by tsdf_next_frame
     } queued;
-    hipEvent_t ev_queued = nullptr;        // the queued frame's records are packed
     std::thread qthread;                   // runs the pageable path's staging so that the caller can go on tracking
     std::mutex qmu;
     std::condition_variable qcv;
@@ -123,20 +122,16 @@ struct tsdf_handle {
     float4* pn = nullptr;          // 2 x float4 per pixel      } the CURRENT frame's buffers: one of the two below
     float4* samples = nullptr;     //                            }
     size_t pn_cap = 0, samples_cap = 0;
-    // Frame side stream: H2D staging copies, pre-processing and pack_kernel of frame k+1 run on `fstream`, so they
-    // overlap the integration of frame k that is still running on `stream`.  The packed records are double-buffered;
-    // `ev_frame` makes `stream` wait for the pack, `ev_buf_used[b]` makes the pack wait for the last integration that
-    // read buffer b (the tracker passes are host-synchronous and need no event).
+    // Frame side stream: the H2D copies and the depth pre-processing of a frame run on `fstream`, so that they overlap
+    // whatever the main stream is doing (the previous frame's integration, this frame's tracker passes).  Every pack --
+    // inside an integrate launch, or a pack_kernel of its own with TSDF_DEFER_PACK=0 -- runs on the MAIN stream since round 6:
+    // the record buffers need no cross-stream ordering any more.  `ev_frame`: the planes of the current frame are complete.
     hipStream_t fstream = nullptr;
     hipEvent_t ev_frame = nullptr;
     hipEvent_t ev_samples = nullptr;           // the frame's sample list is on the device (samples-first uploads)
-    bool records_pending = false;              // the frame's pixel records are still being produced on the frame stream (ev_frame):
-                                               // the tracker may run (it reads the sample list), tsdf_integrate waits for them
+    bool records_pending = false;              // the frame's planes are still being produced on the frame stream (ev_frame): the tracker
+                                               // may run (it reads the sample list, sent ahead), tsdf_integrate waits for them
     hipEvent_t ev_copied = nullptr;            // the H2D copies of a frame handed over in page-locked caller buffers
-    hipEvent_t ev_buf_used[2] = {nullptr, nullptr};
-    bool used_valid[2] = {false, false};
-    bool used_untracked[2] = {false, false};   // read by an integration that recorded no event
-    bool frame_side = false;                   // the current frame was packed on the frame stream
     // the current frame's records (pn) and sample list are still to be written: tsdf_set_frame_device leaves the
     // packing to the integrate launch, and the tracker reads the samples from the xyz plane meanwhile (defer_pack)
     struct DeferredPack {
@@ -277,15 +272,12 @@ void free_frame(tsdf_handle* h);
 int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_staging);
 void pick_pixel_layout(const tsdf_handle* h, int32_t* su, int32_t* sv);
 void choose_pixel_layout(tsdf_handle* h);
-int wait_buffer_free(tsdf_handle* h, int nb, hipStream_t st);
 PackArgs pack_args(const tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t su, int32_t sv, int nb);
 void borrow_device_frame(tsdf_handle* h, int64_t serial, bool internal = false);
 ReleaseWord release_for(tsdf_handle* h, int64_t serial, int s);
 void abandon_device_frame(tsdf_handle* h, int64_t serial);
 int64_t released_serial(tsdf_handle* h, bool own_blocks_too = false);
-int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, hipStream_t st, bool borrowed_planes = false,
-             bool samples_first = false /* the sample list of this frame went up ahead (upload_samples_first): the pack writes the
-                                           records only and the main stream is NOT made to wait for it here -- tsdf_integrate does */);
+int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool registered);
 int ensure_pin_samples(tsdf_handle* h);
 int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width);
 int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false,
@@ -294,6 +286,9 @@ HostPool* host_pool(tsdf_handle* h);        // the staging threads, started by t
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
                             const std::function<void(size_t, size_t)>& fill, int chunks_when_unset = 1,
                             const struct DevPlanes* dst = nullptr /* default: in_xyz | in_nrm | in_rgb */);
+int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes);      // a free block of the ring of device blocks
+DevPlanes block_planes(const tsdf_handle* h, int blk);
+int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nrm, bool has_rgb, bool samples_listed, bool travelling);
 void queue_thread_main(tsdf_handle* h);
 int ensure_second_staging_set(tsdf_handle* h, size_t npix);
 
