@@ -199,3 +199,19 @@ def test_graft_entry_build_passes():
     if root not in sys.path:
         sys.path.insert(0, root)
     importlib.import_module("__graft_entry__").build()
+
+
+def test_library_and_stand_alone_tracker_code_object_carry_the_same_build_id():
+    """lib/tsdf_track.hsaco (the tracker kernel for the optional AQL queue) is a target of its own and carries
+    the hash of the tracker's sources + flags that the library carries; AqlQueue::init refuses any other code object."""
+    import re
+    libdir = os.path.join(ROOT, "tracking_sdf_amd", "lib")
+    so = open(os.path.join(libdir, "libtsdf_hip.so"), "rb").read()
+    co = open(os.path.join(libdir, "tsdf_track.hsaco"), "rb").read()
+    ids = set(re.findall(rb"(?<![0-9a-f])[0-9a-f]{32}\x00", co))
+    assert len(ids) == 1, ids
+    the_id = next(iter(ids))[:-1]
+    assert so.count(the_id) >= 2          # host side (track_kernel_build_id) and the library's own device code
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    assert ".DELETE_ON_ERROR" in mk and "$(HSACO): $(TRACK_DEPS)" in mk
+

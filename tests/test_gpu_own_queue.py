@@ -84,3 +84,43 @@ def test_two_handles_keep_their_own_queues_apart(monkeypatch):
         assert np.array_equal(D, alone[3]) and np.array_equal(Wt, alone[4])
         assert s.read_counters()["track_passes_own_queue"] > 0
         s.close()
+
+
+def test_a_code_object_of_another_build_is_refused(tmp_path):
+    """A tsdf_track.hsaco whose build id is not the library's (a stale or foreign file next to the .so) must not run in place
+    of the library's kernel: with it, TSDF_AQL=2 says why the queue is not in use, no pass goes through the queue, and the
+    results are the stream's."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "tracking_sdf_amd", "lib")
+    shutil.copy(os.path.join(libdir, "libtsdf_hip.so"), tmp_path / "libtsdf_hip.so")
+    co = open(os.path.join(libdir, "tsdf_track.hsaco"), "rb").read()
+    m = re.search(rb"(?<![0-9a-f])[0-9a-f]{32}\x00", co)
+    assert m
+    bad = bytearray(co)
+    bad[m.start()] = ord("f") if co[m.start()] != ord("f") else ord("0")
+    (tmp_path / "tsdf_track.hsaco").write_bytes(bytes(bad))
+    code = (
+        "import numpy as np, tracking_sdf_amd as ts\n"
+        "from tracking_sdf_amd import synth\n"
+        f"seq = synth.Sequence(n_frames=4, width={W}, height={H}, noise=True, holes=0.02, step=4)\n"
+        f"s = ts.SDF({M}, with_color=True); t = ts.CameraTracking(sdf=s); t.set_K(seq.K)\n"
+        "for k in range(4):\n"
+        "    s.set_frame(*seq.frame(k))\n"
+        "    if k: t.estimate_new_position()\n"
+        "    s.update()\n"
+        "cn = s.read_counters(); print('OWNQ', cn['track_passes_own_queue'], cn['track_iterations'], float(t.trans[0]))\n")
+    outs = {}
+    for name, libpath in (("bad", str(tmp_path / "libtsdf_hip.so")), ("good", os.path.join(libdir, "libtsdf_hip.so"))):
+        env = dict(os.environ, TSDF_AQL="2", TSDF_HIP_LIB=libpath, PYTHONPATH=root)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[name] = (p.stdout.strip().splitlines()[-1].split(), p.stderr)
+    assert int(outs["good"][0][1]) > 0                               # the right code object: the queue carries the later passes
+    assert int(outs["bad"][0][1]) == 0 and "not this library's build" in outs["bad"][1]
+    assert outs["bad"][0][2:] == outs["good"][0][2:]                 # same passes, same pose
+

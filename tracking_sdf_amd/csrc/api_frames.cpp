@@ -36,7 +36,6 @@ void free_preproc(tsdf_handle* h) {
 
 void free_frame(tsdf_handle* h) {
     // (xyz | nrm | rgb live in ONE block each: the xyz pointer is the block)
-    if (h->in_xyz) (void)hipFree(h->in_xyz);
     if (h->pin_xyz) (void)hipHostFree(h->pin_xyz);
     if (h->alt_xyz) (void)hipHostFree(h->alt_xyz);
     for (int b = 0; b < 2; ++b) { if (h->pin_samples[b]) (void)hipHostFree(h->pin_samples[b]); h->pin_samples[b] = nullptr; }
@@ -45,7 +44,6 @@ void free_frame(tsdf_handle* h) {
     for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) { if (h->qblk[b]) (void)hipFree(h->qblk[b]); h->qblk[b] = nullptr; h->qblk_serial[b] = 0; }
     h->qblk_cap = 0;
     h->staged_planes[0] = h->staged_planes[1] = nullptr;
-    h->in_xyz = h->in_nrm = nullptr; h->in_rgb = nullptr;
     h->pin_xyz = h->pin_nrm = nullptr; h->pin_rgb = nullptr;
     h->alt_xyz = h->alt_nrm = nullptr; h->alt_rgb = nullptr; h->alt_cap = 0;
     h->stage_recorded[0] = h->stage_recorded[1] = false;
@@ -87,9 +85,7 @@ int ensure_frame_buffers(tsdf_handle* h, int32_t w, int32_t hh, bool need_stagin
         // then ONE host-to-device copy (measured: the copies of a 640x480 frame are bound by their number, not their
         // bytes -- 12 copies per frame 3450 frames/s from PCL clouds, 3 copies 4140)
         const size_t plane = plane_stride_bytes(npix);
-        char* dev = nullptr; char* pin = nullptr;
-        HIP_TRY(h, hipMalloc((void**)&dev, frame_block_bytes(npix)));
-        h->in_xyz = reinterpret_cast<float*>(dev); h->in_nrm = reinterpret_cast<float*>(dev + plane); h->in_rgb = reinterpret_cast<uint8_t*>(dev + 2 * plane);
+        char* pin = nullptr;
         HIP_TRY(h, hipHostMalloc((void**)&pin, frame_block_bytes(npix), hipHostMallocDefault));
         h->pin_xyz = reinterpret_cast<float*>(pin); h->pin_nrm = reinterpret_cast<float*>(pin + plane); h->pin_rgb = reinterpret_cast<uint8_t*>(pin + 2 * plane);
         h->in_cap = npix;
@@ -283,7 +279,7 @@ HostPool* host_pool(tsdf_handle* h) {
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
                             const std::function<void(size_t, size_t)>& fill, int chunks_when_unset, const DevPlanes* dst) {
     constexpr int kMaxChunks = 16;
-    float* const d_xyz = dst ? dst->xyz : h->in_xyz; float* const d_nrm = dst ? dst->nrm : h->in_nrm; uint8_t* const d_rgb = dst ? dst->rgb : h->in_rgb;
+    float* const d_xyz = dst->xyz; float* const d_nrm = dst->nrm; uint8_t* const d_rgb = dst->rgb;
     // TSDF_STAGE_CHUNKS overrides; otherwise the caller's choice: 1 where only throughput counts (the frame queue), 2 where
     // the frame's LATENCY to the device is on the critical path (tsdf_track_frame_aos: medians 2570 / 2850 / 2790 / 2760
     // frames/s with 1 / 2 / 3 / 4 pieces, six alternations)
@@ -357,8 +353,8 @@ DevPlanes block_planes(const tsdf_handle* h, int blk) {
     return p;
 }
 
-// A block of the ring of device blocks for a frame that arrives from host memory (or as raw depth): allocated on first use (same layout as the in_xyz | in_nrm |
-// in_rgb block), free of the frame it held before -- that frame's planes were packed by its own integrate launch, which
+// A block of the ring of device blocks for a frame that arrives from host memory (or as raw depth): allocated on first use (xyz | nrm | rgb,
+// the layout of the pinned staging sets), free of the frame it held before -- that frame's planes were packed by its own integrate launch, which
 // publishes a release ticket (tsdf_device_frame_released's mechanism); two frames later it has long run, so the wait below
 // is a formality, bounded and backed by a real synchronisation.
 int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes) {
@@ -777,7 +773,7 @@ int depth_frame_prepare(tsdf_handle* h, const char* who, bool queued, const uint
     return TSDF_OK;
 }
 
-// Upload, back-projection, filter and normals of a depth frame on the frame stream; in_xyz / in_nrm / in_rgb hold the
+// Upload, back-projection, filter and normals of a depth frame on the frame stream; the planes of `out` hold the
 // frame afterwards.  Runs on the caller's thread (tsdf_set_depth_frame) or on the queue's library thread
 // (tsdf_queue_depth_frame): the bilateral grid's depth extent is the one host round trip of this path.
 // a pageable buffer into pinned staging memory, on the staging threads (the depth + rgb of a 640x480 frame are 1.5 MB:
@@ -916,7 +912,6 @@ int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float*
 int tsdf_get_preprocessed(tsdf_handle* h, float* xyz, float* nrm) {
     int rc = check_ready(h, true);
     if (rc) return rc;
-    if (!h->in_xyz || h->in_cap < (size_t)h->fw * h->fh) return fail(h, TSDF_E_NO_FRAME, "no pre-processed frame held");
     // (a frame queued behind the current one goes into a block of its own since round 6: the current frame's planes stay)
     if (!h->staged_xyz || !h->staged_planes[0] || !h->staged_planes[1])
         return fail(h, TSDF_E_NO_FRAME, "tsdf_get_preprocessed: the library does not hold the planes of the current frame (it came from device memory)");

@@ -82,7 +82,6 @@ struct tsdf_handle {
     int32_t fw = 0, fh = 0, ncols = 0, nrows = 0, n_samples = 0;
     int32_t pix_su = 1, pix_sv = 0;   // layout of the packed pixel records of the current frame
     bool have_frame = false, frame_has_nrm = false, frame_has_rgb = false;
-    float* in_xyz = nullptr; float* in_nrm = nullptr; uint8_t* in_rgb = nullptr;   // device staging (owned)
     float* pin_xyz = nullptr; float* pin_nrm = nullptr; uint8_t* pin_rgb = nullptr;  // pinned host staging (the set in use)
     // second staging set of the frame queue's pageable path: frame k+1 is filled into one set while the DMA engine still
     // reads frame k from the other (with one set the caller's thread waited for those copies before every queue call)
@@ -100,10 +99,10 @@ struct tsdf_handle {
     bool stage_recorded[2] = {false, false};
     size_t in_cap = 0;             // pixels the staging buffers hold
     bool staged_xyz = false;       // the library holds the planes of the CURRENT frame on the device (host / AoS / depth frames) ...
-    const float* staged_planes[2] = {nullptr, nullptr};   // ... here: xyz, nrm (in_xyz / in_nrm, or a block of the ring)
-    int staged_blk = -1;           // the ring block that holds them (-1: the in_xyz | in_nrm | in_rgb block)
+    const float* staged_planes[2] = {nullptr, nullptr};   // ... here: xyz, nrm of a block of the ring below
+    int staged_blk = -1;           // the ring block that holds them
     // Frames that come through the QUEUE from host memory or as raw depth (round 6): their planes land in one of three
-    // device blocks (same layout as in_xyz | in_nrm | in_rgb) and are packed like a frame handed over in device memory --
+    // device blocks (xyz | nrm | rgb, the layout of the pinned staging sets) and are packed like a frame handed over in device memory --
     // by workgroups appended to the frame's OWN integrate launch, the first tracker pass reading its samples from the xyz
     // plane -- instead of by a pack_kernel of their own on the frame stream, which ran next to the current frame's
     // latency-bound tracker passes (profiles/r06_host_queue.json: 4270-4470 -> 4900+ frames/s).  A block is reused once
@@ -284,8 +283,7 @@ int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t
                bool own_block = false /* the planes are a block of the library's own ring */);
 HostPool* host_pool(tsdf_handle* h);        // the staging threads, started by the first pageable frame
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
-                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset = 1,
-                            const struct DevPlanes* dst = nullptr /* default: in_xyz | in_nrm | in_rgb */);
+                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset, const struct DevPlanes* dst);
 int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes);      // a free block of the ring of device blocks
 DevPlanes block_planes(const tsdf_handle* h, int blk);
 int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nrm, bool has_rgb, bool samples_listed, bool travelling);
