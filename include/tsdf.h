@@ -258,13 +258,15 @@ void tsdf_default_preproc(tsdf_preproc_params *p);
 int tsdf_set_depth_frame(tsdf_handle *h, const uint16_t *depth16, const float *depthf, const uint8_t *rgb,
                          int32_t width, int32_t height, const tsdf_preproc_params *params);
 /* The same through the two-deep frame queue (tsdf_queue_frame's rules: one frame queued at a time, of the current
- * frame's size, buffers borrowed until tsdf_next_frame returns): upload, pre-processing -- including its one host round
- * trip for the bilateral grid's depth range -- and packing run on a library thread and the frame stream while the caller
- * tracks and integrates the current frame.  What tsdf_set_depth_frame would have returned for the frame (bad depth
- * range ...) is returned by tsdf_next_frame. */
+ * frame's size, buffers borrowed until tsdf_next_frame returns): upload and pre-processing -- including its one host round
+ * trip for the bilateral grid's depth range -- run on a library thread and the frame stream while the caller tracks and
+ * integrates the current frame (the pixel records are written by the frame's own integrate launch).  What
+ * tsdf_set_depth_frame would have returned for the frame (bad depth range ...) is returned by tsdf_next_frame. */
 int tsdf_queue_depth_frame(tsdf_handle *h, const uint16_t *depth16, const float *depthf, const uint8_t *rgb,
                          int32_t width, int32_t height, const tsdf_preproc_params *params);
-/* copy the current pre-processed frame back (any pointer may be null): xyz, normals as float[h*w*3] */
+/* copy the current frame's planes back as the library holds them (any pointer may be null): xyz, normals as float[h*w*3];
+ * for frames that came from host memory or as raw depth (also while the next frame is queued behind them), TSDF_E_NO_FRAME
+ * for frames handed over in device memory */
 int tsdf_get_preprocessed(tsdf_handle *h, float *xyz, float *nrm);
 
 /* ---- the hot path ------------------------------------------------------------------------- */
@@ -413,8 +415,8 @@ typedef struct tsdf_counters {
     int64_t track_in_grid;      /* owned in-grid samples over all passes (each does <= 13 look-ups)    */
     int64_t track_terms;
     int64_t integrate_items;    /* 64-voxel work items the row clip produced (each is one 512-byte {D,W} segment) */
-    int64_t track_passes_own_queue; /* Gauss-Newton passes submitted through the library's own AQL queue (0: tsdf_kernels.hsaco
-                                 * was not found next to the library, TSDF_AQL=0, or no pass >= 1 qualified); ABI 3 */
+    int64_t track_passes_own_queue; /* Gauss-Newton passes the library's own AQL queue took (an option, TSDF_AQL=1; 0 by default, or when
+                                 * tsdf_track.hsaco next to the library is missing / not this build's, or no pass >= 1 qualified); ABI 3 */
 } tsdf_counters;
 int tsdf_set_timing(tsdf_handle *h, int32_t on);
 int tsdf_read_timing(tsdf_handle *h, tsdf_timing *out, int32_t reset);
