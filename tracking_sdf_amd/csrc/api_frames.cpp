@@ -197,10 +197,20 @@ int ensure_pin_samples(tsdf_handle* h) {
     h->pin_samples_cap = ns;
     return TSDF_OK;
 }
+bool samples_first_enabled() {
+    static const bool on = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
+    return on;
+}
 int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width) {
     int rc = ensure_pin_samples(h);
     if (rc) return rc;
-    const int nb = h->fidx ^ 1;
+    rc = stage_samples(h, base, pixel_bytes, xyz_offset, width, h->fidx ^ 1);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_samples, 0));
+    return TSDF_OK;
+}
+// gather + copy + ev_samples on the frame stream (pin_samples must exist: ensure_pin_samples on the caller's thread)
+int stage_samples(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width, int nb) {
     float4* const ps = h->pin_samples[nb];
     const int32_t st = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows;
     const std::function<void(int, int)> gather = [&](int part, int parts) {
@@ -211,7 +221,6 @@ int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, s
     if (pool) pool->run(gather); else gather(0, 1);
     HIP_TRY(h, hipMemcpyAsync(h->samples_buf[nb], ps, (size_t)h->n_samples * sizeof(float4), hipMemcpyHostToDevice, h->fstream));
     HIP_TRY(h, hipEventRecord(h->ev_samples, h->fstream));
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_samples, 0));
     return TSDF_OK;
 }
 
@@ -428,7 +437,7 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     rc = acquire_queue_block(h, &blk, &dst);
     if (rc) return rc;
     if (!direct) {
-        static const bool samples_first = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
+        const bool samples_first = samples_first_enabled();
         if (samples_first) { rc = upload_samples_first(h, xyz, 12, 0, width); if (rc) return rc; }
         HIP_TRY(h, stage_and_upload(h, npix, true, nrm != nullptr, rgb != nullptr, [&](size_t i0, size_t i1) {
             std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
@@ -484,7 +493,8 @@ int ensure_second_staging_set(tsdf_handle* h, size_t npix) {
 namespace {
 // what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
 int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
-                       bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
+                       bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill,
+                       const void* sample_base = nullptr, size_t pixel_bytes = 0, size_t xyz_offset = 0 /* pageable: where the tracker's samples are */) {
     int rc = bind_device(h);
     if (rc) return rc;
     if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
@@ -495,7 +505,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     const size_t npix = (size_t)width * height;
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess; q.rc = TSDF_OK;
-    q.deferred = q.packed = false;
+    q.deferred = q.packed = false; q.samples_listed = false;
     // The frame's planes go into a block of the queue's ring and stay there, unpacked, until the frame is current: its own
     // integrate launch packs them (tsdf_next_frame -> defer_pack).  Nothing but the copy runs on the frame stream.
     DevPlanes dst;
@@ -515,6 +525,12 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     // the frame before the current one, and the library thread, not the caller, waits for those if it has to.
     rc = ensure_second_staging_set(h, npix);
     if (rc) return rc;
+    // Samples first (as for frames handed over one at a time): the tracker's sample list is gathered from the caller's memory
+    // and copied ahead of the planes, so that the frame's first passes wait for 0.5 MB, not for the 8.3 MB behind it -- only
+    // its integrate launch waits for the planes (records_pending).
+    const bool samples_first = sample_base != nullptr && samples_first_enabled();
+    if (samples_first) { rc = ensure_pin_samples(h); if (rc) return rc; }
+    const int nb = q.nb;
     const auto t_queued = std::chrono::steady_clock::now();
     if (!h->qthread.joinable()) {
         try { h->qthread = std::thread(queue_thread_main, h); }
@@ -523,7 +539,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     {
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
-        h->qjob = [h, npix, has_nrm, has_rgb, fill, dst, blk, t_queued] {
+        h->qjob = [h, npix, width, has_nrm, has_rgb, fill, dst, blk, t_queued, samples_first, sample_base, pixel_bytes, xyz_offset, nb] {
             const auto ts0 = std::chrono::steady_clock::now();
             if (h->sp.on) h->sp.handoff += std::chrono::duration<double, std::nano>(ts0 - t_queued).count();
             // switch to the other staging set (fill and stage_and_upload read h->pin_* when they run)
@@ -531,6 +547,12 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
             std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
             hipError_t e = h->stage_recorded[0] ? hipEventSynchronize(h->ev_stage_done[0]) : hipSuccess;
             if (h->sp.on) h->sp.sync_before += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ts0).count();
+            if (e == hipSuccess && samples_first) {
+                t_err_sink = &h->queued.msg;
+                const int r = stage_samples(h, sample_base, pixel_bytes, xyz_offset, width, nb);
+                t_err_sink = nullptr;
+                if (r == TSDF_OK) h->queued.samples_listed = true; else h->queued.rc = r;
+            }
             if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill, 1, &dst);
             if (e == hipSuccess) { e = hipEventRecord(h->ev_stage_done[0], h->fstream); h->stage_recorded[0] = e == hipSuccess; }
             if (e == hipSuccess) e = hipEventRecord(h->ev_qblk[blk], h->fstream);
@@ -553,7 +575,7 @@ int tsdf_queue_frame(tsdf_handle* h, const float* xyz, const float* nrm, const u
         if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
         if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
     };
-    return queue_frame_common(h, xyz, nrm, rgb, width, height, nrm != nullptr, rgb != nullptr, fill);
+    return queue_frame_common(h, xyz, nrm, rgb, width, height, nrm != nullptr, rgb != nullptr, fill, direct ? nullptr : xyz, 12, 0);
 }
 
 int tsdf_queue_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height) {
@@ -571,7 +593,7 @@ int tsdf_queue_frame_aos(tsdf_handle* h, const void* points, const void* normals
     std::function<void(size_t, size_t)> fill = [h, points, normals, lay, color](size_t i0, size_t i1) {
         repack_aos(lay, points, normals, color, h->pin_xyz, h->pin_nrm, h->pin_rgb, i0, i1);
     };
-    return queue_frame_common(h, nullptr, nullptr, nullptr, width, height, normals != nullptr, color, fill);
+    return queue_frame_common(h, nullptr, nullptr, nullptr, width, height, normals != nullptr, color, fill, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset);
 }
 
 int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
@@ -636,16 +658,15 @@ int tsdf_next_frame(tsdf_handle* h) {
             if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; h->err = q.msg; return r; }
             if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
         }
+        const DevPlanes bp = block_planes(h, blk);
+        if (q.samples_listed) {
+            // the sample list went up ahead: the passes wait for it alone, the integrate launch for the planes (records_pending)
+            q.samples_listed = false;
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_samples, 0));
+            return block_frame_current(h, blk, bp, q.has_nrm, q.has_rgb, true, true);
+        }
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_qblk[blk], 0));   // the first tracker pass and the integrate launch read the planes
-        const size_t plane = plane_stride_bytes(h->in_cap);
-        const float* const bx = reinterpret_cast<const float*>(h->qblk[blk]);
-        const float* const bn = reinterpret_cast<const float*>(h->qblk[blk] + plane);
-        const uint8_t* const bc = reinterpret_cast<const uint8_t*>(h->qblk[blk] + 2 * plane);
-        rc = defer_pack(h, bx, q.has_nrm ? bn : nullptr, q.has_rgb ? bc : nullptr, false, true);
-        if (rc) return rc;
-        h->qblk_serial[blk] = h->frame_serial;               // the block is this frame's until the launch that packs it has run
-        h->staged_xyz = true; h->staged_planes[0] = bx; h->staged_planes[1] = bn; h->staged_blk = blk;
-        return TSDF_OK;
+        return block_frame_current(h, blk, bp, q.has_nrm, q.has_rgb, false, false);
     }
     return fail(h, TSDF_E_BADARG, "tsdf_next_frame: the queued frame has no device block (internal error)");
 }
@@ -688,8 +709,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
     float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
     const tsdf_aos_layout lay = *L;
     // a new cloud: its tracker samples go up first (the passes of a following tsdf_track run under the planes' copy)
-    static const bool samples_first_on = [] { const char* e = std::getenv("TSDF_SAMPLES_FIRST"); return !(e && std::atoi(e) == 0); }();
-    const bool samples_first = samples_first_on && points != nullptr;
+    const bool samples_first = samples_first_enabled() && points != nullptr;
     if (points) {
         // a whole new frame: its planes go into a block of the ring and are packed by its own integrate launch (round 6)
         int blk = -1;

@@ -58,6 +58,7 @@ struct tsdf_handle {
     struct Queued {
         bool active = false, direct = false, device = false, has_nrm = false, has_rgb = false;
         int blk = -1;                      // >= 0: a host / depth frame whose planes are (being) put into qblk[blk]
+        bool samples_listed = false;       // ... and whose sample list went up ahead of the planes (ev_samples)
         // device frames with deferred packing: nothing is launched when the frame is queued; the current frame's integrate
         // launch packs it (packed = true), or it becomes current unpacked like a frame of tsdf_set_frame_device
         bool deferred = false, packed = false;
@@ -279,6 +280,8 @@ int64_t released_serial(tsdf_handle* h, bool own_blocks_too = false);
 int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool registered);
 int ensure_pin_samples(tsdf_handle* h);
 int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width);
+int stage_samples(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width, int nb);   // ... without the main stream's wait
+bool samples_first_enabled();
 int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false,
                bool own_block = false /* the planes are a block of the library's own ring */);
 HostPool* host_pool(tsdf_handle* h);        // the staging threads, started by the first pageable frame
