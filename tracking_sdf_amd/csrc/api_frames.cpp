@@ -493,8 +493,7 @@ int ensure_second_staging_set(tsdf_handle* h, size_t npix) {
 namespace {
 // what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
 int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
-                       bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill,
-                       const void* sample_base = nullptr, size_t pixel_bytes = 0, size_t xyz_offset = 0 /* pageable: where the tracker's samples are */) {
+                       bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
     int rc = bind_device(h);
     if (rc) return rc;
     if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
@@ -505,7 +504,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     const size_t npix = (size_t)width * height;
     tsdf_handle::Queued& q = h->queued;
     q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess; q.rc = TSDF_OK;
-    q.deferred = q.packed = false; q.samples_listed = false;
+    q.deferred = q.packed = false;
     // The frame's planes go into a block of the queue's ring and stay there, unpacked, until the frame is current: its own
     // integrate launch packs them (tsdf_next_frame -> defer_pack).  Nothing but the copy runs on the frame stream.
     DevPlanes dst;
@@ -525,12 +524,9 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     // the frame before the current one, and the library thread, not the caller, waits for those if it has to.
     rc = ensure_second_staging_set(h, npix);
     if (rc) return rc;
-    // Samples first (as for frames handed over one at a time): the tracker's sample list is gathered from the caller's memory
-    // and copied ahead of the planes, so that the frame's first passes wait for 0.5 MB, not for the 8.3 MB behind it -- only
-    // its integrate launch waits for the planes (records_pending).
-    const bool samples_first = sample_base != nullptr && samples_first_enabled();
-    if (samples_first) { rc = ensure_pin_samples(h); if (rc) return rc; }
-    const int nb = q.nb;
+    // (No "samples first" here, unlike frames handed over one at a time: a queued frame's copy runs under the frame before
+    // it, and gathering its sample list on the library thread cost more than the passes' shorter wait gave back --
+    // profiles/r06_host_queue.json, "samples_first_in_queue".)
     const auto t_queued = std::chrono::steady_clock::now();
     if (!h->qthread.joinable()) {
         try { h->qthread = std::thread(queue_thread_main, h); }
@@ -539,7 +535,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     {
         std::lock_guard<std::mutex> g(h->qmu);
         h->qbusy = true;
-        h->qjob = [h, npix, width, has_nrm, has_rgb, fill, dst, blk, t_queued, samples_first, sample_base, pixel_bytes, xyz_offset, nb] {
+        h->qjob = [h, npix, has_nrm, has_rgb, fill, dst, blk, t_queued] {
             const auto ts0 = std::chrono::steady_clock::now();
             if (h->sp.on) h->sp.handoff += std::chrono::duration<double, std::nano>(ts0 - t_queued).count();
             // switch to the other staging set (fill and stage_and_upload read h->pin_* when they run)
@@ -547,12 +543,6 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
             std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
             hipError_t e = h->stage_recorded[0] ? hipEventSynchronize(h->ev_stage_done[0]) : hipSuccess;
             if (h->sp.on) h->sp.sync_before += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ts0).count();
-            if (e == hipSuccess && samples_first) {
-                t_err_sink = &h->queued.msg;
-                const int r = stage_samples(h, sample_base, pixel_bytes, xyz_offset, width, nb);
-                t_err_sink = nullptr;
-                if (r == TSDF_OK) h->queued.samples_listed = true; else h->queued.rc = r;
-            }
             if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill, 1, &dst);
             if (e == hipSuccess) { e = hipEventRecord(h->ev_stage_done[0], h->fstream); h->stage_recorded[0] = e == hipSuccess; }
             if (e == hipSuccess) e = hipEventRecord(h->ev_qblk[blk], h->fstream);
@@ -575,7 +565,7 @@ int tsdf_queue_frame(tsdf_handle* h, const float* xyz, const float* nrm, const u
         if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
         if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
     };
-    return queue_frame_common(h, xyz, nrm, rgb, width, height, nrm != nullptr, rgb != nullptr, fill, direct ? nullptr : xyz, 12, 0);
+    return queue_frame_common(h, xyz, nrm, rgb, width, height, nrm != nullptr, rgb != nullptr, fill);
 }
 
 int tsdf_queue_frame_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height) {
@@ -593,7 +583,7 @@ int tsdf_queue_frame_aos(tsdf_handle* h, const void* points, const void* normals
     std::function<void(size_t, size_t)> fill = [h, points, normals, lay, color](size_t i0, size_t i1) {
         repack_aos(lay, points, normals, color, h->pin_xyz, h->pin_nrm, h->pin_rgb, i0, i1);
     };
-    return queue_frame_common(h, nullptr, nullptr, nullptr, width, height, normals != nullptr, color, fill, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset);
+    return queue_frame_common(h, nullptr, nullptr, nullptr, width, height, normals != nullptr, color, fill);
 }
 
 int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
@@ -659,12 +649,6 @@ int tsdf_next_frame(tsdf_handle* h) {
             if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
         }
         const DevPlanes bp = block_planes(h, blk);
-        if (q.samples_listed) {
-            // the sample list went up ahead: the passes wait for it alone, the integrate launch for the planes (records_pending)
-            q.samples_listed = false;
-            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_samples, 0));
-            return block_frame_current(h, blk, bp, q.has_nrm, q.has_rgb, true, true);
-        }
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_qblk[blk], 0));   // the first tracker pass and the integrate launch read the planes
         return block_frame_current(h, blk, bp, q.has_nrm, q.has_rgb, false, false);
     }

@@ -58,7 +58,6 @@ struct tsdf_handle {
     struct Queued {
         bool active = false, direct = false, device = false, has_nrm = false, has_rgb = false;
         int blk = -1;                      // >= 0: a host / depth frame whose planes are (being) put into qblk[blk]
-        bool samples_listed = false;       // ... and whose sample list went up ahead of the planes (ev_samples)
         // device frames with deferred packing: nothing is launched when the frame is queued; the current frame's integrate
         // launch packs it (packed = true), or it becomes current unpacked like a frame of tsdf_set_frame_device
         bool deferred = false, packed = false;
