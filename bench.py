@@ -84,6 +84,9 @@ def parse(argv=None):
                          "in-library RCCL all-reduce (falls back to the shared-memory fan-in only if RCCL fails its self-test); shm = "
                          "host-side fan-in through a POSIX shared segment; peer = device-side exchange through HIP-IPC-mapped buffers "
                          "(tsdf_comm_init_peer)")
+    ap.add_argument("--queue-ahead", type=int, default=2, choices=[1, 2],
+                    help="frames waiting in the library's queue behind the current one in the host-frame legs (the queue takes "
+                         "two; 1 = round 5's two-deep use)")
     ap.add_argument("--no-frame-queue", dest="frame_queue", action="store_false",
                     help="set every HBM-resident frame in front of its own tracker passes (tsdf_set_frame_device) instead of queueing frame "
                          "k+1 (tsdf_queue_frame_device) while frame k is processed.  Default since round 6: the queue -- frame k+1 is then "
@@ -589,19 +592,21 @@ def run(args):
             elif mode == "depth_q":
                 qd = lambda i: self.sdf.queue_depth_frame(depth16[i], host[i][2])
                 if k == 0:
-                    qd(0)
+                    for j in range(min(args.queue_ahead, len(host))):
+                        qd(j)
                 self.sdf.next_frame()
-                if k + 1 < len(host):
-                    qd(k + 1)
+                if k + args.queue_ahead < len(host):
+                    qd(k + args.queue_ahead)
             elif mode in ("host_q", "aos_q"):
-                # two-deep queue: frame k was queued during step k-1 and becomes current now; frame k+1 is queued before
-                # frame k is tracked and integrated, so its upload runs under the whole of frame k's GPU work
+                # the frame queue: frame k was queued during step k-2 (k-1 with --queue-ahead 1) and becomes current now;
+                # frame k+2 is queued before frame k is tracked and integrated, so its staging and upload have two frames' time
                 q = self.sdf.queue_frame if mode == "host_q" else self.sdf.queue_frame_aos
                 if k == 0:
-                    q(*host[0])
+                    for j in range(min(args.queue_ahead, len(host))):
+                        q(*host[j])
                 self.sdf.next_frame()
-                if k + 1 < len(host):
-                    q(*host[k + 1])
+                if k + args.queue_ahead < len(host):
+                    q(*host[k + args.queue_ahead])
             else:
                 self.sdf.set_depth_frame(depth16[k], host[k][2])
 
@@ -951,7 +956,7 @@ def run(args):
         extras["value_pcl_clouds_inclusive"] = args.steps / e4
         extras["pcl_clouds_note"] = ("frames handed over as arrays of PCL's 32-byte point / normal structs in pageable memory "
                                      "(tsdf_set_frame_aos): what the reference's callback holds, sdf_reconstruction.cpp:33-49")
-        # the same three host-buffer workloads through the two-deep queue (tsdf_queue_frame / tsdf_next_frame)
+        # the same three host-buffer workloads through the frame queue (tsdf_queue_frame / tsdf_next_frame, --queue-ahead frames waiting)
         extras["value_h2d_inclusive_queued"] = args.steps / best_of_two("host_q", [tuple(np.ascontiguousarray(a) for a in f) for f in host_frames])
         extras["value_h2d_inclusive_pinned_buffers_queued"] = args.steps / best_of_two("host_q", pinned_frames)
         extras["value_pcl_clouds_inclusive_queued"] = args.steps / best_of_two("aos_q", aos)
@@ -1164,8 +1169,10 @@ def run(args):
             out["end_to_end"] = {
                 "value": e2e, "unit": "frames/s", "over_device_resident": e2e / (args.steps / elapsed),
                 "what": "xyz + normals + rgb (27 B/pixel, 8.3 MB per 640x480 frame) handed over in PAGEABLE host memory every frame "
-                        "through tsdf_queue_frame / tsdf_next_frame (frame k+1 is staged and copied while frame k is tracked and "
-                        "integrated); same frames, same volume size, same kernels as `value`",
+                        "through tsdf_queue_frame / tsdf_next_frame (%s while frame k is tracked and "
+                        "integrated); same frames, same volume size, same kernels as `value`"
+                        % ("frames k+1 and k+2 wait in the queue: k+2 is staged and copied" if args.queue_ahead == 2 else "frame k+1 is staged and copied"),
+                "frames_waiting_in_the_queue": args.queue_ahead,
                 "page_locked_planes": extras.get("value_h2d_inclusive_pinned_buffers_queued"),
                 "pcl_clouds_pageable": extras.get("value_pcl_clouds_inclusive_queued"),
                 "raw_depth_pageable": extras.get("value_depth_input_inclusive_queued"),

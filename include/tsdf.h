@@ -167,15 +167,19 @@ int tsdf_set_frame_device(tsdf_handle *h, const float *d_xyz, const float *d_nrm
  * compares.  -1 for a NULL handle.  Monotonic; equals tsdf_frame_serial() (+1 with a packed queued device frame) once
  * everything handed over has been read, e.g. after tsdf_synchronize. */
 int64_t tsdf_device_frame_released(const tsdf_handle *h);
-/* Two-deep frame queue: upload and pack the NEXT frame while the current one is still being tracked and integrated
+/* Frame queue: upload coming frames while the current one is still being tracked and integrated
  * (the reference's callback has the next cloud in its subscriber queue while it works on the current one,
  * sdf_reconstruction.cpp:89: queue size 1).  tsdf_queue_frame / tsdf_queue_frame_aos return at once: page-locked
  * plane buffers are read by the DMA engine, pageable ones (and PCL-style arrays of structs) by a library thread that
  * repacks them into pinned staging planes with the TSDF_HOST_THREADS pool -- either way the caller's buffers are
- * BORROWED UNTIL tsdf_next_frame RETURNS and must not change meanwhile.  The hot calls in between (tsdf_track,
- * tsdf_integrate, tsdf_track_and_integrate) keep working on the current frame.  tsdf_next_frame makes the queued frame
- * the current one (device-side wait, no host block beyond the end of the host-side repack).  One frame can be queued
- * at a time, of the same size as the current one; tsdf_set_frame* while a frame is queued is an error.
+ * BORROWED UNTIL THE tsdf_next_frame THAT MAKES THE FRAME CURRENT RETURNS and must not change meanwhile.  The hot
+ * calls in between (tsdf_track, tsdf_integrate, tsdf_track_and_integrate) keep working on the current frame.
+ * tsdf_next_frame makes the oldest queued frame the current one (device-side wait, no host block beyond the end of the
+ * host-side repack).  TWO frames can wait behind the current one (one, until round 5 of this library): a frame's staging + copy
+ * (the copy alone is 155 us for 640x480, a frame's GPU work 190 us) then has two frame times instead of one, which is
+ * what takes the queue from 0.85-0.93 of the device-resident rate to 0.95+.  A third tsdf_queue_frame* is
+ * TSDF_E_BADARG; so is a frame of another size than the current / queued ones, tsdf_set_frame* while a frame is queued,
+ * and tsdf_queue_frame_device behind a queued frame (a frame in device memory has nothing to hide: first place only).
  * tsdf_queue_frame_aos needs the points (it has no 'normals only' form). */
 int tsdf_queue_frame(tsdf_handle *h, const float *xyz, const float *nrm, const uint8_t *rgb, int32_t width, int32_t height);
 /* The same for a frame that is already in device memory (tsdf_set_frame_device's layouts and borrowing rule: the
@@ -257,8 +261,8 @@ void tsdf_default_preproc(tsdf_preproc_params *p);
 /* depth16 (uint16) or depthf (float metres, <= 0 / NaN invalid): exactly one non-null; host pointers; rgb may be null */
 int tsdf_set_depth_frame(tsdf_handle *h, const uint16_t *depth16, const float *depthf, const uint8_t *rgb,
                          int32_t width, int32_t height, const tsdf_preproc_params *params);
-/* The same through the two-deep frame queue (tsdf_queue_frame's rules: one frame queued at a time, of the current
- * frame's size, buffers borrowed until tsdf_next_frame returns): upload and pre-processing -- including its one host round
+/* The same through the frame queue (tsdf_queue_frame's rules: up to two frames waiting, of the current frame's size,
+ * buffers borrowed until the tsdf_next_frame that makes the frame current returns): upload and pre-processing -- including its one host round
  * trip for the bilateral grid's depth range -- run on a library thread and the frame stream while the caller tracks and
  * integrates the current frame (the pixel records are written by the frame's own integrate launch).  What
  * tsdf_set_depth_frame would have returned for the frame (bad depth range ...) is returned by tsdf_next_frame. */

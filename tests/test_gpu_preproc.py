@@ -138,18 +138,22 @@ def test_queued_depth_frames_give_the_same_trajectory_and_volume(pinned):
         else:
             frames.append((z16, np.ascontiguousarray(rgb)))
 
-    def run(queued):
+    def run(queued, ahead=1):
         s = ts.SDF(m, with_color=True)
         t = ts.CameraTracking(sdf=s)
         t.set_K(seq.K)
         poses, pres = [], []
         if queued:
-            s.queue_depth_frame(*frames[0], depth_scale=1.0 / 5000.0, **params)
+            for j in range(ahead):
+                s.queue_depth_frame(*frames[j], depth_scale=1.0 / 5000.0, **params)
         for k in range(n):
             if queued:
                 s.next_frame()
-                if k + 1 < n:
-                    s.queue_depth_frame(*frames[k + 1], depth_scale=1.0 / 5000.0, **params)
+                if k + ahead < n:
+                    s.queue_depth_frame(*frames[k + ahead], depth_scale=1.0 / 5000.0, **params)
+                    if ahead == 2:
+                        with pytest.raises(ts.TsdfError):
+                            s.queue_depth_frame(*frames[k + ahead], depth_scale=1.0 / 5000.0, **params)   # current + 2: full
                     with pytest.raises(ts.TsdfError):
                         s.set_depth_frame(*frames[k], depth_scale=1.0 / 5000.0, **params)      # a frame is queued
             else:
@@ -165,16 +169,17 @@ def test_queued_depth_frames_give_the_same_trajectory_and_volume(pinned):
         out = (poses, s.download(), s.download_color(), pre, pres)
         s.close()
         return out
-    want, got = run(False), run(True)
-    for (r0, t0), (r1, t1) in zip(want[0], got[0]):
-        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
-    for a, b in zip(want[1] + want[2], got[1] + got[2]):
-        assert np.array_equal(a, b)
-    for a, b in zip(want[3], got[3]):
-        assert np.array_equal(a, b, equal_nan=True)
-    for pa, pb in zip(want[4], got[4]):                     # every frame's pre-processed planes, read while it was current
-        for a, b in zip(pa, pb):
+    want = run(False)
+    for got in (run(True), run(True, ahead=2)):             # one frame waiting, two frames waiting
+        for (r0, t0), (r1, t1) in zip(want[0], got[0]):
+            assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+        for a, b in zip(want[1] + want[2], got[1] + got[2]):
+            assert np.array_equal(a, b)
+        for a, b in zip(want[3], got[3]):
             assert np.array_equal(a, b, equal_nan=True)
+        for pa, pb in zip(want[4], got[4]):                 # every frame's pre-processed planes, read while it was current
+            for a, b in zip(pa, pb):
+                assert np.array_equal(a, b, equal_nan=True)
     # a depth range that is no usable bilateral grid: refused by the frame's tsdf_next_frame, the current frame stays
     s = ts.SDF(32)
     t = ts.CameraTracking(sdf=s)

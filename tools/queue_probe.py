@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Pageable frames through the library's frame queue, nothing else: frames/s for --ahead frames waiting, with the staging
+profile (TSDF_PROFILE=1 prints it when the volume is closed).  python3 tools/queue_probe.py --ahead 2 --frames 60"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import tracking_sdf_amd as ts
+from tracking_sdf_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ahead", type=int, default=2)
+ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--warmup", type=int, default=6)
+ap.add_argument("--m", type=int, default=512)
+ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device"])
+ap.add_argument("--repeat", type=int, default=3)
+a = ap.parse_args()
+n = a.frames + a.warmup + 1
+seq = synth.Sequence(n_frames=n, width=640, height=480, noise=True, holes=0.02)
+dev = torch.device("cuda:0")
+fr = [seq.frame_torch(k, dev) for k in range(n)]
+host = [tuple(np.ascontiguousarray(t.cpu().numpy()) for t in f) for f in fr]
+if a.kind == "pinned":
+    hold = [tuple(torch.from_numpy(x).pin_memory() for x in f) for f in host]
+    host = [tuple(t.numpy() for t in f) for f in hold]
+s = ts.SDF(a.m, with_color=True)
+t = ts.CameraTracking(sdf=s)
+t.set_K(seq.K)
+L = ts.lib()
+rates = []
+for rep in range(a.repeat):
+    s.reset()
+    def q(i):
+        if a.kind == "device":
+            s.queue_frame_device(fr[i][0].data_ptr(), fr[i][1].data_ptr(), fr[i][2].data_ptr(), 640, 480, keep=fr[i])
+        else:
+            s.queue_frame(*host[i])
+    ahead = 1 if a.kind == "device" else a.ahead
+    for j in range(ahead):
+        q(j)
+    t0 = None
+    for k in range(n):
+        if k == a.warmup + 1:
+            s.synchronize(); t0 = time.perf_counter()
+        s.next_frame()
+        if k + ahead < n:
+            q(k + ahead)
+        if k == 0:
+            s.update(want_stats=False)
+        else:
+            s._check(L.tsdf_track_and_integrate(s._h, 1, None, None))
+    s.synchronize()
+    rates.append(a.frames / (time.perf_counter() - t0))
+print("queue_probe", a.kind, "ahead", a.ahead, "threads", os.environ.get("TSDF_HOST_THREADS", "default"), "frames/s", [round(r, 1) for r in rates], flush=True)
+s.close()

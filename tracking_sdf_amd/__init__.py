@@ -446,7 +446,7 @@ class SDF:
         """tsdf_queue_depth_frame: the same through the two-deep frame queue (see queue_frame); the arrays are borrowed
         until next_frame returns (references are kept that long)."""
         keep = self._depth_frame(lib().tsdf_queue_depth_frame, depth, rgb, params)
-        self._queued_keep = keep
+        self._queued_keep = (getattr(self, "_queued_keep", None) or []) + [keep]
 
     def _depth_frame(self, entry, depth, rgb, params):
         pp = PreprocParams()
@@ -553,8 +553,9 @@ class SDF:
         return _struct_dict(st) if want_stats else None
 
     def queue_frame(self, xyz, normals=None, rgb=None):
-        """tsdf_queue_frame: stage the NEXT frame while the current one is tracked / integrated.  The arrays are borrowed
-        until next_frame() returns (they are kept alive here); they must already be C-contiguous float32 / uint8."""
+        """tsdf_queue_frame: stage a coming frame while the current one is tracked / integrated (up to two frames may wait:
+        the second gives a frame's staging and copy two frame times).  The arrays are borrowed until the next_frame()
+        that makes this frame current returns (they are kept alive here); they must already be C-contiguous float32 / uint8."""
         for a, dt in ((xyz, np.float32), (normals, np.float32), (rgb, np.uint8)):
             if a is not None and not (a.flags["C_CONTIGUOUS"] and a.dtype == dt):
                 raise ValueError("queue_frame borrows the buffers: C-contiguous float32 / uint8 arrays are needed")
@@ -562,7 +563,8 @@ class SDF:
         keep = (xyz, normals, rgb)
         self._check(lib().tsdf_queue_frame(self._h, _fptr(xyz), _fptr(normals) if normals is not None else None,
                                            rgb.ctypes.data_as(C.POINTER(C.c_uint8)) if rgb is not None else None, w, h))
-        self._queued_keep = keep       # only now: a refused call must not drop the references of the frame that IS queued
+        # only now: a refused call must not drop the references of the frames that ARE queued (up to two, oldest first)
+        self._queued_keep = (getattr(self, "_queued_keep", None) or []) + [keep]
 
     def queue_frame_aos(self, points, normals=None):
         """tsdf_queue_frame_aos: as queue_frame, for arrays of point structs (see set_frame_aos)."""
@@ -580,12 +582,12 @@ class SDF:
             raise ValueError("queue_frame_aos borrows the buffers: C-contiguous arrays are needed")
         keep = (points, normals)
         self._check(lib().tsdf_queue_frame_aos(self._h, C.c_void_p(points.ctypes.data), nn, C.byref(lay), points.shape[1], points.shape[0]))
-        self._queued_keep = keep
+        self._queued_keep = (getattr(self, "_queued_keep", None) or []) + [keep]
 
     def next_frame(self):
-        """tsdf_next_frame: the queued frame becomes the current one; its buffers are the caller's again."""
+        """tsdf_next_frame: the oldest queued frame becomes the current one; its buffers are the caller's again."""
         self._check(lib().tsdf_next_frame(self._h))
-        self._queued_keep = None
+        self._queued_keep = (getattr(self, "_queued_keep", None) or [])[1:]
 
     def set_frame_device(self, d_xyz, d_normals, d_rgb, width, height, keep=None):
         """Borrow device pointers (ints, e.g. torch.Tensor.data_ptr()) of images already in HBM.  The frame is packed

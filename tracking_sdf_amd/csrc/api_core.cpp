@@ -297,11 +297,8 @@ void tsdf_destroy(tsdf_handle* h) {
         std::fprintf(stderr, "TRACKPROFILE passes %lld  ns per pass: parameters %.0f  launch call %.0f  wait for the row %.0f  fold+solve+pose %.0f\n",
                      h->tp_passes, h->tp_fill / h->tp_passes, h->tp_launch / h->tp_passes, h->tp_wait / h->tp_passes, h->tp_post / h->tp_passes);
     if (h->qthread.joinable()) {                           // the staging thread of the frame queue
-        {
-            std::unique_lock<std::mutex> g(h->qmu);
-            h->qcv.wait(g, [&] { return !h->qbusy; });
-            h->qstop = true;
-        }
+        wait_staging_job(h, 0);
+        { std::lock_guard<std::mutex> g(h->qmu); h->qstop = true; }
         h->qcv.notify_all();
         h->qthread.join();
     }
@@ -451,10 +448,7 @@ int tsdf_read_counters(tsdf_handle* h, tsdf_counters* out, int32_t reset) {
 int tsdf_synchronize(tsdf_handle* h) {
     int rc = check_ready(h, false);
     if (rc) return rc;
-    {   // a queued pageable frame: its copies and pack are only on the frame stream once the staging thread has issued them
-        std::unique_lock<std::mutex> g(h->qmu);
-        h->qcv.wait(g, [&] { return !h->qbusy; });
-    }
+    wait_staging_job(h, 0);    // queued pageable frames: their copies are only on the frame stream once the staging thread has issued them
     // Device frames whose packing is still deferred: tsdf_synchronize ends the library's claim on borrowed device
     // planes (tsdf.h), so what has not been packed yet is packed now, by a launch of its own
     if (h->deferred.pending) {
@@ -463,10 +457,10 @@ int tsdf_synchronize(tsdf_handle* h) {
         HIP_TRY(h, launch_pack(h->stream, own));
         h->deferred.pending = false;
     }
-    if (h->queued.active && h->queued.device && !h->queued.packed) {      // (deferred or, TSDF_DEFER_PACK=0, waiting for tsdf_next_frame)
-        tsdf_handle::Queued& q = h->queued;
+    if (h->qcount > 0 && h->queued_front().device && !h->queued_front().packed) {      // (deferred or, TSDF_DEFER_PACK=0, waiting for tsdf_next_frame)
+        tsdf_handle::Queued& q = h->queued_front();
         pick_pixel_layout(h, &q.su, &q.sv);
-        HIP_TRY(h, launch_pack(h->stream, pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, q.nb)));
+        HIP_TRY(h, launch_pack(h->stream, pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, h->fidx ^ 1)));
         q.packed = true;
     }
     HIP_TRY(h, hipStreamSynchronize(h->fstream));

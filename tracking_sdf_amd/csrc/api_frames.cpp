@@ -147,7 +147,7 @@ int64_t released_serial(tsdf_handle* h, bool own_blocks_too) {
         return b.stream < 0 || (b.ticket && __atomic_load_n(h->release_host + b.stream, __ATOMIC_ACQUIRE) < b.ticket);
     };
     while (!h->borrowed.empty() && !pending(h->borrowed.front())) h->borrowed.pop_front();
-    int64_t rel = h->frame_serial + ((h->queued.active && h->queued.device) ? 1 : 0);
+    int64_t rel = h->frame_serial + ((h->qcount > 0 && h->queued_front().device) ? 1 : 0);   // (a device frame waits at the front only)
     for (const auto& b : h->borrowed)
         if ((own_blocks_too || !b.internal) && pending(b)) { rel = b.serial - 1; break; }
     if (h->borrow_lost >= 0 && rel >= h->borrow_lost) rel = h->borrow_lost - 1;
@@ -162,7 +162,7 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);      // the frame this one replaces was never packed
     choose_pixel_layout(h);
     const int nb = h->fidx ^ 1;                               // the buffer the previous frame did not use
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first");
+    if (h->qcount > 0) return fail(h, TSDF_E_BADARG, "a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first");
     EventPair* ep;
     int rc = timed_begin(h, 1, &ep, h->stream);
     if (rc) return rc;
@@ -416,7 +416,7 @@ int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nr
 
 int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height) {
     if (!h || !xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame: bad argument") : TSDF_E_BADARG;
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame");
+    if (h->qcount > 0) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame");
     int rc = bind_device(h);
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, true);
@@ -463,14 +463,35 @@ void queue_thread_main(tsdf_handle* h) {
         std::function<void()> job;
         {
             std::unique_lock<std::mutex> g(h->qmu);
-            h->qcv.wait(g, [&] { return h->qstop || h->qjob; });
-            if (h->qstop) return;
-            job.swap(h->qjob);
+            h->qcv.wait(g, [&] { return h->qstop || !h->qjobs.empty(); });
+            if (h->qjobs.empty()) return;                   // (qstop is only set once the thread is idle)
+            job.swap(h->qjobs.front());
+            h->qjobs.pop_front();
         }
         job();
-        { std::lock_guard<std::mutex> g(h->qmu); h->qbusy = false; }
+        { std::lock_guard<std::mutex> g(h->qmu); h->qdone++; }
         h->qcv.notify_all();
     }
+}
+
+uint64_t submit_staging_job(tsdf_handle* h, std::function<void()> job) {
+    if (!h->qthread.joinable()) {
+        try { h->qthread = std::thread(queue_thread_main, h); }
+        catch (...) { return 0; }
+    }
+    uint64_t id = 0;
+    try {
+        std::lock_guard<std::mutex> g(h->qmu);
+        h->qjobs.push_back(std::move(job));
+        id = ++h->qissued;
+    } catch (...) { return 0; }
+    h->qcv.notify_all();
+    return id;
+}
+
+void wait_staging_job(tsdf_handle* h, uint64_t job) {
+    std::unique_lock<std::mutex> g(h->qmu);
+    h->qcv.wait(g, [&] { return h->qdone >= (job ? job : h->qissued); });
 }
 
 // the second set of pinned staging planes (the frame queue and tsdf_track_aos alternate between two sets)
@@ -491,20 +512,31 @@ int ensure_second_staging_set(tsdf_handle* h, size_t npix) {
 }  // namespace tsdf_api
 
 namespace {
+// May one more frame be queued?  Behind an empty queue anything; behind one queued frame a host or depth frame (`from_host`),
+// of the same size as everything else in flight.
+int queue_admit(tsdf_handle* h, bool from_host, int32_t width, int32_t height) {
+    if (h->qcount >= tsdf_handle::kQueueDepth)
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: %d frames are queued already (the queue holds the current frame + %d)", h->qcount, tsdf_handle::kQueueDepth);
+    if (h->qcount > 0 && !from_host)
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame_device: a frame is queued already (a frame in device memory is taken as the first queued frame only)");
+    if ((h->have_frame || h->qcount > 0) && (h->fw != width || h->fh != height))
+        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    return TSDF_OK;
+}
+
 // what both queue entry points share.  `fill` is null for page-locked plane buffers (copied from directly).
 int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, int32_t width, int32_t height,
                        bool has_nrm, bool has_rgb, std::function<void(size_t, size_t)> fill) {
     int rc = bind_device(h);
     if (rc) return rc;
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
-    if (h->have_frame && (h->fw != width || h->fh != height))
-        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    rc = queue_admit(h, true, width, height);
+    if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, true);
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
-    tsdf_handle::Queued& q = h->queued;
-    q.nb = h->fidx ^ 1; q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill; q.device = false; q.err = hipSuccess; q.rc = TSDF_OK;
-    q.deferred = q.packed = false;
+    tsdf_handle::Queued& q = h->queued_slot(h->qcount);
+    q = tsdf_handle::Queued();
+    q.has_nrm = has_nrm; q.has_rgb = has_rgb; q.direct = !fill;
     // The frame's planes go into a block of the queue's ring and stay there, unpacked, until the frame is current: its own
     // integrate launch packs them (tsdf_next_frame -> defer_pack).  Nothing but the copy runs on the frame stream.
     DevPlanes dst;
@@ -516,7 +548,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
         if (nrm) HIP_TRY(h, hipMemcpyAsync(dst.nrm, nrm, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
         if (rgb) HIP_TRY(h, hipMemcpyAsync(dst.rgb, rgb, npix * 3, hipMemcpyHostToDevice, h->fstream));
         HIP_TRY(h, hipEventRecord(h->ev_qblk[blk], h->fstream));
-        q.active = true;
+        q.active = true; h->qcount++;
         return TSDF_OK;
     }
     // pageable buffers: a library thread fills pinned staging planes (with the staging pool) and issues copies and pack
@@ -528,14 +560,8 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
     // it, and gathering its sample list on the library thread cost more than the passes' shorter wait gave back --
     // profiles/r06_host_queue.json, "samples_first_in_queue".)
     const auto t_queued = std::chrono::steady_clock::now();
-    if (!h->qthread.joinable()) {
-        try { h->qthread = std::thread(queue_thread_main, h); }
-        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_frame: cannot start the staging thread"); }
-    }
-    {
-        std::lock_guard<std::mutex> g(h->qmu);
-        h->qbusy = true;
-        h->qjob = [h, npix, has_nrm, has_rgb, fill, dst, blk, t_queued] {
+    tsdf_handle::Queued* const slot = &q;
+    q.job = submit_staging_job(h, [h, npix, has_nrm, has_rgb, fill, dst, blk, t_queued, slot] {
             const auto ts0 = std::chrono::steady_clock::now();
             if (h->sp.on) h->sp.handoff += std::chrono::duration<double, std::nano>(ts0 - t_queued).count();
             // switch to the other staging set (fill and stage_and_upload read h->pin_* when they run)
@@ -546,11 +572,10 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
             if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill, 1, &dst);
             if (e == hipSuccess) { e = hipEventRecord(h->ev_stage_done[0], h->fstream); h->stage_recorded[0] = e == hipSuccess; }
             if (e == hipSuccess) e = hipEventRecord(h->ev_qblk[blk], h->fstream);
-            h->queued.err = e;
-        };
-    }
-    h->qcv.notify_all();
-    q.active = true;
+            slot->err = e;
+        });
+    if (!q.job) return fail(h, TSDF_E_NOMEM, "tsdf_queue_frame: cannot start the staging thread");
+    q.active = true; h->qcount++;
     return TSDF_OK;
 }
 }  // namespace
@@ -590,29 +615,30 @@ int tsdf_queue_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_n
     if (!h || !d_xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_queue_frame_device: bad argument") : TSDF_E_BADARG;
     int rc = bind_device(h);
     if (rc) return rc;
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: a frame is queued already (the queue is two deep: current + next)");
-    if (h->have_frame && (h->fw != width || h->fh != height))
-        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    rc = queue_admit(h, false, width, height);
+    if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, false);
     if (rc) return rc;
-    tsdf_handle::Queued& q = h->queued;
-    q.nb = h->fidx ^ 1; q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true; q.err = hipSuccess; q.rc = TSDF_OK;
+    tsdf_handle::Queued& q = h->queued_slot(0);
+    q = tsdf_handle::Queued();
+    q.has_nrm = d_nrm != nullptr; q.has_rgb = d_rgb != nullptr; q.direct = true; q.device = true;
     // No launch now.  Default: the integrate launch of the CURRENT frame packs this one in workgroups appended to its
     // list_rows_kernel (tsdf_integrate), on the main stream, i.e. behind the last reader of the record buffer (q.deferred).
     // TSDF_DEFER_PACK=0: a pack_kernel launch of its own when the frame becomes current (tsdf_next_frame).
     q.deferred = h->defer_device_pack; q.packed = false;
     q.d_xyz = d_xyz; q.d_nrm = d_nrm; q.d_rgb = d_rgb;
-    q.active = true;
+    q.active = true; h->qcount = 1;
     borrow_device_frame(h, h->frame_serial + 1);
     return TSDF_OK;
 }
 
 int tsdf_next_frame(tsdf_handle* h) {
     if (!h) return TSDF_E_BADARG;
-    tsdf_handle::Queued& q = h->queued;
-    if (!q.active) return fail(h, TSDF_E_NO_FRAME, "tsdf_next_frame: no frame is queued");
+    if (h->qcount == 0) return fail(h, TSDF_E_NO_FRAME, "tsdf_next_frame: no frame is queued");
     int rc = bind_device(h);
     if (rc) return rc;
+    tsdf_handle::Queued& q = h->queued_front();
+    h->qhead = (h->qhead + 1) % tsdf_handle::kQueueDepth; h->qcount--;     // (q stays where it is: the slot is rewritten by the next tsdf_queue_frame*)
     q.active = false;
     const bool from_device = q.device;
     q.device = false;
@@ -624,7 +650,8 @@ int tsdf_next_frame(tsdf_handle* h) {
             return deferred ? defer_pack(h, q.d_xyz, q.d_nrm, q.d_rgb, true) : run_pack(h, q.d_xyz, q.d_nrm, q.d_rgb, true);
         // packed inside the previous frame's integrate launch (or by tsdf_synchronize), on the main stream: nothing to wait for
         if (h->deferred.pending) abandon_device_frame(h, h->frame_serial);
-        h->fidx = q.nb; h->pn = h->pn_buf[q.nb]; h->samples = h->samples_buf[q.nb];
+        const int nb = h->fidx ^ 1;                        // where the launch that packed it put its records
+        h->fidx = nb; h->pn = h->pn_buf[nb]; h->samples = h->samples_buf[nb];
         h->deferred = tsdf_handle::DeferredPack();
         h->pix_su = q.su; h->pix_sv = q.sv;
         h->have_frame = true;
@@ -642,8 +669,7 @@ int tsdf_next_frame(tsdf_handle* h) {
             HIP_TRY(h, hipEventSynchronize(h->ev_qblk[blk]));
         } else {
             const auto tw0 = std::chrono::steady_clock::now();
-            std::unique_lock<std::mutex> g(h->qmu);
-            h->qcv.wait(g, [&] { return !h->qbusy; });       // the staging thread is done with the caller's buffers
+            wait_staging_job(h, q.job);                      // the staging thread is done with the caller's buffers
             if (h->sp.on) h->sp.next_wait += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
             if (q.rc != TSDF_OK) { const int r = q.rc; q.rc = TSDF_OK; h->err = q.msg; return r; }
             if (q.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_queue_frame: staging failed: %s", hipGetErrorString(q.err));
@@ -657,7 +683,7 @@ int tsdf_next_frame(tsdf_handle* h) {
 
 int tsdf_set_frame_device(tsdf_handle* h, const float* d_xyz, const float* d_nrm, const uint8_t* d_rgb, int32_t width, int32_t height) {
     if (!h || !d_xyz || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_device: bad argument") : TSDF_E_BADARG;
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_device");
+    if (h->qcount > 0) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_device");
     int rc = bind_device(h);
     if (rc) return rc;
     rc = ensure_frame_buffers(h, width, height, false);
@@ -671,7 +697,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
                        int32_t width, int32_t height) {
     if (!h || !L || (!points && !normals) || width <= 0 || height <= 0)
         return h ? fail(h, TSDF_E_BADARG, "tsdf_set_frame_aos: bad argument") : TSDF_E_BADARG;
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_aos");
+    if (h->qcount > 0) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_set_frame_aos");
     const bool color = points && L->r_offset >= 0 && L->g_offset >= 0 && L->b_offset >= 0;
     if (points && (L->point_stride < 12 || L->xyz_offset < 0 || L->xyz_offset + 12 > L->point_stride ||
                    (color && (L->r_offset >= L->point_stride || L->g_offset >= L->point_stride || L->b_offset >= L->point_stride))))
@@ -753,12 +779,11 @@ int depth_frame_prepare(tsdf_handle* h, const char* who, bool queued, const uint
         return fail(h, TSDF_E_BADARG, "%s: the bilateral grid takes sigma_s in [1, 30] pixels, not %g", who, (double)pp.sigma_s);
     if (depth16 && !(pp.depth_scale > 0))
         return fail(h, TSDF_E_BADARG, "%s: depth_scale must be positive", who);
-    if (h->queued.active)
+    if (!queued && h->qcount > 0)
         return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", who);
     int rc = bind_device(h);
     if (rc) return rc;
-    if (queued && h->have_frame && (h->fw != width || h->fh != height))
-        return fail(h, TSDF_E_BADARG, "tsdf_queue_frame: the queued frame must have the size of the current one (%dx%d)", h->fw, h->fh);
+    if (queued) { rc = queue_admit(h, true, width, height); if (rc) return rc; }
     rc = ensure_frame_buffers(h, width, height, true);
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
@@ -880,36 +905,29 @@ int tsdf_queue_depth_frame(tsdf_handle* h, const uint16_t* depth16, const float*
     tsdf_preproc_params pp;
     int rc = depth_frame_prepare(h, "tsdf_queue_depth_frame", true, depth16, depthf, width, height, params, &pp);
     if (rc) return rc;
-    tsdf_handle::Queued& q = h->queued;
-    q.nb = h->fidx ^ 1; q.has_nrm = true; q.has_rgb = rgb != nullptr; q.direct = false; q.device = false; q.err = hipSuccess;
-    q.deferred = q.packed = false; q.rc = TSDF_OK;
+    tsdf_handle::Queued& q = h->queued_slot(h->qcount);
+    q = tsdf_handle::Queued();
+    q.has_nrm = true; q.has_rgb = rgb != nullptr;
     // the pre-processed planes go into a block of the queue's ring and are packed by the frame's own integrate launch
     DevPlanes dst;
     rc = acquire_queue_block(h, &q.blk, &dst);
     if (rc) return rc;
     const int blk = q.blk;
-    if (!h->qthread.joinable()) {
-        try { h->qthread = std::thread(queue_thread_main, h); }
-        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_queue_depth_frame: cannot start the staging thread"); }
-    }
-    {
-        std::lock_guard<std::mutex> g(h->qmu);
-        h->qbusy = true;
-        h->qjob = [h, depth16, depthf, rgb, width, height, pp, dst, blk] {
+    tsdf_handle::Queued* const slot = &q;
+    q.job = submit_staging_job(h, [h, depth16, depthf, rgb, width, height, pp, dst, blk, slot] {
             bool direct = false;
-            t_err_sink = &h->queued.msg;
+            t_err_sink = &slot->msg;
             int r = depth_frame_work(h, "tsdf_queue_depth_frame", depth16, depthf, rgb, width, height, pp, &direct, dst);
             t_err_sink = nullptr;
             hipError_t e = hipSuccess;
             if (r == TSDF_OK) e = hipEventRecord(h->ev_qblk[blk], h->fstream);
             const bool use_grid = pp.grid_filter != 0 && pp.radius > 0;
             if (r == TSDF_OK && e == hipSuccess && direct && !use_grid) e = hipEventSynchronize(h->ev_copied);   // the caller's buffers have been read
-            h->queued.rc = r;
-            h->queued.err = e;
-        };
-    }
-    h->qcv.notify_all();
-    q.active = true;
+            slot->rc = r;
+            slot->err = e;
+        });
+    if (!q.job) return fail(h, TSDF_E_NOMEM, "tsdf_queue_depth_frame: cannot start the staging thread");
+    q.active = true; h->qcount++;
     return TSDF_OK;
 }
 

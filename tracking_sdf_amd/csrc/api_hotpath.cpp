@@ -251,8 +251,8 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     PackArgs pa;
     bool fused = false, fused_queued = false;
     ReleaseWord rel;                         // tells the host when the borrowed planes packed by this launch have been read
-    tsdf_handle::Queued& q = h->queued;
-    if (q.active && q.device && q.deferred && !q.packed) {
+    tsdf_handle::Queued& q = h->queued_front();       // (a frame in device memory waits at the front of the queue only)
+    if (h->qcount > 0 && q.active && q.device && q.deferred && !q.packed) {
         const bool own_too = h->deferred.pending;
         if (own_too) {
             PackArgs own = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
@@ -261,7 +261,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
             h->deferred.pending = false;
         }
         q.su = h->pix_su; q.sv = h->pix_sv;      // laid out for this frame's pose: the next one's is close to it
-        pa = pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, q.nb);
+        pa = pack_args(h, q.d_xyz, q.d_nrm, q.d_rgb, q.su, q.sv, h->fidx ^ 1);
         rel = release_for(h, h->frame_serial + 1, 0);
         if (own_too)                             // the launch in front, same stream: read by the time the ticket appears
             for (auto& b : h->borrowed) if (b.serial == h->frame_serial) { b.stream = 0; b.ticket = rel.ticket; }
@@ -441,7 +441,7 @@ int tsdf_track_frame_aos(tsdf_handle* h, const void* points, const void* normals
 namespace {
 int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height, tsdf_track_stats* stats) {
     if (!h || !L || !points || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_track_aos: bad argument") : TSDF_E_BADARG;
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_track_aos");
+    if (h->qcount > 0) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_track_aos");
     bool color = false;
     int rc = check_point_layout(h, "tsdf_track_aos", L, &color);
     if (rc) return rc;
@@ -460,10 +460,6 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
     lap(tp, h->sp.a_prep1);
     rc = ensure_pin_samples(h);
     if (rc) return rc;
-    if (!h->qthread.joinable()) {
-        try { h->qthread = std::thread(queue_thread_main, h); }
-        catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_track_aos: cannot start the staging thread"); }
-    }
     // the other set of pinned planes: the copies out of it were those of the frame before the last one
     std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
     std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
@@ -489,33 +485,29 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
     // 2. the whole cloud -> pinned planes -> the block, on the library threads and the frame stream, under the passes
     //    (tsdf_track_frame_aos: the normals as well -- one block, one copy: the frame is complete when the passes are over and
     //    tsdf_integrate only waits for the copy on the device)
+    uint64_t job = 0;
     {
         const tsdf_aos_layout lay = *L;
-        std::lock_guard<std::mutex> g(h->qmu);
-        h->qbusy = true;
-        h->queued.err = hipSuccess;
-        h->qjob = [h, npix, points, normals, lay, color, dst] {
+        h->stage_err = hipSuccess;
+        job = submit_staging_job(h, [h, npix, points, normals, lay, color, dst] {
             float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
             hipError_t e = stage_and_upload(h, npix, true, normals != nullptr, color, [&](size_t i0, size_t i1) {
                 repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
             }, normals ? 2 : 1, &dst);
             if (e == hipSuccess) e = hipEventRecord(h->ev_frame, h->fstream);
-            h->queued.err = e;
-        };
+            h->stage_err = e;
+        });
     }
-    h->qcv.notify_all();
+    if (!job) return fail(h, TSDF_E_NOMEM, "tsdf_track_aos: cannot start the staging thread");
     lap(tp, h->sp.a_issue);
     // 3. estimate_new_position on the list
     const int rc_track = track_loop(h, stats);
     lap(tp, h->sp.a_loop);
     // 4. the cloud is the caller's again when this call returns
-    {
-        std::unique_lock<std::mutex> g(h->qmu);
-        h->qcv.wait(g, [&] { return !h->qbusy; });
-    }
+    wait_staging_job(h, job);
     lap(tp, h->sp.a_wait);
     if (prof) h->sp.aos_frames++;
-    if (h->queued.err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_track_aos: staging the cloud failed: %s", hipGetErrorString(h->queued.err));
+    if (h->stage_err != hipSuccess) return fail(h, TSDF_E_HIP, "tsdf_track_aos: staging the cloud failed: %s", hipGetErrorString(h->stage_err));
     HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));      // the copies out of this set of planes, so far
     h->stage_recorded[0] = true;
     h->staged_xyz = true; h->staged_planes[0] = dst.xyz; h->staged_planes[1] = dst.nrm; h->staged_blk = blk;
@@ -531,7 +523,7 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
 int tsdf_integrate_aos(tsdf_handle* h, const void* points, const void* normals, const tsdf_aos_layout* L, int32_t width, int32_t height,
                        tsdf_integrate_stats* stats) {
     if (!h || !L || !normals || width <= 0 || height <= 0) return h ? fail(h, TSDF_E_BADARG, "tsdf_integrate_aos: bad argument (the normals are required)") : TSDF_E_BADARG;
-    if (h->queued.active) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_integrate_aos");
+    if (h->qcount > 0) return fail(h, TSDF_E_BADARG, "%s: a frame is queued (tsdf_queue_frame): take it with tsdf_next_frame first", "tsdf_integrate_aos");
     bool color = false;
     int rc = points ? check_point_layout(h, "tsdf_integrate_aos", L, &color) : TSDF_OK;
     if (rc) return rc;

@@ -53,8 +53,12 @@ struct tsdf_handle {
     unsigned long long* wg_counts = nullptr;      // device: {owned, halo} voxels updated, cumulative, per integrate workgroup
     unsigned long long* wg_counts_host = nullptr; // pinned mirror
     int64_t frame_serial = 0;      // frames made current so far (tsdf_frame_serial)
-    // two-deep frame queue (tsdf_queue_frame / tsdf_next_frame): the NEXT frame is uploaded and packed into the pixel
-    // buffer the current frame does not use while the current one is tracked and integrated
+    // Frame queue (tsdf_queue_frame* / tsdf_next_frame): up to kQueueDepth frames wait behind the current one while it is
+    // tracked and integrated -- their planes travel to (or already sit in) device memory meanwhile.  A frame handed over
+    // in DEVICE memory only as the first of them (its records are packed ahead, into the record buffer the current frame
+    // does not use); host and depth frames in either place: the second one gives the staging + copy of a frame two frame
+    // times instead of one (the copy alone is 155 us of a 190 us frame: profiles/r06_host_queue.json).
+    static constexpr int kQueueDepth = 2;
     struct Queued {
         bool active = false, direct = false, device = false, has_nrm = false, has_rgb = false;
         int blk = -1;                      // >= 0: a host / depth frame whose planes are (being) put into qblk[blk]
@@ -62,17 +66,22 @@ struct tsdf_handle {
         // launch packs it (packed = true), or it becomes current unpacked like a frame of tsdf_set_frame_device
         bool deferred = false, packed = false;
         const float* d_xyz = nullptr; const float* d_nrm = nullptr; const uint8_t* d_rgb = nullptr;
-        int nb = 0;
         int32_t su = 1, sv = 0;
+        uint64_t job = 0;                  // > 0: the staging thread's job for this frame (done once qdone >= job)
         hipError_t err = hipSuccess;       // what the staging thread's HIP calls returned
         int rc = 0;                        // tsdf_queue_depth_frame: what the pre-processing on the staging thread returned
         std::string msg;                   // ... and its message, handed to the handle by tsdf_next_frame
-    } queued;
+    } qslot[kQueueDepth];
+    int qhead = 0, qcount = 0;             // the queue: qslot[qhead] is the frame tsdf_next_frame takes next
+    Queued& queued_front() { return qslot[qhead]; }
+    Queued& queued_slot(int pos) { return qslot[(qhead + pos) % kQueueDepth]; }
     std::thread qthread;                   // runs the pageable path's staging so that the caller can go on tracking
     std::mutex qmu;
     std::condition_variable qcv;
-    std::function<void()> qjob;
-    bool qbusy = false, qstop = false;
+    std::deque<std::function<void()>> qjobs;   // in order, one at a time (they share the pinned staging sets and the frame stream's order)
+    uint64_t qissued = 0, qdone = 0;       // jobs handed to the thread / finished (under qmu)
+    bool qstop = false;
+    hipError_t stage_err = hipSuccess;     // tsdf_track_aos: what its staging job's HIP calls returned
     void* worklist = nullptr;      // integrate work items (32-byte descriptors: row << 6 | chunk, the row's share of rot_inv * g)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
     int integrate_blocks = 0;      // persistent grid of integrate_kernel: the most workgroups a launch uses (CUs x workgroups per CU)
@@ -101,17 +110,17 @@ struct tsdf_handle {
     bool staged_xyz = false;       // the library holds the planes of the CURRENT frame on the device (host / AoS / depth frames) ...
     const float* staged_planes[2] = {nullptr, nullptr};   // ... here: xyz, nrm of a block of the ring below
     int staged_blk = -1;           // the ring block that holds them
-    // Frames that come through the QUEUE from host memory or as raw depth (round 6): their planes land in one of three
+    // Frames that come through the QUEUE from host memory or as raw depth (round 6): their planes land in one of kQueueBlocks
     // device blocks (xyz | nrm | rgb, the layout of the pinned staging sets) and are packed like a frame handed over in device memory --
     // by workgroups appended to the frame's OWN integrate launch, the first tracker pass reading its samples from the xyz
     // plane -- instead of by a pack_kernel of their own on the frame stream, which ran next to the current frame's
     // latency-bound tracker passes (profiles/r06_host_queue.json: 4270-4470 -> 4900+ frames/s).  A block is reused once
     // the launch that packed its frame has run (the release tickets of tsdf_device_frame_released).
-    static constexpr int kQueueBlocks = 3;
-    char* qblk[kQueueBlocks] = {nullptr, nullptr, nullptr};
+    static constexpr int kQueueBlocks = kQueueDepth + 2;   // the current frame's, the queued frames', and one whose integrate launch may still run
+    char* qblk[kQueueBlocks] = {};
     size_t qblk_cap = 0;                                   // pixels a block holds
-    int64_t qblk_serial[kQueueBlocks] = {0, 0, 0};         // serial of the frame whose planes the block holds unpacked (0: none)
-    hipEvent_t ev_qblk[kQueueBlocks] = {nullptr, nullptr, nullptr};   // frame stream: the block's planes are complete
+    int64_t qblk_serial[kQueueBlocks] = {};         // serial of the frame whose planes the block holds unpacked (0: none)
+    hipEvent_t ev_qblk[kQueueBlocks] = {};   // frame stream: the block's planes are complete
     int qblk_next = 0;
     std::unique_ptr<tsdf_api::HostPool> pool;   // staging threads, started by the first pageable frame (TSDF_HOST_THREADS, default: usable cores - 2, at most 12)
     float* pre_z = nullptr; float* pre_zf = nullptr; void* pre_depth = nullptr; void* pin_depth = nullptr;   // pre-processing scratch
@@ -290,6 +299,10 @@ int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes);      // a 
 DevPlanes block_planes(const tsdf_handle* h, int blk);
 int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nrm, bool has_rgb, bool samples_listed, bool travelling);
 void queue_thread_main(tsdf_handle* h);
+// hands a job to the staging thread (started on first use); 0: the thread could not be started
+uint64_t submit_staging_job(tsdf_handle* h, std::function<void()> job);
+// until that job has finished (0: until the thread is idle)
+void wait_staging_job(tsdf_handle* h, uint64_t job);
 int ensure_second_staging_set(tsdf_handle* h, size_t npix);
 
 // ---- api_hotpath.cpp
