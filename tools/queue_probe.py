@@ -13,7 +13,7 @@ ap.add_argument("--ahead", type=int, default=2)
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--warmup", type=int, default=6)
 ap.add_argument("--m", type=int, default=512)
-ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device"])
+ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device", "set", "set_aos"])
 ap.add_argument("--repeat", type=int, default=3)
 a = ap.parse_args()
 n = a.frames + a.warmup + 1
@@ -24,6 +24,18 @@ host = [tuple(np.ascontiguousarray(t.cpu().numpy()) for t in f) for f in fr]
 if a.kind == "pinned":
     hold = [tuple(torch.from_numpy(x).pin_memory() for x in f) for f in host]
     host = [tuple(t.numpy() for t in f) for f in hold]
+aos = None
+if a.kind == "set_aos":
+    def clouds(xyz, nrm, rgb):
+        pts = np.zeros(xyz.shape[:2], dtype=np.dtype({"names": ["x", "y", "z", "b", "g", "r"], "formats": ["<f4"] * 3 + ["u1"] * 3,
+                                                     "offsets": [0, 4, 8, 16, 17, 18], "itemsize": 32}))
+        nn = np.zeros(xyz.shape[:2], dtype=np.dtype({"names": ["normal_x", "normal_y", "normal_z"], "formats": ["<f4"] * 3,
+                                                    "offsets": [0, 4, 8], "itemsize": 32}))
+        pts["x"], pts["y"], pts["z"] = xyz[..., 0], xyz[..., 1], xyz[..., 2]
+        pts["r"], pts["g"], pts["b"] = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+        nn["normal_x"], nn["normal_y"], nn["normal_z"] = nrm[..., 0], nrm[..., 1], nrm[..., 2]
+        return pts, nn
+    aos = [clouds(*f) for f in host]
 s = ts.SDF(a.m, with_color=True)
 t = ts.CameraTracking(sdf=s)
 t.set_K(seq.K)
@@ -36,16 +48,21 @@ for rep in range(a.repeat):
             s.queue_frame_device(fr[i][0].data_ptr(), fr[i][1].data_ptr(), fr[i][2].data_ptr(), 640, 480, keep=fr[i])
         else:
             s.queue_frame(*host[i])
-    ahead = 1 if a.kind == "device" else a.ahead
+    ahead = 1 if a.kind == "device" else 0 if a.kind.startswith("set") else a.ahead
     for j in range(ahead):
         q(j)
     t0 = None
     for k in range(n):
         if k == a.warmup + 1:
             s.synchronize(); t0 = time.perf_counter()
-        s.next_frame()
-        if k + ahead < n:
-            q(k + ahead)
+        if a.kind == "set":                       # one frame at a time, pageable planes
+            s.set_frame(*host[k])
+        elif a.kind == "set_aos":
+            s.set_frame_aos(*aos[k])
+        else:
+            s.next_frame()
+            if k + ahead < n:
+                q(k + ahead)
         if k == 0:
             s.update(want_stats=False)
         else:
