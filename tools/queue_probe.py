@@ -15,6 +15,7 @@ ap.add_argument("--warmup", type=int, default=6)
 ap.add_argument("--m", type=int, default=512)
 ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device", "set", "set_aos"])
 ap.add_argument("--repeat", type=int, default=3)
+ap.add_argument("--times", action="store_true", help="wall time inside the frame call and inside the hot call, per frame")
 a = ap.parse_args()
 n = a.frames + a.warmup + 1
 seq = synth.Sequence(n_frames=n, width=640, height=480, noise=True, holes=0.02)
@@ -52,9 +53,11 @@ for rep in range(a.repeat):
     for j in range(ahead):
         q(j)
     t0 = None
+    t_feed = t_hot = 0.0
     for k in range(n):
         if k == a.warmup + 1:
-            s.synchronize(); t0 = time.perf_counter()
+            s.synchronize(); t0 = time.perf_counter(); t_feed = t_hot = 0.0
+        ta = time.perf_counter()
         if a.kind == "set":                       # one frame at a time, pageable planes
             s.set_frame(*host[k])
         elif a.kind == "set_aos":
@@ -63,11 +66,16 @@ for rep in range(a.repeat):
             s.next_frame()
             if k + ahead < n:
                 q(k + ahead)
+        tb = time.perf_counter()
         if k == 0:
             s.update(want_stats=False)
         else:
             s._check(L.tsdf_track_and_integrate(s._h, 1, None, None))
+        tc = time.perf_counter()
+        t_feed += tb - ta; t_hot += tc - tb
     s.synchronize()
     rates.append(a.frames / (time.perf_counter() - t0))
+    if a.times:
+        print("  us per frame: frame call(s) %.1f  tsdf_track_and_integrate %.1f  whole %.1f" % (t_feed / a.frames * 1e6, t_hot / a.frames * 1e6, 1e6 / rates[-1]), flush=True)
 print("queue_probe", a.kind, "ahead", a.ahead, "threads", os.environ.get("TSDF_HOST_THREADS", "default"), "frames/s", [round(r, 1) for r in rates], flush=True)
 s.close()

@@ -211,16 +211,46 @@ int upload_samples_first(tsdf_handle* h, const void* base, size_t pixel_bytes, s
 }
 // gather + copy + ev_samples on the frame stream (pin_samples must exist: ensure_pin_samples on the caller's thread)
 int stage_samples(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width, int nb) {
+    const StageFirst f = samples_first_work(h, base, pixel_bytes, xyz_offset, width, nb, false);
+    HostPool* const pool = host_pool(h);
+    if (pool) pool->run(f.work); else f.work(0, 1);
+    HIP_TRY(h, f.issue());
+    return TSDF_OK;
+}
+// The same as part of a frame's staging job (stage_and_upload's `first`): the workers gather their shares of the sample
+// rows before they fill their shares of the planes, the caller issues the list's copy in front of the planes' -- and, with
+// `main_stream_waits`, makes the main stream wait for that copy alone (upload_samples_first's rule).
+StageFirst samples_first_work(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width, int nb, bool main_stream_waits) {
     float4* const ps = h->pin_samples[nb];
     const int32_t st = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows;
-    const std::function<void(int, int)> gather = [&](int part, int parts) {
+    StageFirst f;
+    f.work = [=](int part, int parts) {
         const int r0 = (int)((long long)nrows * part / parts), r1 = (int)((long long)nrows * (part + 1) / parts);
         gather_samples(base, pixel_bytes, xyz_offset, width, st, ncols, nrows, r0, r1, reinterpret_cast<float*>(ps));
     };
-    HostPool* const pool = host_pool(h);
-    if (pool) pool->run(gather); else gather(0, 1);
-    HIP_TRY(h, hipMemcpyAsync(h->samples_buf[nb], ps, (size_t)h->n_samples * sizeof(float4), hipMemcpyHostToDevice, h->fstream));
-    HIP_TRY(h, hipEventRecord(h->ev_samples, h->fstream));
+    f.issue = [=]() -> hipError_t {
+        hipError_t e = hipMemcpyAsync(h->samples_buf[nb], ps, (size_t)h->n_samples * sizeof(float4), hipMemcpyHostToDevice, h->fstream);
+        if (e == hipSuccess) e = hipEventRecord(h->ev_samples, h->fstream);
+        if (e == hipSuccess && main_stream_waits) e = hipStreamWaitEvent(h->stream, h->ev_samples, 0);
+        return e;
+    };
+    return f;
+}
+
+// The other set of pinned staging planes, free of the copies that last read it (those of the frame before the last one):
+// a frame handed over one at a time no longer waits for the PREVIOUS frame's copy before it may fill its planes
+// (hipStreamSynchronize(fstream) at the top of tsdf_set_frame until round 6: ~40 us of every frame).
+int next_staging_set(tsdf_handle* h, size_t npix) {
+    const int rc = ensure_second_staging_set(h, npix);
+    if (rc) return rc;
+    std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
+    std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
+    if (h->stage_recorded[0]) HIP_TRY(h, hipEventSynchronize(h->ev_stage_done[0]));
+    return TSDF_OK;
+}
+int staging_set_copies_issued(tsdf_handle* h) {
+    HIP_TRY(h, hipEventRecord(h->ev_stage_done[0], h->fstream));
+    h->stage_recorded[0] = true;
     return TSDF_OK;
 }
 
@@ -285,8 +315,12 @@ HostPool* host_pool(tsdf_handle* h) {
 // NUMBER (~15-20 us each whatever the size), so 12 copies per frame lose more than the overlap wins (PCL clouds through
 // the queue: 8 chunks 2490 frames/s, 4 chunks 3450, 2 chunks 4010, 1 chunk = 3 copies 4140).  Default now: one chunk,
 // and the three planes in one block = ONE copy per frame.  TSDF_STAGE_CHUNKS keeps the pipelined form for large images.
+// `first` (optional): work of the same pool job in front of the chunks -- every worker does its share (first->work), the
+// caller issues what they made (first->issue) before the first chunk's copy: the tracker's sample list of "samples first",
+// which until round 6 was a pool job of its own (one more wake-up of eleven sleeping threads, 20-50 us, in front of every frame).
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
-                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset, const DevPlanes* dst) {
+                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset, const DevPlanes* dst,
+                            const StageFirst* first) {
     constexpr int kMaxChunks = 16;
     float* const d_xyz = dst->xyz; float* const d_nrm = dst->nrm; uint8_t* const d_rgb = dst->rgb;
     // TSDF_STAGE_CHUNKS overrides; otherwise the caller's choice: 1 where only throughput counts (the frame queue), 2 where
@@ -296,6 +330,7 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
     const int kChunks = kEnvChunks > 0 ? kEnvChunks : (chunks_when_unset < 1 ? 1 : chunks_when_unset > kMaxChunks ? kMaxChunks : chunks_when_unset);
     std::atomic<int> done[kMaxChunks];
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    std::atomic<int> first_done{0};
     hipError_t err = hipSuccess;
     using clk = std::chrono::steady_clock;
     const bool prof = h->sp.on;
@@ -321,14 +356,20 @@ hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_
     HostPool* const pool = host_pool(h);
     const std::function<void(int, int)> job = [&](int part, int parts) {
         if (parts == 1) {                                   // no workers: fill and issue in turn (the DMA still overlaps)
+            if (first) { first->work(0, 1); err = first->issue(); }
             for (int c = 0; c < kChunks; ++c) { fill(chunk_lo(c), chunk_lo(c + 1)); upload(c); }
         } else if (part == 0) {                             // the caller: HIP calls only
+            if (first) {
+                while (first_done.load(std::memory_order_acquire) < parts - 1) std::this_thread::yield();
+                err = first->issue();
+            }
             for (int c = 0; c < kChunks; ++c) {
                 while (done[c].load(std::memory_order_acquire) < parts - 1) std::this_thread::yield();
                 upload(c);
             }
         } else {
             const size_t wk = (size_t)(part - 1), nw = (size_t)(parts - 1);
+            if (first) { first->work(part - 1, parts - 1); first_done.fetch_add(1, std::memory_order_release); }
             long long mine = 0;
             for (int c = 0; c < kChunks; ++c) {
                 const size_t c0 = chunk_lo(c), n = chunk_lo(c + 1) - c0;
@@ -426,9 +467,6 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     // at 640x480 that memcpy is 8.3 MB per frame, longer than the frame's GPU work); the copies are complete when the
     // call returns, so the buffers are borrowed for the call only, as for pageable ones.
     const bool direct = is_pinned_host(xyz, npix * 12) && (!nrm || is_pinned_host(nrm, npix * 12)) && (!rgb || is_pinned_host(rgb, npix * 3));
-    // the pinned staging buffers may still feed the previous frame's async copies (frame stream only: the
-    // integration of the previous frame keeps running on the main stream meanwhile)
-    HIP_TRY(h, hipStreamSynchronize(h->fstream));
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
     // The planes go into a block of the ring and are packed by the frame's own integrate launch (as a frame handed over in
     // device memory is; round 6: no pack_kernel on the frame stream).
@@ -437,13 +475,23 @@ int tsdf_set_frame(tsdf_handle* h, const float* xyz, const float* nrm, const uin
     rc = acquire_queue_block(h, &blk, &dst);
     if (rc) return rc;
     if (!direct) {
+        // the staging set the frame before the last one used (its copies are long done; the previous frame's may still run)
+        rc = next_staging_set(h, npix);
+        if (rc) return rc;
         const bool samples_first = samples_first_enabled();
-        if (samples_first) { rc = upload_samples_first(h, xyz, 12, 0, width); if (rc) return rc; }
+        StageFirst first;
+        if (samples_first) {
+            rc = ensure_pin_samples(h);
+            if (rc) return rc;
+            first = samples_first_work(h, xyz, 12, 0, width, h->fidx ^ 1, true);
+        }
         HIP_TRY(h, stage_and_upload(h, npix, true, nrm != nullptr, rgb != nullptr, [&](size_t i0, size_t i1) {
             std::memcpy(h->pin_xyz + 3 * i0, xyz + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (nrm) std::memcpy(h->pin_nrm + 3 * i0, nrm + 3 * i0, (i1 - i0) * 3 * sizeof(float));
             if (rgb) std::memcpy(h->pin_rgb + 3 * i0, rgb + 3 * i0, (i1 - i0) * 3);
-        }, 1, &dst));
+        }, 1, &dst, samples_first ? &first : nullptr));
+        rc = staging_set_copies_issued(h);
+        if (rc) return rc;
         return block_frame_current(h, blk, dst, nrm != nullptr, rgb != nullptr, samples_first, true);
     }
     HIP_TRY(h, hipMemcpyAsync(dst.xyz, xyz, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->fstream));
@@ -569,7 +617,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
             std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
             hipError_t e = h->stage_recorded[0] ? hipEventSynchronize(h->ev_stage_done[0]) : hipSuccess;
             if (h->sp.on) h->sp.sync_before += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ts0).count();
-            if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill, 1, &dst);
+            if (e == hipSuccess) e = stage_and_upload(h, npix, true, has_nrm, has_rgb, fill, 1, &dst, nullptr);
             if (e == hipSuccess) { e = hipEventRecord(h->ev_stage_done[0], h->fstream); h->stage_recorded[0] = e == hipSuccess; }
             if (e == hipSuccess) e = hipEventRecord(h->ev_qblk[blk], h->fstream);
             slot->err = e;
@@ -713,9 +761,12 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
     rc = ensure_frame_buffers(h, width, height, true);
     if (rc) return rc;
     const size_t npix = (size_t)width * height;
-    HIP_TRY(h, hipStreamSynchronize(h->fstream));          // the pinned staging buffers may still feed the previous frame
     const bool had_rgb = h->frame_has_rgb;
     h->staged_xyz = false;                                 // until this frame's planes are complete on the device
+    // a whole new frame takes the other set of pinned planes (next_staging_set); normals alone go into the set their points
+    // went through, once nothing copies out of it any more
+    if (points) { rc = next_staging_set(h, npix); if (rc) return rc; }
+    else HIP_TRY(h, hipStreamSynchronize(h->fstream));
     float* const px = h->pin_xyz; float* const pnm = h->pin_nrm; uint8_t* const pc = h->pin_rgb;
     const tsdf_aos_layout lay = *L;
     // a new cloud: its tracker samples go up first (the passes of a following tsdf_track run under the planes' copy)
@@ -726,10 +777,17 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
         DevPlanes dst;
         rc = acquire_queue_block(h, &blk, &dst);
         if (rc) return rc;
-        if (samples_first) { rc = upload_samples_first(h, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset, width); if (rc) return rc; }
+        StageFirst first;
+        if (samples_first) {
+            rc = ensure_pin_samples(h);
+            if (rc) return rc;
+            first = samples_first_work(h, points, (size_t)lay.point_stride, (size_t)lay.xyz_offset, width, h->fidx ^ 1, true);
+        }
         HIP_TRY(h, stage_and_upload(h, npix, true, normals != nullptr, color, [&](size_t i0, size_t i1) {
             repack_aos(lay, points, normals, color, px, pnm, pc, i0, i1);
-        }, 1, &dst));
+        }, 1, &dst, samples_first ? &first : nullptr));
+        rc = staging_set_copies_issued(h);
+        if (rc) return rc;
         return block_frame_current(h, blk, dst, normals != nullptr, color, samples_first, true);
     }
     if (h->staged_blk >= 0) {
@@ -742,7 +800,7 @@ int tsdf_set_frame_aos(tsdf_handle* h, const void* points, const void* normals, 
         dst.rgb = reinterpret_cast<uint8_t*>(h->qblk[blk] + 2 * plane);
         HIP_TRY(h, stage_and_upload(h, npix, false, true, false, [&](size_t i0, size_t i1) {
             repack_aos(lay, nullptr, normals, false, nullptr, pnm, nullptr, i0, i1);
-        }, 1, &dst));
+        }, 1, &dst, nullptr));
         HIP_TRY(h, hipEventRecord(h->ev_frame, h->fstream));
         if (!h->deferred.pending) {
             borrow_device_frame(h, h->frame_serial, true);

@@ -293,8 +293,18 @@ bool samples_first_enabled();
 int defer_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* rgb, bool already_borrowed = false,
                bool own_block = false /* the planes are a block of the library's own ring */);
 HostPool* host_pool(tsdf_handle* h);        // the staging threads, started by the first pageable frame
+// work of a frame's staging job in front of its chunks: every pool thread does its share, the caller issues what they made
+struct StageFirst {
+    std::function<void(int, int)> work;      // (part, parts)
+    std::function<hipError_t()> issue;
+};
 hipError_t stage_and_upload(tsdf_handle* h, size_t npix, bool has_xyz, bool has_nrm, bool has_rgb,
-                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset, const struct DevPlanes* dst);
+                            const std::function<void(size_t, size_t)>& fill, int chunks_when_unset, const struct DevPlanes* dst,
+                            const StageFirst* first = nullptr);
+StageFirst samples_first_work(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width, int nb, bool main_stream_waits);
+int next_staging_set(tsdf_handle* h, size_t npix);
+int staging_set_copies_issued(tsdf_handle* h);
+int ensure_second_staging_set(tsdf_handle* h, size_t npix);
 int acquire_queue_block(tsdf_handle* h, int* blk, DevPlanes* planes);      // a free block of the ring of device blocks
 DevPlanes block_planes(const tsdf_handle* h, int blk);
 int block_frame_current(tsdf_handle* h, int blk, const DevPlanes& p, bool has_nrm, bool has_rgb, bool samples_listed, bool travelling);
@@ -303,7 +313,6 @@ void queue_thread_main(tsdf_handle* h);
 uint64_t submit_staging_job(tsdf_handle* h, std::function<void()> job);
 // until that job has finished (0: until the thread is idle)
 void wait_staging_job(tsdf_handle* h, uint64_t job);
-int ensure_second_staging_set(tsdf_handle* h, size_t npix);
 
 // ---- api_hotpath.cpp
 int accumulate_pass(tsdf_handle* h, bool reduce_ranks, bool later_pass = false /* pass >= 1 of a tsdf_track call */);
