@@ -13,7 +13,7 @@ ap.add_argument("--ahead", type=int, default=2)
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--warmup", type=int, default=6)
 ap.add_argument("--m", type=int, default=512)
-ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device", "set", "set_aos"])
+ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device", "set", "set_aos", "ref"])
 ap.add_argument("--repeat", type=int, default=3)
 ap.add_argument("--times", action="store_true", help="wall time inside the frame call and inside the hot call, per frame")
 a = ap.parse_args()
@@ -26,7 +26,7 @@ if a.kind == "pinned":
     hold = [tuple(torch.from_numpy(x).pin_memory() for x in f) for f in host]
     host = [tuple(t.numpy() for t in f) for f in hold]
 aos = None
-if a.kind == "set_aos":
+if a.kind in ("set_aos", "ref"):
     def clouds(xyz, nrm, rgb):
         pts = np.zeros(xyz.shape[:2], dtype=np.dtype({"names": ["x", "y", "z", "b", "g", "r"], "formats": ["<f4"] * 3 + ["u1"] * 3,
                                                      "offsets": [0, 4, 8, 16, 17, 18], "itemsize": 32}))
@@ -49,7 +49,7 @@ for rep in range(a.repeat):
             s.queue_frame_device(fr[i][0].data_ptr(), fr[i][1].data_ptr(), fr[i][2].data_ptr(), 640, 480, keep=fr[i])
         else:
             s.queue_frame(*host[i])
-    ahead = 1 if a.kind == "device" else 0 if a.kind.startswith("set") else a.ahead
+    ahead = 1 if a.kind == "device" else 0 if a.kind.startswith("set") or a.kind == "ref" else a.ahead
     for j in range(ahead):
         q(j)
     t0 = None
@@ -58,7 +58,9 @@ for rep in range(a.repeat):
         if k == a.warmup + 1:
             s.synchronize(); t0 = time.perf_counter(); t_feed = t_hot = 0.0
         ta = time.perf_counter()
-        if a.kind == "set":                       # one frame at a time, pageable planes
+        if a.kind == "ref":                       # the reference's two calls (estimate_new_position, update), synchronously
+            pass
+        elif a.kind == "set":                     # one frame at a time, pageable planes
             s.set_frame(*host[k])
         elif a.kind == "set_aos":
             s.set_frame_aos(*aos[k])
@@ -67,7 +69,12 @@ for rep in range(a.repeat):
             if k + ahead < n:
                 q(k + ahead)
         tb = time.perf_counter()
-        if k == 0:
+        if a.kind == "ref":
+            if k > 0:
+                s.track_aos(aos[k][0], None)
+            tb = time.perf_counter()
+            s.update_aos(aos[k][0], aos[k][1])
+        elif k == 0:
             s.update(want_stats=False)
         else:
             s._check(L.tsdf_track_and_integrate(s._h, 1, None, None))
