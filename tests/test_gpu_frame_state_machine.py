@@ -2,7 +2,7 @@
 
 Every way a frame can reach the library -- host planes set one by one, PCL-style clouds, device planes (packed
 inside their integrate launch, samples read from the plane by the first tracker pass), and the same three through the
-two-deep queue (queued before or after the current frame's hot calls, page-locked or pageable) -- mixed at random from
+frame queue (queued before or after the current frame's hot calls, page-locked or pageable, one or two frames ahead) -- mixed at random from
 frame to frame, with frames that are only tracked, only integrated or neither, extra accumulation passes and
 tsdf_synchronize calls thrown in.  Whatever the route, poses, normal equations and the volume must equal the plain
 host-plane loop bit for bit: the routes differ in WHEN records and sample lists are written, never in what they hold."""
@@ -33,6 +33,7 @@ def plan(seed):
     for k in range(N):
         out.append({"kind": kinds[rng.integers(len(kinds))] if k > 0 else kinds[rng.integers(3)],
                     "queue_early": bool(rng.integers(2)),          # queued before (True) or after the previous frame's hot calls
+                    "two_ahead": bool(rng.integers(2)),            # ... and the frame after it as well, if that one comes from host memory through the queue
                     "track": k > 0 and rng.random() < 0.85, "integrate": k == 0 or rng.random() < 0.8,
                     "accumulate": rng.random() < 0.4, "sync": rng.random() < 0.25})
     return out
@@ -89,10 +90,20 @@ def mixed(seq, steps):
             s.queue_frame_device(dev[k][0].data_ptr(), dev[k][1].data_ptr(), dev[k][2].data_ptr(), W, H, keep=dev[k])
 
     log = []
+    queued = set()
+
+    def queue_ahead(k):
+        """frame k+1 into the queue, and frame k+2 behind it when the plan says so and the library takes it there (a host
+        frame; a frame in device memory waits in the first place only)"""
+        if k + 1 not in queued:
+            queue(k + 1); queued.add(k + 1)
+        if (steps[k + 1]["two_ahead"] and k + 2 < N and steps[k + 2]["kind"] in ("q_host", "q_pinned", "q_aos") and k + 2 not in queued):
+            queue(k + 2); queued.add(k + 2)
+
     for k, st in enumerate(steps):
         kind = st["kind"]
         if kind.startswith("q_"):
-            s.next_frame()                                   # queued during frame k-1
+            s.next_frame()                                   # queued during frame k-1 (or k-2)
         elif kind == "set_host":
             s.set_frame(*host[k])
         elif kind == "set_aos":
@@ -101,7 +112,7 @@ def mixed(seq, steps):
             s.set_frame_device(dev[k][0].data_ptr(), dev[k][1].data_ptr(), dev[k][2].data_ptr(), W, H, keep=dev[k])
         nxt = steps[k + 1] if k + 1 < N else None
         if nxt and nxt["kind"].startswith("q_") and nxt["queue_early"]:
-            queue(k + 1)
+            queue_ahead(k)
         if st["track"]:
             track(ts, t, log)
         if st["sync"]:
@@ -111,7 +122,7 @@ def mixed(seq, steps):
         if st["integrate"]:
             s.update()
         if nxt and nxt["kind"].startswith("q_") and not nxt["queue_early"]:
-            queue(k + 1)
+            queue_ahead(k)
         log.append((t.rot.copy(), t.trans.copy()))
     out = (log, s.download(), s.download_color())
     s.close()

@@ -452,6 +452,10 @@ int tsdf_synchronize(tsdf_handle* h) {
     // Device frames whose packing is still deferred: tsdf_synchronize ends the library's claim on borrowed device
     // planes (tsdf.h), so what has not been packed yet is packed now, by a launch of its own
     if (h->deferred.pending) {
+        if (h->records_pending) {             // a samples-first host frame: its planes may still be travelling on the frame stream
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_frame, 0));
+            h->records_pending = false;
+        }
         PackArgs own = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
         if (h->deferred.samples_listed) own.samples = nullptr;
         HIP_TRY(h, launch_pack(h->stream, own));
