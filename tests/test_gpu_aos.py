@@ -366,6 +366,56 @@ def test_synchronize_between_a_host_frame_and_its_update_waits_for_the_planes(ro
             assert np.array_equal(a_, b_)
 
 
+def test_a_sample_list_sent_ahead_is_not_overwritten_by_an_earlier_frames_packing():
+    """A host frame's sample list travels on the frame stream ("samples first") into the list buffer that the frame two
+    before it used.  When the host is several untracked frames ahead of the GPU -- here twelve frames in device memory
+    integrated at given poses through the queue, 100 us of GPU work each, handed over in 20 us each -- the launch that
+    packs that earlier frame (and writes ITS list into the same buffer) may not have run yet when the copy is issued: the
+    copy must be ordered behind it, or the tracker reads the older frame's samples.  Pose and volume equal the same
+    sequence with a tsdf_synchronize after every frame, bit for bit."""
+    import torch
+    import tracking_sdf_amd as ts
+    w, h, m, n = 640, 480, 512, 14
+    seq = synth.Sequence(n_frames=n, width=w, height=h, noise=True, holes=0.02, step=2)
+    dev = [seq.frame_torch(k, "cuda") for k in range(n - 1)]
+    first = tuple(np.ascontiguousarray(a) for a in seq.frame(0))
+    last = tuple(np.ascontiguousarray(a) for a in seq.frame(n - 1))
+    torch.cuda.synchronize()
+
+    def run(sync_every_frame):
+        s = ts.SDF(m, with_color=False)
+        t = ts.CameraTracking(sdf=s)
+        t.set_K(seq.K)
+        q = lambda k: s.queue_frame_device(dev[k][0].data_ptr(), dev[k][1].data_ptr(), 0, w, h, keep=dev[k])
+        # (a host frame first: staging planes, device blocks and sample buffers exist from here on -- allocating them later
+        # would synchronise the streams and hide what this test is about)
+        t.set_camera_transformation(seq.R[0], seq.t[0])
+        s.set_frame(first[0], first[1], None)
+        s.update(want_stats=False)
+        s.synchronize()
+        q(1)
+        for k in range(1, n - 1):
+            s.next_frame()
+            if k + 1 < n - 1:
+                q(k + 1)                                  # packed, sample list included, by frame k's integrate launch
+            t.set_camera_transformation(seq.R[k], seq.t[k])
+            s.update(want_stats=False)
+            if sync_every_frame:
+                s.synchronize()
+        s.set_frame(last[0], last[1], None)               # pageable planes: the sample list goes ahead
+        st = t.estimate_new_position()
+        pose = (t.rot.copy(), t.trans.copy(), st["iterations"])
+        s.update(want_stats=False)
+        D, Wt = s.download()
+        s.close()
+        return pose, D, Wt
+    want = run(True)
+    for _ in range(3):
+        got = run(False)
+        assert got[0][2] == want[0][2] and np.array_equal(got[0][0], want[0][0]) and np.array_equal(got[0][1], want[0][1])
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
 def test_a_queued_frame_of_another_size_is_refused_whatever_waits():
     import tracking_sdf_amd as ts
     seq = synth.Sequence(n_frames=2, width=W, height=H, noise=False, step=4)

@@ -198,6 +198,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_samples, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[1], hipEventDisableTiming));
     h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
@@ -316,6 +317,7 @@ void tsdf_destroy(tsdf_handle* h) {
     }
     if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
+    if (h->ev_order) (void)hipEventDestroy(h->ev_order);
     if (h->ev_samples) (void)hipEventDestroy(h->ev_samples);
     for (int b = 0; b < tsdf_handle::kQueueBlocks; ++b) if (h->ev_qblk[b]) (void)hipEventDestroy(h->ev_qblk[b]);
     for (int b = 0; b < 2; ++b) if (h->ev_stage_done[b]) (void)hipEventDestroy(h->ev_stage_done[b]);
@@ -473,6 +475,7 @@ int tsdf_synchronize(tsdf_handle* h) {
         h->aql_on = false;
         return fail(h, TSDF_E_HIP, "tsdf_synchronize: the library's own queue did not become idle (queue disabled; borrowed frames stay borrowed)");
     }
+    h->samples_written_ticket[0] = h->samples_written_ticket[1] = 0ull;      // ... or writes a sample list
     h->borrowed.clear();                     // nothing launched so far reads a borrowed plane any more
     h->borrow_lost = -1;
     return TSDF_OK;

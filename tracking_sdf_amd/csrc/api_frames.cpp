@@ -168,7 +168,9 @@ int run_pack(tsdf_handle* h, const float* xyz, const float* nrm, const uint8_t* 
     if (rc) return rc;
     HIP_TRY(h, launch_pack(h->stream, pack_args(h, xyz, nrm, rgb, h->pix_su, h->pix_sv, nb)));
     if (!registered) borrow_device_frame(h, h->frame_serial + 1);
-    HIP_TRY(h, launch_release(h->stream, release_for(h, h->frame_serial + 1, 0)));
+    const ReleaseWord packed = release_for(h, h->frame_serial + 1, 0);
+    HIP_TRY(h, launch_release(h->stream, packed));
+    h->samples_written_ticket[nb] = packed.ticket;
     rc = timed_end(h, ep, h->stream);
     if (rc) return rc;
     h->records_pending = false;
@@ -221,7 +223,7 @@ int stage_samples(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t x
 // rows before they fill their shares of the planes, the caller issues the list's copy in front of the planes' -- and, with
 // `main_stream_waits`, makes the main stream wait for that copy alone (upload_samples_first's rule).
 StageFirst samples_first_work(tsdf_handle* h, const void* base, size_t pixel_bytes, size_t xyz_offset, int32_t width, int nb, bool main_stream_waits) {
-    float4* const ps = h->pin_samples[nb];
+    float4* const ps = h->pin_samples[0];       // the list buffer of the staging set in use (they swap together: next_staging_set)
     const int32_t st = h->cfg.pixel_stride, ncols = h->ncols, nrows = h->nrows;
     StageFirst f;
     f.work = [=](int part, int parts) {
@@ -229,7 +231,15 @@ StageFirst samples_first_work(tsdf_handle* h, const void* base, size_t pixel_byt
         gather_samples(base, pixel_bytes, xyz_offset, width, st, ncols, nrows, r0, r1, reinterpret_cast<float*>(ps));
     };
     f.issue = [=]() -> hipError_t {
-        hipError_t e = hipMemcpyAsync(h->samples_buf[nb], ps, (size_t)h->n_samples * sizeof(float4), hipMemcpyHostToDevice, h->fstream);
+        hipError_t e = hipSuccess;
+        // (see samples_written_ticket: an earlier launch on the main stream may still have this buffer's list to write)
+        const unsigned long long need = h->samples_written_ticket[nb];
+        if (need && __atomic_load_n(h->release_host + 0, __ATOMIC_ACQUIRE) < need) {
+            e = hipEventRecord(h->ev_order, h->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->fstream, h->ev_order, 0);
+        }
+        h->samples_written_ticket[nb] = 0ull;
+        if (e == hipSuccess) e = hipMemcpyAsync(h->samples_buf[nb], ps, (size_t)h->n_samples * sizeof(float4), hipMemcpyHostToDevice, h->fstream);
         if (e == hipSuccess) e = hipEventRecord(h->ev_samples, h->fstream);
         if (e == hipSuccess && main_stream_waits) e = hipStreamWaitEvent(h->stream, h->ev_samples, 0);
         return e;
@@ -243,7 +253,7 @@ StageFirst samples_first_work(tsdf_handle* h, const void* base, size_t pixel_byt
 int next_staging_set(tsdf_handle* h, size_t npix) {
     const int rc = ensure_second_staging_set(h, npix);
     if (rc) return rc;
-    std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
+    std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb); std::swap(h->pin_samples[0], h->pin_samples[1]);
     std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
     if (h->stage_recorded[0]) HIP_TRY(h, hipEventSynchronize(h->ev_stage_done[0]));
     return TSDF_OK;
@@ -613,7 +623,7 @@ int queue_frame_common(tsdf_handle* h, const float* xyz, const float* nrm, const
             const auto ts0 = std::chrono::steady_clock::now();
             if (h->sp.on) h->sp.handoff += std::chrono::duration<double, std::nano>(ts0 - t_queued).count();
             // switch to the other staging set (fill and stage_and_upload read h->pin_* when they run)
-            std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
+            std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb); std::swap(h->pin_samples[0], h->pin_samples[1]);
             std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
             hipError_t e = h->stage_recorded[0] ? hipEventSynchronize(h->ev_stage_done[0]) : hipSuccess;
             if (h->sp.on) h->sp.sync_before += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ts0).count();

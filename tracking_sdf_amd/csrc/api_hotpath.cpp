@@ -249,7 +249,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
     // A queued device frame goes first -- that is the packing of the NEXT frame, sample list included, hidden under this
     // frame's list kernel; the current frame's own records then need a launch in front (the first frame of a stream only).
     PackArgs pa;
-    bool fused = false, fused_queued = false;
+    bool fused = false, fused_queued = false, wrote_own_list = false;
     ReleaseWord rel;                         // tells the host when the borrowed planes packed by this launch have been read
     tsdf_handle::Queued& q = h->queued_front();       // (a frame in device memory waits at the front of the queue only)
     if (h->qcount > 0 && q.active && q.device && q.deferred && !q.packed) {
@@ -257,6 +257,7 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
         if (own_too) {
             PackArgs own = pack_args(h, h->deferred.xyz, h->deferred.nrm, h->deferred.rgb, h->pix_su, h->pix_sv, h->fidx);
             if (h->deferred.samples_listed) own.samples = nullptr;
+            wrote_own_list = own.samples != nullptr;
             HIP_TRY(h, launch_pack(h->stream, own));
             h->deferred.pending = false;
         }
@@ -299,6 +300,10 @@ int tsdf_integrate(tsdf_handle* h, tsdf_integrate_stats* stats) {
         }
     }
     h->integrate_launches++;
+    if (fused) {                             // sample lists this launch (or the pack launch in front of it) writes: see samples_written_ticket
+        if (fused_queued) { h->samples_written_ticket[h->fidx ^ 1] = rel.ticket; if (wrote_own_list) h->samples_written_ticket[h->fidx] = rel.ticket; }
+        else if (pa.samples) h->samples_written_ticket[h->fidx] = rel.ticket;
+    }
     if (fused_queued) q.packed = true;       // only now: a failed launch must not leave an unpacked record buffer marked as packed
     h->deferred.pending = false;             // records and sample list of the current frame are complete from here on
     rc = timed_end(h, ep, h->stream);
@@ -461,7 +466,7 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
     rc = ensure_pin_samples(h);
     if (rc) return rc;
     // the other set of pinned planes: the copies out of it were those of the frame before the last one
-    std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb);
+    std::swap(h->pin_xyz, h->alt_xyz); std::swap(h->pin_nrm, h->alt_nrm); std::swap(h->pin_rgb, h->alt_rgb); std::swap(h->pin_samples[0], h->pin_samples[1]);
     std::swap(h->ev_stage_done[0], h->ev_stage_done[1]); std::swap(h->stage_recorded[0], h->stage_recorded[1]);
     if (h->stage_recorded[0]) HIP_TRY(h, hipEventSynchronize(h->ev_stage_done[0]));
     lap(tp, h->sp.a_prep2);

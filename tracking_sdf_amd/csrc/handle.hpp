@@ -97,7 +97,8 @@ struct tsdf_handle {
     float* alt_xyz = nullptr; float* alt_nrm = nullptr; uint8_t* alt_rgb = nullptr; size_t alt_cap = 0;
     // tsdf_track_aos / tsdf_integrate_aos (the reference's two calls on its own clouds): the tracker's samples go up first,
     // through their own pinned list; the cloud estimate_new_position was called with, for SDF::update's "same cloud?" check
-    float4* pin_samples[2] = {nullptr, nullptr}; size_t pin_samples_cap = 0;
+    float4* pin_samples[2] = {nullptr, nullptr}; size_t pin_samples_cap = 0;   // [0]: of the staging set in use, [1]: of the other (swapped with them:
+                                                                               // a set's ev_stage_done then covers the list's copy as well)
     struct TrackedCloud {
         bool valid = false, color = false;
         const void* points = nullptr; int32_t w = 0, h = 0; int64_t serial = -1;
@@ -140,6 +141,14 @@ struct tsdf_handle {
     bool records_pending = false;              // the frame's planes are still being produced on the frame stream (ev_frame): the tracker
                                                // may run (it reads the sample list, sent ahead), tsdf_integrate waits for them
     hipEvent_t ev_copied = nullptr;            // the H2D copies of a frame handed over in page-locked caller buffers
+    // A sample list that travels on the frame stream ("samples first") lands in samples_buf[nb] unordered against the main
+    // stream, where the launch that packed an EARLIER frame into the same buffer (two frames ago: deferred / fused packing
+    // writes the list too) may not have run yet when the host is several untracked frames ahead of the GPU -- it would
+    // then overwrite the newer list.  samples_written_ticket[nb]: main-stream release ticket of the last such launch
+    // (0: none outstanding); the copy is issued at once when the ticket has appeared in release_host[0] (always, in a
+    // tracked stream), else behind ev_order recorded on the main stream.
+    unsigned long long samples_written_ticket[2] = {0ull, 0ull};
+    hipEvent_t ev_order = nullptr;
     // the current frame's records (pn) and sample list are still to be written: tsdf_set_frame_device leaves the
     // packing to the integrate launch, and the tracker reads the samples from the xyz plane meanwhile (defer_pack)
     struct DeferredPack {
