@@ -416,6 +416,55 @@ def test_a_sample_list_sent_ahead_is_not_overwritten_by_an_earlier_frames_packin
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
 
 
+def test_the_whole_path_gives_the_same_trajectory_through_the_host_queue():
+    """All 1246 poses of the synthetic fr1/plant path at 640x480, 256^3 with colour: frames handed over in device memory
+    one at a time against the same frames copied to pageable host memory and handed over through the queue, two frames
+    waiting (three host buffers in rotation, as a reader thread would hold them).  1245 tracked poses and the final volume
+    equal bit for bit -- the routes differ in when records and sample lists are written, over a long run with every
+    buffer of every ring reused hundreds of times."""
+    import torch
+    import tracking_sdf_amd as ts
+    seq = synth.Sequence(n_frames=None, width=640, height=480, noise=True, holes=0.02)      # the whole trajectory file
+    n = len(seq)
+    assert n > 1200
+    lib = ts.lib()
+
+    def run(route):
+        import ctypes as C
+        s = ts.SDF(256, with_color=True)
+        t = ts.CameraTracking(sdf=s)
+        t.set_K(seq.K)
+        poses = np.zeros((n, 12))
+        ring = [None] * 4                                   # host copies of the frames in flight (current + two waiting + one being made)
+
+        def to_host(k):
+            f = seq.frame_torch(k, "cuda")
+            ring[k % 4] = tuple(np.ascontiguousarray(x.cpu().numpy()) for x in f)
+            return ring[k % 4]
+        if route == "queue":
+            s.queue_frame(*to_host(0))
+            s.queue_frame(*to_host(1))
+        for k in range(n):
+            if route == "device":
+                f = seq.frame_torch(k, "cuda")
+                torch.cuda.synchronize()                   # rendered on torch's stream; the library reads it on its own
+                s.set_frame_device(f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(), 640, 480, keep=f)
+            else:
+                s.next_frame()
+                if k + 2 < n:
+                    s.queue_frame(*to_host(k + 2))
+            s._check(lib.tsdf_track_and_integrate(s._h, 1 if k else 0, None, None))
+            poses[k, :9], poses[k, 9:] = t.rot.ravel(), t.trans
+        out = (poses, s.download(), s.download_color())
+        s.close()
+        return out
+    want, got = run("device"), run("queue")
+    assert np.array_equal(want[0], got[0])
+    assert np.linalg.norm(want[0][-1, 9:] - seq.t[n - 1]) < 0.15          # and it is the path, not a stand-still
+    for a_, b_ in zip(want[1] + tuple(want[2]), got[1] + tuple(got[2])):
+        assert np.array_equal(a_, b_)
+
+
 def test_a_queued_frame_of_another_size_is_refused_whatever_waits():
     import tracking_sdf_amd as ts
     seq = synth.Sequence(n_frames=2, width=W, height=H, noise=False, step=4)
