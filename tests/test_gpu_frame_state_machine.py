@@ -129,8 +129,7 @@ def mixed(seq, steps):
     return out
 
 
-@pytest.mark.parametrize("seed,defer", [(1, None), (2, None), (3, None), (4, None), (5, None), (6, None), (7, None), (8, None),
-                                        (1, "0"), (2, "0"), (3, "2"), (4, "2")])
+@pytest.mark.parametrize("seed,defer", [(k, None) for k in range(1, 17)] + [(1, "0"), (2, "0"), (3, "2"), (4, "2")])
 def test_every_route_of_a_frame_gives_the_same_bits(seed, defer, monkeypatch):
     if defer is None:
         monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
