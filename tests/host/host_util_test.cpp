@@ -38,10 +38,6 @@ static int case_pool() {
             pool.run(fn);
             for (int i = 0; i < n; ++i) { CHECK(hit[(size_t)i] == 1); expect += i; }
             if (job % 500 == 0) usleep(2000);          // let the workers fall asleep: the next run() must wake them
-            // expect(): sleepers get up and look for a job that may (the next run) or may not (they sleep again) come
-            if (job % 250 == 100) { usleep(1500); pool.expect(300000); }
-            if (job % 250 == 200) { usleep(1500); pool.expect(200000); usleep(600); }
-            if (job % 7 == 3) pool.expect(20000);
         }
         long long got = 0;
         for (long long a : acc) got += a;

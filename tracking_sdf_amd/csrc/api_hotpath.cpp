@@ -370,9 +370,6 @@ int track_loop(tsdf_handle* h, tsdf_track_stats* stats) {
     for (g = 0; g < h->cfg.gn_max_iter && !stop; ++g) {            // camera_tracking.cpp:79
         const auto tq0 = h->track_profile ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         const double waited = h->tp_wait, before = h->tp_fill + h->tp_launch;
-        // tsdf_track_aos without the normals: tsdf_integrate_aos follows, and its first job (the normals' repack) is on the
-        // frame's critical path -- from the third pass on (any of them may be the last) the staging threads are told to be up
-        if (h->prewake_pool && g >= 2 && h->pool) h->pool->expect(40000);
         rc = accumulate_pass(h, true, g > 0);
         if (rc) { h->pose = entry; return rc; }
         n_terms = (int64_t)h->red_host[27];
@@ -509,10 +506,7 @@ int track_aos_impl(tsdf_handle* h, const void* points, const void* normals, cons
     if (!job) return fail(h, TSDF_E_NOMEM, "tsdf_track_aos: cannot start the staging thread");
     lap(tp, h->sp.a_issue);
     // 3. estimate_new_position on the list
-    h->prewake_pool = normals == nullptr;
     const int rc_track = track_loop(h, stats);
-    if (h->prewake_pool && h->pool) h->pool->expect(60000);        // ... until the caller is back with the normals
-    h->prewake_pool = false;
     lap(tp, h->sp.a_loop);
     // 4. the cloud is the caller's again when this call returns
     wait_staging_job(h, job);

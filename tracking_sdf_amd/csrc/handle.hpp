@@ -82,7 +82,6 @@ struct tsdf_handle {
     uint64_t qissued = 0, qdone = 0;       // jobs handed to the thread / finished (under qmu)
     bool qstop = false;
     hipError_t stage_err = hipSuccess;     // tsdf_track_aos: what its staging job's HIP calls returned
-    bool prewake_pool = false;             // ... and: its Gauss-Newton loop tells the staging threads that a job is about to come
     void* worklist = nullptr;      // integrate work items (32-byte descriptors: row << 6 | chunk, the row's share of rot_inv * g)
     unsigned* work_count = nullptr;   // work-list bookkeeping (two alternating sets: item count, band histogram, cursors)
     int integrate_blocks = 0;      // persistent grid of integrate_kernel: the most workgroups a launch uses (CUs x workgroups per CU)

@@ -45,17 +45,6 @@ public:
         for (auto& t : threads_) t.join();
     }
     int parts() const { return (int)threads_.size() + 1; }
-    // A job is about to come (within `ns`): sleeping workers get up now and look for it that long, so that it finds them
-    // awake -- waking eleven sleeping threads costs the job 20-50 us, and one job of every frame of the synchronous
-    // two-call sequence (the normals' repack in tsdf_integrate_aos) has nothing to hide behind.
-    void expect(long long ns) {
-        if (threads_.empty()) return;
-        expect_until_.store(now_ns() + ns, std::memory_order_release);
-        if (sleepers_.load(std::memory_order_acquire) > 0) {
-            { std::lock_guard<std::mutex> g(mu_); }          // (a worker about to sleep has either seen the deadline or is waiting by now)
-            cv_.notify_all();
-        }
-    }
     void run(const std::function<void(int, int)>& fn) {
         if (threads_.empty()) { fn(0, 1); return; }
         fn_ = &fn;
@@ -80,9 +69,6 @@ public:
     }
 
 private:
-    static long long now_ns() {
-        return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    }
     static void cpu_relax() {
 #if defined(__SSE2__)
         _mm_pause();
@@ -95,6 +81,8 @@ private:
     // could keep looking for the next job for spin_ns_ after the last one before it sleeps.  It is 0: on the GPU boxes
     // (16-CPU quota, other tenants) 150 us of spinning changed nothing (medians 2186 against 2165 frames/s through the
     // reference's two calls, 8 alternations, profiles/r05_entry_points.json) and eleven spinning workers eat most of such a quota.
+    // Round 6 tried the other end -- the hot calls telling sleeping workers to get up ahead of the job that follows
+    // (profiles/r06_prewake.json): not significant for the two calls, slower for frames set one at a time.  Not kept.
     void loop(int part) {
         unsigned long long seen = 0;
         for (;;) {
@@ -103,18 +91,15 @@ private:
             for (unsigned spins = 0;; ++spins) {
                 if (stop_.load(std::memory_order_acquire)) return;
                 if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; }
-                if ((spins & 63u) == 63u && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns_ &&
-                    now_ns() >= expect_until_.load(std::memory_order_acquire)) break;
+                if ((spins & 63u) == 63u && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns_) break;
                 cpu_relax();
             }
             if (!got) {
                 std::unique_lock<std::mutex> g(mu_);
                 sleepers_.fetch_add(1, std::memory_order_release);
-                cv_.wait(g, [&] { return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen ||
-                                         now_ns() < expect_until_.load(std::memory_order_acquire); });
+                cv_.wait(g, [&] { return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; });
                 sleepers_.fetch_sub(1, std::memory_order_release);
                 if (stop_.load(std::memory_order_acquire)) return;
-                if (gen_.load(std::memory_order_acquire) == seen) continue;      // woken by expect(): look for the job, then sleep again
             }
             seen = gen_.load(std::memory_order_acquire);
             const std::function<void(int, int)>* fn = fn_;
@@ -129,7 +114,6 @@ private:
     std::atomic<unsigned long long> gen_{0};
     std::atomic<int> pending_{0}, sleepers_{0};
     std::atomic<bool> stop_{false};
-    std::atomic<long long> expect_until_{0};
     long long spin_ns_ = 0;
 };
 
