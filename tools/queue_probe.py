@@ -13,7 +13,7 @@ ap.add_argument("--ahead", type=int, default=2)
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--warmup", type=int, default=6)
 ap.add_argument("--m", type=int, default=512)
-ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device", "set", "set_aos", "ref"])
+ap.add_argument("--kind", default="pageable", choices=["pageable", "pinned", "device", "device_set", "set", "set_aos", "ref"])
 ap.add_argument("--repeat", type=int, default=3)
 ap.add_argument("--times", action="store_true", help="wall time inside the frame call and inside the hot call, per frame")
 a = ap.parse_args()
@@ -49,7 +49,7 @@ for rep in range(a.repeat):
             s.queue_frame_device(fr[i][0].data_ptr(), fr[i][1].data_ptr(), fr[i][2].data_ptr(), 640, 480, keep=fr[i])
         else:
             s.queue_frame(*host[i])
-    ahead = 1 if a.kind == "device" else 0 if a.kind.startswith("set") or a.kind == "ref" else a.ahead
+    ahead = 1 if a.kind == "device" else 0 if a.kind.startswith("set") or a.kind in ("ref", "device_set") else a.ahead
     for j in range(ahead):
         q(j)
     t0 = None
@@ -60,6 +60,8 @@ for rep in range(a.repeat):
         ta = time.perf_counter()
         if a.kind == "ref":                       # the reference's two calls (estimate_new_position, update), synchronously
             pass
+        elif a.kind == "device_set":              # frames resident in HBM, one at a time
+            s.set_frame_device(fr[k][0].data_ptr(), fr[k][1].data_ptr(), fr[k][2].data_ptr(), 640, 480, keep=fr[k])
         elif a.kind == "set":                     # one frame at a time, pageable planes
             s.set_frame(*host[k])
         elif a.kind == "set_aos":
