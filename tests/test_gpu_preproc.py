@@ -194,6 +194,43 @@ def test_queued_depth_frames_give_the_same_trajectory_and_volume(pinned):
     s.close()
 
 
+def test_a_bad_frame_behind_a_good_one_in_the_queue_is_reported_by_its_own_next_frame():
+    """Two depth frames waiting, the second one with a depth range that is no usable bilateral grid: the first
+    tsdf_next_frame succeeds, the second reports the second frame's error (and its message), the current frame stays, and the
+    queue goes on working."""
+    import tracking_sdf_amd as ts
+    w, h = 160, 120
+    seq = synth.Sequence(n_frames=3, width=w, height=h, noise=True, holes=0.02, step=3)
+    params = dict(sigma_s=3.0, sigma_r=0.05, normal_radius=3)
+    z16 = []
+    for k in range(3):
+        xyz = seq.frame(k)[0]
+        z16.append(np.clip(np.where(np.isnan(xyz[..., 2]), 0.0, xyz[..., 2]) * 5000.0, 0, 65535).astype(np.uint16))
+    bad = np.linspace(1.0, 5.0, h * w, dtype=np.float32).reshape(h, w)
+    s = ts.SDF(32)
+    t = ts.CameraTracking(sdf=s)
+    t.set_K(seq.K)
+    s.queue_depth_frame(z16[0], None, depth_scale=1.0 / 5000.0, **params)
+    s.queue_depth_frame(bad, None, sigma_s=1.0, sigma_r=0.001, normal_radius=3)
+    s.next_frame()
+    s.update()
+    first = s.get_preprocessed()
+    with pytest.raises(ts.TsdfError) as ei:
+        s.next_frame()
+    assert "too large" in str(ei.value)
+    again = s.get_preprocessed()                     # frame 0 is still the current one
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(first, again))
+    s.queue_depth_frame(z16[1], None, depth_scale=1.0 / 5000.0, **params)
+    s.queue_depth_frame(z16[2], None, depth_scale=1.0 / 5000.0, **params)
+    for _ in range(2):
+        s.next_frame()
+        t.estimate_new_position()
+        s.update()
+    with pytest.raises(ts.TsdfError):
+        s.next_frame()
+    s.close()
+
+
 def test_preproc_argument_checks():
     import tracking_sdf_amd as ts
     s = ts.SDF(32)
