@@ -207,7 +207,7 @@ def test_a_bad_frame_behind_a_good_one_in_the_queue_is_reported_by_its_own_next_
         xyz = seq.frame(k)[0]
         z16.append(np.clip(np.where(np.isnan(xyz[..., 2]), 0.0, xyz[..., 2]) * 5000.0, 0, 65535).astype(np.uint16))
     bad = np.linspace(1.0, 5.0, h * w, dtype=np.float32).reshape(h, w)
-    s = ts.SDF(32)
+    s = ts.SDF(32, with_color=False)
     t = ts.CameraTracking(sdf=s)
     t.set_K(seq.K)
     s.queue_depth_frame(z16[0], None, depth_scale=1.0 / 5000.0, **params)
