@@ -26,12 +26,12 @@ def test_header_symbols_all_exported_and_bound():
     for name in syms:
         assert hasattr(L, name), f"{name} declared in include/tsdf.h but not exported by libtsdf_hip.so"
     assert sorted(ts.ABI_SYMBOLS) == syms, "python binding and header disagree"
-    assert L.tsdf_abi_version() == 3
+    assert L.tsdf_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     # tsdf_config: 4+3*4 = 16, origin (8-aligned) 24, then 4*... -> check against a hand computation
-    assert C.sizeof(ts.Config) == 96           # (carry_threads took the padding word in front of the 8-aligned end)
+    assert C.sizeof(ts.Config) == 104          # (slab_stride + a padding word in front of the 8-aligned end)
     assert ts.Config.origin.offset == 16 and ts.Config.delta.offset == 40 and ts.Config.carry_threads.offset == 72
     assert ts.Config.device.offset == 92
     assert C.sizeof(ts.IntegrateStats) == 24 and C.sizeof(ts.AccumStats) == 48

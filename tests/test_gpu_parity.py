@@ -374,6 +374,93 @@ def test_slab_shards_sum_to_whole():
     assert sym_rel_err(sum(p[1] for p in parts), b) < 1e-12
 
 
+@pytest.mark.parametrize("m,nr,block,with_color", [(64, 2, 16, True), (64, 4, 8, False), (128, 4, 16, True)])
+def test_block_cyclic_shards_sum_to_whole(m, nr, block, with_color):
+    """Block-cyclic placement (tsdf_config::slab_stride; DESIGN 6.1): rank r owns the blocks [r B + j N B, (r+1) B + j N B),
+    each stored with its halo.  Emulated on one GPU, one handle per rank: every rank integrates the same three noisy frames
+    at the same poses; its own layers equal the same layers of the whole volume bit for bit (D, W, colour), the owned
+    n_updated counts add up to the whole volume's per frame, and one Gauss-Newton pass at a fourth pose adds up -- counts
+    exactly, A and b to 1e-12 (f64, another summation order).  tsdf_sample agrees wherever a rank stores the point."""
+    import tracking_sdf_amd as ts
+    seq, fr = frames(4, noise=True, holes=0.02)
+    whole, wt = make_gpu(m, seq.K, with_color=with_color)
+    halo = ts.halo_for(whole.cfg, 6.0)
+    assert nr * block - block >= 2 * halo or pytest.skip("halo too wide for this block size")
+    ranks = [make_gpu(m, seq.K, with_color=with_color, slab=(r * block, (r + 1) * block), halo=halo, slab_stride=nr * block) for r in range(nr)]
+    for k in range(3):
+        xyz, nrm, rgb = fr[k]
+        wt.set_camera_transformation(seq.R[k], seq.t[k])
+        st = whole.update(wt, xyz, nrm, rgb if with_color else None)
+        own = 0
+        for gs, gtr in ranks:
+            gtr.set_camera_transformation(seq.R[k], seq.t[k])
+            sr = gs.update(gtr, xyz, nrm, rgb if with_color else None)
+            own += sr["n_updated"]
+        assert own == st["n_updated"] and own > 0
+    Df, Wf = (a.reshape(m, m * m) for a in whole.download())
+    colf = [a.reshape(m, m * m) for a in whole.download_color()] if with_color else None
+    seen = np.zeros(m, bool)
+    for gs, _ in ranks:
+        xs = gs.owned_x()
+        assert not seen[xs].any()
+        seen[xs] = True
+        Ds, Ws = (a.reshape(len(xs), m * m) for a in gs.download())
+        assert np.array_equal(Ds, Df[xs], equal_nan=True) and np.array_equal(Ws, Wf[xs], equal_nan=True)
+        if with_color:
+            for a, b in zip(gs.download_color(), colf):
+                assert np.array_equal(a.reshape(len(xs), m * m), b[xs], equal_nan=True)
+    assert seen.all()                                       # every layer has exactly one owner
+    # one Gauss-Newton pass at the pose of the fourth frame
+    pose = (seq.R[3], seq.t[3])
+    xyz = fr[3][0]
+    wt.set_camera_transformation(*pose)
+    whole.set_frame(xyz)
+    A, b, st = wt.accumulate()
+    parts = []
+    for gs, gtr in ranks:
+        gtr.set_camera_transformation(*pose)
+        gs.set_frame(xyz)
+        parts.append(gtr.accumulate())
+    for key in ("n_terms", "n_ok", "n_in_grid_owned"):
+        assert sum(p[2][key] for p in parts) == st[key], key
+    assert st["n_ok"] > 0.3 * st["n_samples"]
+    assert sym_rel_err(sum(p[0] for p in parts), A) < 1e-12
+    assert sym_rel_err(sum(p[1] for p in parts), b) < 1e-12
+    # device-side sampling: a point is answered by the rank that stores its cell, with the whole volume's value
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(1.0, m - 2.0, size=(4000, 3))
+    vw, okw = whole.interpolate_distance(pts, raw=True)
+    answered = np.zeros(len(pts), bool)
+    for gs, _ in ranks:
+        mine = np.isin(np.floor(pts[:, 0]).astype(int), gs.owned_x())        # the cell starts in one of the rank's own layers
+        v, ok = gs.interpolate_distance(pts[mine], raw=True)
+        assert np.array_equal(ok, okw[mine]) and np.array_equal(v.view(np.uint32), vw[mine].view(np.uint32))
+        answered |= mine
+    assert answered.all()
+    with pytest.raises(ts.TsdfError) as ei:                # ... and a point two blocks away is refused, not answered from elsewhere
+        far = np.array([[float(ranks[0][0].owned_x()[0] + block + halo + 1) + 0.5, m / 2, m / 2]])
+        ranks[0][0].interpolate_distance(far)
+    assert ei.value.code == ts.E_HALO
+    # what a block-cyclic handle refuses: meshes and checkpoints (hot path only)
+    for call in (lambda: ranks[0][0].mesh(), lambda: ranks[0][0].save("/tmp/_cyclic.tsdfvol")):
+        with pytest.raises(ts.TsdfError):
+            call()
+    for gs, _ in ranks:
+        gs.close()
+    whole.close()
+
+
+def test_block_cyclic_configurations_that_are_refused():
+    import tracking_sdf_amd as ts
+    for kw in (dict(m=96, slab=(0, 16), halo=2, slab_stride=32),        # m not a power of two
+               dict(m=64, slab=(0, 12), halo=2, slab_stride=24),        # m not a multiple of the block
+               dict(m=64, slab=(8, 24), halo=2, slab_stride=32),        # block not at a multiple of its size
+               dict(m=64, slab=(0, 16), halo=9, slab_stride=32),        # stored ranges of two blocks would overlap
+               dict(m=64, slab=(0, 16), halo=2, slab_stride=-16)):
+        with pytest.raises(ts.TsdfError):
+            ts.SDF(with_color=False, **kw)
+
+
 def test_halo_too_small_is_reported():
     import tracking_sdf_amd as ts
     m = 64

@@ -26,7 +26,7 @@ OK, E_BADARG, E_NO_DEVICE, E_HIP, E_NO_INTRINSICS, E_NO_FRAME, E_SINGULAR, E_NO_
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 RED_WIDTH = 34
 RED_ALLREDUCE = 30
-ABI_VERSION = 3          # TSDF_ABI_VERSION of include/tsdf.h this module mirrors (struct layouts)
+ABI_VERSION = 4          # TSDF_ABI_VERSION of include/tsdf.h this module mirrors (struct layouts)
 
 
 class TsdfError(RuntimeError):
@@ -41,7 +41,8 @@ class Config(C.Structure):
                 ("origin", C.c_double * 3), ("delta", C.c_float), ("epsilon", C.c_float),
                 ("gn_max_iter", C.c_int32), ("max_twist_diff", C.c_float), ("v_h", C.c_float), ("w_h", C.c_float),
                 ("pixel_stride", C.c_int32), ("stale_carry", C.c_int32), ("carry_threads", C.c_int32), ("with_color", C.c_int32),
-                ("slab_x0", C.c_int32), ("slab_x1", C.c_int32), ("halo", C.c_int32), ("device", C.c_int32)]
+                ("slab_x0", C.c_int32), ("slab_x1", C.c_int32), ("halo", C.c_int32), ("device", C.c_int32),
+                ("slab_stride", C.c_int32)]
 
 
 class PreprocParams(C.Structure):
@@ -370,7 +371,7 @@ class SDF:
     """
 
     def __init__(self, m=256, width=6.0, height=6.0, depth=3.5, sdf_origin=(-3.0, -3.0, -0.5),
-                 distance_delta=0.3, distance_epsilon=0.025, *, with_color=True, slab=None, halo=0,
+                 distance_delta=0.3, distance_epsilon=0.025, *, with_color=True, slab=None, halo=0, slab_stride=0,
                  device=0, stale_carry=True, carry_threads=1, gn_max_iter=20, max_twist_diff=0.001, v_h=1.0, w_h=0.01,
                  pixel_stride=3):
         L = lib()
@@ -382,6 +383,7 @@ class SDF:
                              pixel_stride=int(pixel_stride))
         if slab is not None:
             cfg.slab_x0, cfg.slab_x1 = int(slab[0]), int(slab[1])
+        cfg.slab_stride = int(slab_stride)      # > 0: block-cyclic placement, blocks [x0 + b*stride, x1 + b*stride) (tsdf.h)
         self._h = C.c_void_p()
         rc = L.tsdf_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -625,12 +627,14 @@ class SDF:
         return None
 
     # -- SDF::interpolate_distance, sdf.h:86 (batched; voxel coordinates like the reference's argument)
-    def interpolate_distance(self, voxel_coordinates):
+    def interpolate_distance(self, voxel_coordinates, raw=False):
+        """tsdf_sample.  raw=True returns the int32 flags as they come: 1 interpolated, 0 not (the reference's
+        is_interpolated = false), -1 a corner lies in the grid but outside the layers this handle stores."""
         v = np.ascontiguousarray(voxel_coordinates, dtype=np.float64).reshape(-1, 3)
         val = np.zeros(len(v), dtype=np.float32)
         ok = np.zeros(len(v), dtype=np.int32)
         self._check(lib().tsdf_sample(self._h, _dptr(v), len(v), _fptr(val), ok.ctypes.data_as(C.POINTER(C.c_int32))))
-        return val, ok.astype(bool)
+        return val, (ok if raw else ok.astype(bool))
 
     # -- the visualiser thread's mesh (sdf.cpp:317-391; pcl::MarchingCubesSDF::performReconstruction)
     def mesh(self, iso_level=0.0, with_color=False, read=True):
@@ -647,8 +651,19 @@ class SDF:
         return (v, c) if with_color else v
 
     # -- host mirrors of D/W (what the reference hands to its mesher, sdf.cpp:47-49)
+    def owned_layers(self):
+        """x layers this handle owns: the slab's, or the sum over the blocks of a block-cyclic handle (owned_x() lists them)."""
+        return len(self.owned_x())
+
+    def owned_x(self):
+        """global x indices of the owned layers, in the order download() returns them"""
+        x0, x1, st = int(self.cfg.slab_x0), int(self.cfg.slab_x1), int(self.cfg.slab_stride)
+        if st <= 0:
+            return np.arange(x0, x1)
+        return np.concatenate([np.arange(x0 + b, x1 + b) for b in range(0, self.m - x0, st)])
+
     def download(self):
-        n = (self.cfg.slab_x1 - self.cfg.slab_x0) * self.m * self.m
+        n = self.owned_layers() * self.m * self.m
         D = np.empty(n, dtype=np.float32)
         W = np.empty(n, dtype=np.float32)
         self._check(lib().tsdf_download(self._h, _fptr(D), _fptr(W)))
@@ -657,7 +672,7 @@ class SDF:
     def upload(self, D, W):
         D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1)
         W = np.ascontiguousarray(W, dtype=np.float32).reshape(-1)
-        n = (self.cfg.slab_x1 - self.cfg.slab_x0) * self.m * self.m
+        n = self.owned_layers() * self.m * self.m
         assert D.size == n and W.size == n
         self._check(lib().tsdf_upload(self._h, _fptr(D), _fptr(W)))
 
@@ -680,7 +695,7 @@ class SDF:
         self._check(lib().tsdf_upload_color_with_halo(self._h, *[_fptr(a) for a in arrs]))
 
     def download_color(self):
-        n = (self.cfg.slab_x1 - self.cfg.slab_x0) * self.m * self.m
+        n = self.owned_layers() * self.m * self.m
         out = [np.empty(n, dtype=np.float32) for _ in range(4)]
         self._check(lib().tsdf_download_color(self._h, *[_fptr(a) for a in out]))
         return tuple(out)

@@ -146,6 +146,17 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     int32_t x0 = cfg->slab_x0, x1 = cfg->slab_x1;
     if (x0 == 0 && x1 == 0) x1 = cfg->m;
     if (x0 < 0 || x1 > cfg->m || x0 >= x1) return fail(nullptr, TSDF_E_BADARG, "tsdf_create: bad slab [%d,%d)", x0, x1);
+    const int32_t stride = cfg->slab_stride;
+    if (stride < 0) return fail(nullptr, TSDF_E_BADARG, "tsdf_create: slab_stride %d", stride);
+    if (stride > 0) {
+        const int32_t B = x1 - x0, Lb = B + 2 * cfg->halo;
+        if ((cfg->m & (cfg->m - 1)) != 0 || cfg->m % B != 0 || x0 % B != 0 || stride % B != 0 || stride < Lb)
+            return fail(nullptr, TSDF_E_BADARG, "tsdf_create: block-cyclic placement needs m a power of two and a multiple of the block (%d), "
+                        "blocks at multiples of it, and stride (%d) >= block + 2 * halo (%d)", B, stride, Lb);
+        const unsigned long long layers = (unsigned long long)((cfg->m - x0 + stride - 1) / stride) * (unsigned long long)Lb;
+        if (layers * Lb * Lb >= (1ull << 32))                              // (the multiply-high division of grid_global_layer)
+            return fail(nullptr, TSDF_E_BADARG, "tsdf_create: %llu stored layers in blocks of %d are too many for the block arithmetic", layers, Lb);
+    }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -166,6 +177,11 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     g.own_x0 = x0; g.own_x1 = x1;
     g.xs = x0 - cfg->halo < 0 ? 0 : x0 - cfg->halo;
     g.xe = x1 + cfg->halo > cfg->m ? cfg->m : x1 + cfg->halo;
+    if (stride > 0) {
+        g.blk_own = x1 - x0; g.blk_layers = g.blk_own + 2 * cfg->halo; g.blk_stride = stride; g.blk_first = x0 - cfg->halo;
+        g.n_blocks = (cfg->m - x0 + stride - 1) / stride;
+        g.blk_magic = (uint32_t)((1ull << 32) / (unsigned)g.blk_layers + 1ull);
+    }
     g.cell_w = cfg->width / ((float)cfg->m);       // sdf.h:154-156
     g.cell_h = cfg->height / ((float)cfg->m);
     g.cell_d = cfg->depth / ((float)cfg->m);
@@ -201,7 +217,7 @@ int tsdf_create(const tsdf_config* cfg, tsdf_handle** out) {
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_stage_done[1], hipEventDisableTiming));
-    h->n_stored = (int64_t)(g.xe - g.xs) * g.m * g.m;
+    h->n_stored = (int64_t)grid_stored_layers(g) * g.m * g.m;
     // Padding voxels {D = 0, W = 0} around the volume (16 in front: keeps the 128-byte alignment of the rows; 2 behind).
     // Tracker look-ups read the corner pair (k, k+1) with one 16-byte load at k in [-1, m-1]: at the two ends of a row
     // that touches the neighbouring row or, for the first / last row, this padding; the pair behind the volume also

@@ -19,9 +19,16 @@ using namespace tsdf_api;
 
 // ---- mesh extraction ---------------------------------------------------------------------------------
 
+static int refuse_cyclic(tsdf_handle* h, const char* who) {
+    if (h->grid.blk_own > 0)
+        return fail(h, TSDF_E_BADARG, "%s: not available for a handle with block-cyclic placement (slab_stride > 0): hot path only", who);
+    return TSDF_OK;
+}
+
 int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64_t* n_triangles) {
     int rc = check_ready(h, false);
     if (rc) return rc;
+    if ((rc = refuse_cyclic(h, "tsdf_mesh_extract")) != TSDF_OK) return rc;
     if (n_triangles) *n_triangles = 0;
     h->mesh_ntri = -1;
     if (!(iso_level >= 0.0f && iso_level < 1.0f))                 // marching_cubes_sdf.cpp:246-252
@@ -157,30 +164,45 @@ int volume_io(tsdf_handle* h, bool download, bool color, int64_t first, int64_t 
     return TSDF_OK;
 }
 
+// the handle's OWN layers, in increasing x: one range of a plain slab, one per block of a block-cyclic handle
+int owned_io(tsdf_handle* h, bool download, bool color, float* const* host) {
+    const Grid& g = h->grid;
+    const int64_t mm = (int64_t)g.m * g.m;
+    if (g.blk_own <= 0) return volume_io(h, download, color, (g.own_x0 - g.xs) * mm, (g.own_x1 - g.own_x0) * mm, host);
+    const int planes = color ? 4 : 2;
+    const int64_t n = (int64_t)g.blk_own * mm;
+    for (int b = 0; b < g.n_blocks; ++b) {
+        float* at[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int q = 0; q < planes; ++q) at[q] = host[q] + (int64_t)b * n;
+        const int rc = volume_io(h, download, color, ((int64_t)b * g.blk_layers + (g.own_x0 - g.blk_first)) * mm, n, at);
+        if (rc) return rc;
+    }
+    return TSDF_OK;
+}
+
 }  // namespace
 
 int tsdf_download(tsdf_handle* h, float* D, float* W) {
     int rc = check_ready(h, false);
     if (rc) return rc;
     if (!D || !W) return fail(h, TSDF_E_BADARG, "tsdf_download: null output");
-    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
     float* host[4] = {D, W, nullptr, nullptr};
-    return volume_io(h, true, false, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+    return owned_io(h, true, false, host);
 }
 
 int tsdf_upload(tsdf_handle* h, const float* D, const float* W) {
     int rc = check_ready(h, false);
     if (rc) return rc;
     if (!D || !W) return fail(h, TSDF_E_BADARG, "tsdf_upload: null input");
-    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
     float* host[4] = {const_cast<float*>(D), const_cast<float*>(W), nullptr, nullptr};
-    return volume_io(h, false, false, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+    return owned_io(h, false, false, host);
 }
 
 int tsdf_upload_with_halo(tsdf_handle* h, const float* D, const float* W) {
     int rc = check_ready(h, false);
     if (rc) return rc;
     if (!D || !W) return fail(h, TSDF_E_BADARG, "tsdf_upload_with_halo: null input");
+    if ((rc = refuse_cyclic(h, "tsdf_upload_with_halo")) != TSDF_OK) return rc;
     float* host[4] = {const_cast<float*>(D), const_cast<float*>(W), nullptr, nullptr};
     return volume_io(h, false, false, 0, h->n_stored, host);
 }
@@ -190,9 +212,8 @@ int tsdf_download_color(tsdf_handle* h, float* Color_W, float* R, float* G, floa
     if (rc) return rc;
     if (!h->crgb) return fail(h, TSDF_E_BADARG, "volume was created with with_color=0");
     if (!Color_W || !R || !G || !B) return fail(h, TSDF_E_BADARG, "tsdf_download_color: null output");
-    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
     float* host[4] = {Color_W, R, G, B};
-    return volume_io(h, true, true, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+    return owned_io(h, true, true, host);
 }
 
 int tsdf_upload_color(tsdf_handle* h, const float* Color_W, const float* R, const float* G, const float* B) {
@@ -200,14 +221,14 @@ int tsdf_upload_color(tsdf_handle* h, const float* Color_W, const float* R, cons
     if (rc) return rc;
     if (!h->crgb) return fail(h, TSDF_E_BADARG, "volume was created with with_color=0");
     if (!Color_W || !R || !G || !B) return fail(h, TSDF_E_BADARG, "tsdf_upload_color: null input");
-    const int64_t mm = (int64_t)h->grid.m * h->grid.m;
     float* host[4] = {const_cast<float*>(Color_W), const_cast<float*>(R), const_cast<float*>(G), const_cast<float*>(B)};
-    return volume_io(h, false, true, (h->grid.own_x0 - h->grid.xs) * mm, (h->grid.own_x1 - h->grid.own_x0) * mm, host);
+    return owned_io(h, false, true, host);
 }
 
 int tsdf_upload_color_with_halo(tsdf_handle* h, const float* Color_W, const float* R, const float* G, const float* B) {
     int rc = check_ready(h, false);
     if (rc) return rc;
+    if ((rc = refuse_cyclic(h, "tsdf_upload_color_with_halo")) != TSDF_OK) return rc;
     if (!h->crgb) return fail(h, TSDF_E_BADARG, "volume was created with with_color=0");
     if (!Color_W || !R || !G || !B) return fail(h, TSDF_E_BADARG, "tsdf_upload_color_with_halo: null input");
     float* host[4] = {const_cast<float*>(Color_W), const_cast<float*>(R), const_cast<float*>(G), const_cast<float*>(B)};
@@ -237,6 +258,7 @@ bool read_plane(FILE* f, long long plane_floats, int plane, long long first, flo
 int tsdf_save(tsdf_handle* h, const char* path) {
     int rc = check_ready(h, false);
     if (rc) return rc;
+    if ((rc = refuse_cyclic(h, "tsdf_save")) != TSDF_OK) return rc;
     if (!path) return fail(h, TSDF_E_BADARG, "tsdf_save: null path");
     const size_t n = (size_t)h->n_stored;              // slab + halo: a restored shard needs its halo layers too
     std::vector<float> buf;
@@ -280,6 +302,7 @@ int tsdf_save(tsdf_handle* h, const char* path) {
 int tsdf_load(tsdf_handle* h, const char* path) {
     int rc = check_ready(h, false);
     if (rc) return rc;
+    if ((rc = refuse_cyclic(h, "tsdf_load")) != TSDF_OK) return rc;
     if (!path) return fail(h, TSDF_E_BADARG, "tsdf_load: null path");
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(h, TSDF_E_BADARG, "tsdf_load: cannot open %s", path);

@@ -203,7 +203,7 @@ void tsdf_default_config(tsdf_config* c) {
     c->stale_carry = 1;
     c->carry_threads = 1;
     c->with_color = 1;
-    c->slab_x0 = 0; c->slab_x1 = 0; c->halo = 0; c->device = 0;
+    c->slab_x0 = 0; c->slab_x1 = 0; c->halo = 0; c->device = 0; c->slab_stride = 0;
 }
 
 const char* tsdf_strerror(int s) {

@@ -224,8 +224,9 @@ __global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p
         if (tl.log2m >= 0) { il = (int)(row >> tl.log2m); j = (int)(row & (m - 1)); }
         else { il = (int)(row / m); j = (int)(row - (long long)il * m); }
         const double cw = (double)p.g.cell_w, ch = (double)p.g.cell_h, cd = (double)p.g.cell_d;
+        const int gi = grid_global_layer(p.g, il);                     // (il + xs for a plain slab)
         // get_global_coordinates, sdf.h:153-157: (extent/(float)m) * (i + 0.5) + origin
-        const double gx = cw * ((double)(il + p.g.xs) + 0.5) + p.g.origin[0];
+        const double gx = cw * ((double)gi + 0.5) + p.g.origin[0];
         const double gy = ch * ((double)j + 0.5) + p.g.origin[1];
         // first two terms of rot_inv * g in Eigen's order ((r0*gx + r1*gy) + r2*gz): the same for every k
         double S[3];
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p
                 bin = fb >= 0.0 ? (fb < (double)(kBins - 1) ? (int)fb : kBins - 1) : 0;       // NaN -> 0
             }
         }
-        if (klo <= khi) { c0 = klo >> 6; n = (khi >> 6) - c0 + 1; }
+        if (klo <= khi && gi >= 0 && gi < m) { c0 = klo >> 6; n = (khi >> 6) - c0 + 1; }      // (a block-cyclic handle's padding layers hold no voxel)
     }
     unsigned rank = 0u;
     if (n) rank = atomicAdd(&s_wg[bin], (unsigned)n);
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(kClipBlock) void list_rows_kernel(IntegrateParams p
         if (tl.log2m >= 0) { il = (int)(rrow >> tl.log2m); jr = (int)(rrow & (m - 1)); }
         else { il = (int)(rrow / m); jr = (int)(rrow - (long long)il * m); }
         // get_global_coordinates, sdf.h:153-157: (extent/(float)m) * (i + 0.5) + origin
-        const double gx = (double)p.g.cell_w * ((double)(il + p.g.xs) + 0.5) + p.g.origin[0];
+        const double gx = (double)p.g.cell_w * ((double)grid_global_layer(p.g, il) + 0.5) + p.g.origin[0];
         const double gy = (double)p.g.cell_h * ((double)jr + 0.5) + p.g.origin[1];
         ItemDesc d;
         d.pad = 0u;
@@ -668,7 +669,7 @@ hipError_t launch_release(hipStream_t s, const ReleaseWord& rel) {
     return hipGetLastError();
 }
 
-template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB>
+template <bool COLOR, bool KSTD, bool EXPPOLY, bool KTAB, bool CYC /* block-cyclic placement: which rows are the handle's own */>
 __global__ __launch_bounds__(kIntegrateBlock, kIntegrateMinWaves) void integrate_kernel(
     IntegrateParams p, IntegrateTiling tl, const ItemDesc* __restrict__ list, const unsigned* __restrict__ set,
     unsigned* __restrict__ next_set, unsigned ovf_base, unsigned long long* __restrict__ totals,
@@ -868,7 +869,13 @@ __global__ __launch_bounds__(kIntegrateBlock, kIntegrateMinWaves) void integrate
     auto stage3 = [&](const UpdateState& uin /*item j-1-DEPTH, volume data arrived*/) {
         const unsigned code3 = uin.code;
         const unsigned row3 = code3 >> 6;
-        const bool owned3 = row3 >= own_row0 && row3 < own_row1;            // wave-uniform; rows of the owned x layers
+        bool owned3;                                                        // wave-uniform; rows of the owned x layers
+        if (!CYC) owned3 = row3 >= own_row0 && row3 < own_row1;
+        else {      // local layer -> position in its block (m is a power of two here; blocks lie inside the grid: tsdf_create)
+            const unsigned il3 = row3 >> (unsigned)tl.log2m;
+            const unsigned o3 = il3 - __umulhi(il3, p.g.blk_magic) * (unsigned)p.g.blk_layers;
+            owned3 = o3 - (unsigned)(p.g.own_x0 - p.g.blk_first) < (unsigned)p.g.blk_own;
+        }
         long long base3 = (long long)row3 * m + (long long)(code3 & 63u) * 64;
         const unsigned n_live = (unsigned)__popcll(uin.live);
         n_own += owned3 ? n_live : 0u;
@@ -986,7 +993,7 @@ __global__ __launch_bounds__(kIntegrateBlock, kIntegrateMinWaves) void integrate
     }
 }
 size_t integrate_worklist_entries(const Grid& g) {
-    return (size_t)(g.xe - g.xs) * g.m * ((g.m + 63) / 64);
+    return (size_t)grid_stored_layers(g) * g.m * ((g.m + 63) / 64);
 }
 // The band regions in front of the overflow region hold at most a quarter of all possible items (a frame lists a few
 // percent of them: 9 % at 512^3; whatever the bands' capacities cannot take goes to the overflow region, which is
@@ -1004,7 +1011,7 @@ size_t integrate_worklist_bytes(const Grid& g) {
 
 int integrate_blocks_per_cu() {
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true, true, true>, kIntegrateBlock, 512 * 24);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, integrate_kernel<true, true, true, true, false>, kIntegrateBlock, 512 * 24);
     if (e != hipSuccess || n < 1) n = kIntegrateMinWaves;
     return n;
 }
@@ -1015,7 +1022,7 @@ static_assert((2 * kBinSetWords) % 2 == 0, "the 64-bit tick sums of the feedback
 
 static bool make_tiling(const IntegrateParams& p, IntegrateTiling& tl) {
     const int m = p.g.m;
-    const int nx = p.g.xe - p.g.xs;
+    const int nx = grid_stored_layers(p.g);
     tl.n_rows = (long long)nx * m;
     tl.log2m = -1;
     for (int b = 0; b < 31; ++b) if ((1 << b) == m) tl.log2m = b;
@@ -1039,7 +1046,7 @@ static bool use_exp_poly(const IntegrateParams& p) {
 hipError_t launch_integrate_list(hipStream_t s, const IntegrateParams& p, void* worklist, unsigned* work_count,
                                  unsigned launch_parity, const PackArgs* pack) {
     const int m = p.g.m;
-    const int nx = p.g.xe - p.g.xs;
+    const int nx = grid_stored_layers(p.g);
     if (nx <= 0 || m <= 0) return hipSuccess;
     IntegrateTiling tl;
     if (!make_tiling(p, tl)) return hipErrorInvalidValue;
@@ -1062,7 +1069,7 @@ hipError_t launch_integrate_items(hipStream_t s, const IntegrateParams& p, float
                                   void* worklist, unsigned* work_count, int n_blocks,
                                   unsigned launch_parity, unsigned long long* wg_counts, const ReleaseWord* release) {
     const int m = p.g.m;
-    const int nx = p.g.xe - p.g.xs;
+    const int nx = grid_stored_layers(p.g);
     if (nx <= 0 || m <= 0) return hipSuccess;
     IntegrateTiling tl;
     if (!make_tiling(p, tl)) return hipErrorInvalidValue;
@@ -1074,11 +1081,13 @@ hipError_t launch_integrate_items(hipStream_t s, const IntegrateParams& p, float
     const unsigned ovf_base = (unsigned)integrate_band_region_entries(p.g);
     const bool exp_poly = use_exp_poly(p);
     const bool ktab = m <= 1024;                                       // 24 bytes of LDS per k
+    const bool cyc = p.g.blk_own > 0;
     const size_t lds = ktab ? (size_t)m * 24 : 0;
     const char* planes = reinterpret_cast<const char*>(pn);
     const ReleaseWord rel = release ? *release : ReleaseWord{};
 #define TSDF_LAUNCH_INTEGRATE(C, KS, EP, KT) \
-    integrate_kernel<C, KS, EP, KT><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb, rel)
+    do { if (cyc) integrate_kernel<C, KS, EP, KT, true><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb, rel); \
+         else integrate_kernel<C, KS, EP, KT, false><<<dim3(n_blocks), dim3(kIntegrateBlock), lds, s>>>(p, tl, list, cur, nxt, ovf_base, counters, dw, crgb, planes, wg_counts, xcd_fb, rel); } while (0)
 #define TSDF_LAUNCH_INTEGRATE3(C, KS, EP) do { if (ktab) TSDF_LAUNCH_INTEGRATE(C, KS, EP, true); else TSDF_LAUNCH_INTEGRATE(C, KS, EP, false); } while (0)
 #define TSDF_LAUNCH_INTEGRATE2(C, KS) do { if (exp_poly) TSDF_LAUNCH_INTEGRATE3(C, KS, true); else TSDF_LAUNCH_INTEGRATE3(C, KS, false); } while (0)
     if (p.with_color) { if (tl.k_std) TSDF_LAUNCH_INTEGRATE2(true, true); else TSDF_LAUNCH_INTEGRATE2(true, false); }

@@ -33,9 +33,20 @@ namespace tsdf {
 
 struct Vol {
     const float2* dw;
-    int m, xs, xe;
-    __device__ __forceinline__ long long dummy() const { return (long long)(xe - xs) * m * m; }   // the {0,0} pair behind the volume
+    int m, xs, xe;           // the stored x layers a look-up may touch: the slab's -- or, block-cyclic, those of ONE block (make_vol)
+    int xoff;                // global layer of local layer 0 as seen from that block (the slab's xs)
+    int n_layers;            // all stored layers of the handle
+    __device__ __forceinline__ long long dummy() const { return (long long)n_layers * m * m; }   // the {0,0} pair behind the volume
 };
+// The part of the volume a look-up around the centre voxel layer `ci` may touch.  A plain slab: all of it.  Block-cyclic: the
+// stored layers of the block `ci` belongs to (a sample this rank owns has its 13 look-ups within the halo of that block).
+__device__ __forceinline__ Vol make_vol(const Grid& g, const float2* dw, int ci) {
+    if (g.blk_own <= 0) return Vol{dw, g.m, g.xs, g.xe, g.xs, g.xe - g.xs};
+    const int b = grid_block_of(g, ci);
+    const int first = g.blk_first + b * g.blk_stride;
+    const int lo = first < 0 ? 0 : first, hi = first + g.blk_layers > g.m ? g.m : first + g.blk_layers;
+    return Vol{dw, g.m, lo, hi, first - b * g.blk_layers, g.n_blocks * g.blk_layers};
+}
 
 typedef float vol_f4 __attribute__((ext_vector_type(4), aligned(8)));   // two neighbouring voxels {D,W,D,W}
 
@@ -70,7 +81,7 @@ __device__ __forceinline__ void lookup_issue(const Vol& V, double vx, double vy,
     const bool i_st[2] = {i_in[0] && bi >= V.xs && bi < V.xe, i_in[1] && bi + 1 >= V.xs && bi + 1 < V.xe};
     const bool k_any = L.k_ok[0] | L.k_ok[1];
     const long long mm = (long long)m * m;
-    const long long base = (((long long)bi - V.xs) * m + bj) * m + kc;
+    const long long base = (((long long)bi - V.xoff) * m + bj) * m + kc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int io = r >> 1, jo = r & 1;
@@ -138,10 +149,11 @@ __global__ __launch_bounds__(256) void sample_kernel(Grid g, const float2* __res
                                                       float* __restrict__ val, int* __restrict__ okv) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    Vol V{dw, g.m, g.xs, g.xe};
+    const double vx0 = vox[3 * t + 0];
+    const Vol V = make_vol(g, dw, (vx0 >= 0.0 && vx0 < (double)g.m) ? (int)vx0 : 0);
     float out = 0.0f;
     unsigned viol = 0;
-    const bool ok = interp(V, vox[3 * t + 0], vox[3 * t + 1], vox[3 * t + 2], out, viol);
+    const bool ok = interp(V, vx0, vox[3 * t + 1], vox[3 * t + 2], out, viol);
     val[t] = out;
     okv[t] = viol ? -1 : (ok ? 1 : 0);
 }
@@ -342,9 +354,10 @@ hipError_t launch_peer_exchange(hipStream_t s, const PeerExchange& px, double* r
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const float2* __restrict__ dw,
-                                                             const float4* __restrict__ samples,
-                                                             double* __restrict__ partials, TrackFold fold) {
+template <bool CYC /* block-cyclic placement */>
+__device__ __forceinline__ void track_body(const TrackParams& p, const float2* __restrict__ dw,
+                                           const float4* __restrict__ samples,
+                                           double* __restrict__ partials, const TrackFold& fold) {
     constexpr int NW = kTrackBlock / 64;
     __shared__ unsigned long long s_in[1], s_oog[1];       // the 64-sample window of this workgroup
     __shared__ unsigned long long s_in2[NW], s_oog2[NW];   // look-ahead windows
@@ -457,7 +470,10 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
 
     // ---- the look-ups of this lane (camera_tracking.cpp:269-361): slot A = look-up q (centre, +x -x +y -y +z -z)
     // on lanes 0..6, slot B = look-up 7 + q (r1p r1m r2p r2m r3p r3m) on lanes 0..5
-    const bool owned = (cls == kClsIn) && (sg.vx >= (double)p.g.own_x0) && (sg.vx < (double)p.g.own_x1);
+    bool owned;
+    int centre_layer = 0;
+    if (!CYC) owned = (cls == kClsIn) && (sg.vx >= (double)p.g.own_x0) && (sg.vx < (double)p.g.own_x1);
+    else { centre_layer = cls == kClsIn ? (int)sg.vx : 0; owned = (cls == kClsIn) && grid_owns_layer(p.g, centre_layer); }   // (0 <= vx < m: truncation = floor)
     float valA = 0.0f, valB = 0.0f;
     unsigned viol = 0;
     bool okA = false, okB = false;
@@ -465,7 +481,7 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
         // both look-ups are issued before either is evaluated; lanes without a look-up run the same code on their
         // sample's centre (in-cache, results masked) so that the whole section stays one basic block
         const bool actA = owned && q < 7, actB = owned && q < 6;
-        Vol V{dw, p.g.m, p.g.xs, p.g.xe};
+        const Vol V = CYC ? make_vol(p.g, dw, centre_layer) : Vol{dw, p.g.m, p.g.xs, p.g.xe, p.g.xs, p.g.xe - p.g.xs};
         double ax = sg.vx, ay = sg.vy, az = sg.vz;
         // (lanes without a look-up repeating the address of a NEIGHBOURING lane of their quad instead of the centre's:
         // measured in round 6, no difference -- profiles/r06_track_duplicate_addresses.json)
@@ -725,6 +741,17 @@ __global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const
                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// (track_kernel keeps its name and argument list: the stand-alone code object of the library's own queue is found by them)
+__global__ __launch_bounds__(kTrackBlock) void track_kernel(TrackParams p, const float2* __restrict__ dw,
+                                                             const float4* __restrict__ samples,
+                                                             double* __restrict__ partials, TrackFold fold) {
+    track_body<false>(p, dw, samples, partials, fold);
+}
+__global__ __launch_bounds__(kTrackBlock) void track_kernel_cyclic(TrackParams p, const float2* __restrict__ dw,
+                                                                    const float4* __restrict__ samples,
+                                                                    double* __restrict__ partials, TrackFold fold) {
+    track_body<true>(p, dw, samples, partials, fold);
+}
 
 // After an in-stream all-reduce (RCCL) of red_dev: hand the reduced row to the host the way track_kernel's last
 // workgroup does (pinned memory + system-scope release of the pass number), so the host can poll instead of
@@ -771,6 +798,10 @@ hipError_t launch_track_folded(hipStream_t s, const TrackParams& p, const float2
     f.tag = (double)(pass & 0xFFFFFFFFFFFFull);
     if (peers) f.peers = *peers;
     if (went_through_queue) *went_through_queue = false;
+    if (p.g.blk_own > 0) {
+        track_kernel_cyclic<<<dim3(nb), dim3(kTrackBlock), 0, s>>>(p, dw, samples, partials, f);
+        return hipGetLastError();
+    }
     if (aql) {
         TrackKernarg ka{p, dw, samples, partials, f};
         if (aql->submit(&ka, (uint32_t)nb, (uint32_t)kTrackBlock)) { if (went_through_queue) *went_through_queue = true; return hipSuccess; }

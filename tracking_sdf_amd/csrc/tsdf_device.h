@@ -56,13 +56,49 @@ inline void track_unpack_row(const double* tot, double* red) {
 // idx = m*m*i + m*j + k restricted to i in [xs, xe)  (x-slab + halo), k fastest.
 struct Grid {
     int32_t m;
-    int32_t xs, xe;          // stored x layers [xs, xe)
-    int32_t own_x0, own_x1;  // owned x layers (slab without halo)
+    int32_t xs, xe;          // stored x layers [xs, xe)  (block-cyclic: those of block 0, clipped to the grid)
+    int32_t own_x0, own_x1;  // owned x layers (slab without halo; block-cyclic: those of block 0)
     float cell_w, cell_h, cell_d;     // extent / (float)m, float quotients (sdf.h:154-156)
     float m_div_w, m_div_h, m_div_d;  // m / extent, float quotients (sdf.cpp:19-21)
     double origin[3];
     float delta, epsilon;
+    // Block-cyclic placement (blk_own > 0; tsdf_config::slab_stride): the handle owns the layers
+    // [own_x0 + b * blk_stride, own_x0 + b * blk_stride + blk_own) of blocks b = 0 .. n_blocks - 1 and stores each block with
+    // its halo: blk_layers = blk_own + 2 * halo layers per block, back to back in memory, block b's first stored layer
+    // being the global layer blk_first + b * blk_stride (blk_first = own_x0 - halo; layers outside [0, m) -- the halo of
+    // a block at the edge of the grid -- exist in memory and are never listed, read or written).  The stored ranges of
+    // two blocks never overlap (blk_stride >= blk_layers).  blk_magic = 2^32 / blk_layers + 1: local layer / blk_layers
+    // as a multiply-high (exact for local layers < 2^32 / blk_layers^2: checked at creation).
+    int32_t blk_own, blk_layers, blk_stride, blk_first, n_blocks;
+    uint32_t blk_magic;
 };
+
+#if defined(__HIPCC__)
+#define TSDF_HD __host__ __device__
+#else
+#define TSDF_HD
+#endif
+// stored x layers of the handle (every block with its halo)
+TSDF_HD inline int grid_stored_layers(const Grid& g) { return g.blk_own > 0 ? g.n_blocks * g.blk_layers : g.xe - g.xs; }
+// local stored layer -> global x layer (outside [0, m) for the padding layers of a block at the edge)
+TSDF_HD inline int grid_global_layer(const Grid& g, int il) {
+    if (g.blk_own <= 0) return il + g.xs;
+    const int b = (int)(((unsigned long long)(unsigned)il * g.blk_magic) >> 32);
+    return g.blk_first + b * g.blk_stride + (il - b * g.blk_layers);
+}
+// is the global x layer one of the handle's OWN layers?
+TSDF_HD inline bool grid_owns_layer(const Grid& g, int gi) {
+    if (g.blk_own <= 0) return gi >= g.own_x0 && gi < g.own_x1;
+    if (gi < g.own_x0 || gi >= g.m) return false;
+    return (gi - g.own_x0) % g.blk_stride < g.blk_own;
+}
+// The block whose stored layers hold (or would hold) the global layer gi: its index, clamped to the handle's blocks.
+TSDF_HD inline int grid_block_of(const Grid& g, int gi) {
+    if (g.blk_own <= 0) return 0;
+    int t = gi - g.blk_first;
+    int b = t < 0 ? 0 : t / g.blk_stride;
+    return b >= g.n_blocks ? g.n_blocks - 1 : b;
+}
 
 struct IntegrateParams {
     Grid g;

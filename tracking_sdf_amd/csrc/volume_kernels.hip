@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void fill_kernel(float2* __restrict__ dw, floa
 }
 
 hipError_t launch_fill(hipStream_t s, const Grid& g, float2* dw, float4* crgb, float d0) {
-    const long long n = (long long)(g.xe - g.xs) * g.m * g.m;
+    const long long n = (long long)grid_stored_layers(g) * g.m * g.m;
     if (n <= 0) return hipSuccess;
     long long blocks = (n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
