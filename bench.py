@@ -64,10 +64,18 @@ def parse(argv=None):
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--frame-step", type=int, default=1, help="use every n-th 30 Hz pose")
     ap.add_argument("--max-range", type=float, default=6.0, help="metres; sizes the slab halo")
-    ap.add_argument("--slabs", default="auto", choices=["auto", "path", "balanced", "uniform"],
-                    help="N > 1: path = x-slabs of equal expected WORK over the PLANNED camera path (tsdf_slab_range_weighted on view-frustum "
+    ap.add_argument("--cyclic-block", type=int, default=0,
+                    help="--slabs cyclic: x layers per block (0 = m / (2 N) rounded down to a power of two: two blocks per rank, "
+                         "the best trade of halo work against balance in DESIGN 6.1's table)")
+    ap.add_argument("--slabs", default="auto", choices=["auto", "cyclic", "path", "balanced", "uniform"],
+                    help="N > 1: cyclic = BLOCK-CYCLIC placement (tsdf_config::slab_stride): rank r owns the blocks [r B + j N B, (r+1) B + j N B), "
+                         "each stored with its halo -- every rank holds a share of every view, whatever the camera does (a plain slab's busiest "
+                         "rank carries 0.32-0.34 of a frame's work at N = 8 along fr1/plant, a block-cyclic rank 0.22-0.25); "
+                         "path = x-slabs of equal expected WORK over the PLANNED camera path (tsdf_slab_range_weighted on view-frustum "
                          "weights accumulated over the poses this run will visit: thin slabs where the camera looks, along the whole path); "
-                         "auto (default) = path when the path is known (it is here: the ground-truth trajectory), uniform otherwise; "
+                         "auto (default) = of cyclic (where the volume allows it: m a power of two, blocks wider than the halo) and path, the "
+                         "one whose busiest rank carries the smaller share of a frame's work over the planned path (it is known here: the "
+                         "ground-truth trajectory), else uniform; "
                          "balanced = the weights of the reference's initial pose only (camera_tracking.cpp:5-7; round 5's default: good "
                          "for the first ~100 frames, worse than uniform 480 frames down the path); uniform = equal thickness (tsdf_slab_range)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=24)
@@ -90,7 +98,7 @@ def parse(argv=None):
     ap.add_argument("--no-frame-queue", dest="frame_queue", action="store_false",
                     help="set every HBM-resident frame in front of its own tracker passes (tsdf_set_frame_device) instead of queueing frame "
                          "k+1 (tsdf_queue_frame_device) while frame k is processed.  Default since round 6: the queue -- frame k+1 is then "
-                         "packed, sample list included, inside frame k's integrate launch (+3 % frames/s, same bits)")
+                         "packed, sample list included, inside frame k's integrate launch (+3 %% frames/s, same bits)")
     ap.set_defaults(frame_queue=True)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the launcher plumbing (gloo lets several ranks share one GPU for testing)")
@@ -495,30 +503,61 @@ def run(args):
             self.m, self.w, self.h = m, w, h
             cfg0 = ts.default_config(m=m)
             self.halo = ts.halo_for(cfg0, args.max_range) if world > 1 else 0
-            policy = args.slabs if args.slabs != "auto" else ("path" if path is not None else "uniform")
-            if world > 1 and policy == "path" and path is not None:
-                # every rank computes the same cuts: the frusta of the poses this run will visit, up to the sensor's 5 m;
-                # boundaries that minimise the path-average of the busiest rank (tracking_sdf_amd.slab_cuts_for_path)
-                cuts = ts.slab_cuts_for_path(cfg0, K, w, h, path[0], path[1], world, self.halo, 5.0)
-                x0, x1 = cuts[rank], cuts[rank + 1]
-            elif world > 1 and policy == "balanced":
-                wts = ts.frustum_layer_weights(cfg0, K, w, h, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1], 5.0)
-                x0, x1 = ts.slab_range_weighted(m, world, rank, self.halo, wts)
-            else:
-                x0, x1 = ts.slab_range(m, world, rank)
-            self.slab_policy = policy if world > 1 else None
-            # for DESIGN 6.1's model in the result line: the busiest rank's share of the expected integration work (frustum
-            # weights of the layers a rank STORES, summed over the planned path; 1 for a single rank)
-            self.busiest_share = 1.0
-            if world > 1 and path is not None:
-                wts = ts.path_layer_weights(cfg0, K, w, h, path[0], path[1], 5.0)
-                pre = np.concatenate([[0.0], np.cumsum(wts)])
-                cuts = (ts.slab_cuts_for_path(cfg0, K, w, h, path[0], path[1], world, self.halo, 5.0) if policy == "path" else
-                        [ts.slab_range(m, world, r)[0] for r in range(world)] + [m]) if policy != "balanced" else None
-                if cuts is not None and pre[-1] > 0:
-                    self.busiest_share = float(max(pre[min(m, cuts[r + 1] + self.halo)] - pre[max(0, cuts[r] - self.halo)] for r in range(world)) / pre[-1])
+            # The placements a run may use: {name: (x0, x1, stride, owned ranges of every rank)}.
+            placements = {}
+            if world > 1:
+                cuts_u = [ts.slab_range(m, world, r)[0] for r in range(world)] + [m]
+                placements["uniform"] = (cuts_u[rank], cuts_u[rank + 1], 0, [[(cuts_u[r], cuts_u[r + 1])] for r in range(world)])
+                if path is not None:
+                    # every rank computes the same cuts: the frusta of the poses this run will visit, up to the sensor's 5 m;
+                    # boundaries that minimise the path-average of the busiest rank (tracking_sdf_amd.slab_cuts_for_path)
+                    cuts = ts.slab_cuts_for_path(cfg0, K, w, h, path[0], path[1], world, self.halo, 5.0)
+                    placements["path"] = (cuts[rank], cuts[rank + 1], 0, [[(cuts[r], cuts[r + 1])] for r in range(world)])
+                if args.slabs == "balanced":
+                    wts = ts.frustum_layer_weights(cfg0, K, w, h, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1], 5.0)
+                    rb = [ts.slab_range_weighted(m, world, r, self.halo, wts) for r in range(world)]
+                    placements["balanced"] = (rb[rank][0], rb[rank][1], 0, [[tuple(x)] for x in rb])
+                # block-cyclic placement: two blocks per rank unless told otherwise; blocks must be wider than the halo allows
+                # (stride = N B >= B + 2 halo) and divide the power-of-two m
+                if m & (m - 1) == 0:
+                    blk = args.cyclic_block if args.cyclic_block > 0 else 1 << max(0, (m // (2 * world)).bit_length() - 1)
+                    while blk < m and (world - 1) * blk < 2 * self.halo:
+                        blk *= 2
+                    if blk > 0 and m % blk == 0 and world * blk <= m and (world - 1) * blk >= 2 * self.halo:
+                        placements["cyclic"] = (rank * blk, (rank + 1) * blk, world * blk,
+                                                [[(a, a + blk) for a in range(r * blk, m, world * blk)] for r in range(world)])
+                if args.slabs == "cyclic" and "cyclic" not in placements:
+                    raise SystemExit(f"--slabs cyclic: no block size fits m={m}, {world} ranks, halo {self.halo}")
+            # A frame waits for its busiest rank (the all-reduce of every pass synchronises them): what a placement costs is the
+            # busiest rank's share of THAT frame's frustum work (the layers it STORES, halo included), averaged over the frames
+            # of the planned path -- DESIGN 6.1's model, also printed in the result line (1 for a single rank).
+            def busiest_share(owned):
+                if path is None:
+                    return 1.0
+                pick = np.unique(np.linspace(0, len(path[0]) - 1, min(32, len(path[0]))).astype(int))
+                shares = []
+                for k in pick:
+                    pre = np.concatenate([[0.0], np.cumsum(ts.frustum_layer_weights(cfg0, K, w, h, path[0][k], path[1][k], 5.0))])
+                    if pre[-1] > 0:
+                        shares.append(max(sum(pre[min(m, b + self.halo)] - pre[max(0, a - self.halo)] for a, b in owned[r]) for r in range(world)) / pre[-1])
+                return float(np.mean(shares)) if shares else 1.0
+            self.busiest_share, self.placement_shares = 1.0, None
+            x0, x1, stride, policy = 0, m, 0, None
+            if world > 1:
+                if args.slabs == "auto":
+                    # the path is known (this run's own): take the placement the model prices lowest over it -- cuts tuned to a short
+                    # window of the path beat the block-cyclic placement's halo work, a camera that sweeps across x does not
+                    cand = [p_ for p_ in ("cyclic", "path") if p_ in placements] if path is not None else []
+                    self.placement_shares = {p_: busiest_share(placements[p_][3]) for p_ in cand}
+                    policy = min(cand, key=lambda p_: self.placement_shares[p_]) if cand else "uniform"
+                else:
+                    policy = args.slabs if args.slabs in placements else "uniform"
+                x0, x1, stride, owned = placements[policy]
+                self.busiest_share = self.placement_shares[policy] if self.placement_shares and policy in self.placement_shares else busiest_share(owned)
+            self.slab_policy = policy
             self.slab = (x0, x1)
-            self.sdf = ts.SDF(m, with_color=not args.no_color, slab=(x0, x1), halo=self.halo, device=dev_index)
+            self.slab_stride = stride
+            self.sdf = ts.SDF(m, with_color=not args.no_color, slab=(x0, x1), halo=self.halo, slab_stride=stride, device=dev_index)
             self.trk = ts.CameraTracking(sdf=self.sdf)
             self.trk.set_K(K)
             self.pose_t = np.zeros(3)
@@ -682,6 +721,8 @@ def run(args):
     leg = Leg(m, width, height, seq.K, (seq.R[:n_frames], seq.t[:n_frames]))
     leg_slab0 = leg.slab
     leg_slab_policy = leg.slab_policy
+    leg_slab_stride = leg.slab_stride
+    leg_placement_shares = leg.placement_shares
     leg_busiest_share = leg.busiest_share
     sdf = leg.sdf
     halo_main = leg.halo
@@ -1118,7 +1159,8 @@ def run(args):
                                    f"pillars/domes/furniture), {width}x{height} depth with Kinect noise + 2% holes, "
                                    f"{m}^3 voxels, 6x6x3.5 m volume, colour lanes {'off' if args.no_color else 'on'}; "
                                    f"TUM images are not available on the box",
-                       "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}" + (f" ({leg_slab_policy} slabs, rank 0 owns layers [{leg_slab0[0]}, {leg_slab0[1]}))" if world > 1 else ""),
+                       "config": args.config, "m": m, "image": [width, height], "parallelism": f"x-slab x{world}" + ((f" (block-cyclic: rank r owns the layers [{leg_slab0[1] - leg_slab0[0]} r + {leg_slab_stride} j, ...) of every block j, {leg_slab0[1] - leg_slab0[0]} layers each)"
+                                                                              if leg_slab_stride else f" ({leg_slab_policy} slabs, rank 0 owns layers [{leg_slab0[0]}, {leg_slab0[1]}))") if world > 1 else ""),
                        "halo": halo_main,
                        "allreduce": allreduce_kind, "exchange_step_us_measured": exchange_us,
                        "exchange_trial_frames_per_s": exchange_trial, "slabs": leg_slab_policy},
@@ -1126,11 +1168,12 @@ def run(args):
                 "predicted_value": 1e6 / (17.0 + (120.0 - 17.0) * leg_busiest_share + ppf * (26.0 + ex)),
                 "formula": "frames/s = 1e6 / (17 + (120 - 17) * busiest_share + passes_per_frame * (26 + exchange_us)): DESIGN 6.1's model with the "
                            "single-GPU constants measured in rounds 5-6 (integrate launch 120 us of which 17 us do not shrink with the slab, a "
-                           "tracker pass 26 us whatever the slab); busiest_share = the busiest rank's share of the frustum work over this run's "
-                           "path; exchange_us = this machine's measured time of the chosen exchange step as a stand-alone tsdf_allreduce (an "
+                           "tracker pass 26 us whatever the slab); busiest_share = the busiest rank's share of a frame's frustum work (the layers it "
+                           "STORES, halo included), averaged over this run's path; exchange_us = this machine's measured time of the chosen exchange step as a stand-alone tsdf_allreduce (an "
                            "upper bound of what it costs inside a pass).  Printed next to the measured `value` so that the first run on a "
                            "multi-GPU node confirms or falsifies the model by itself.",
-                "busiest_share": leg_busiest_share, "passes_per_frame": ppf, "exchange_us": ex})(
+                "busiest_share": leg_busiest_share, "busiest_share_of_the_candidates": leg_placement_shares,
+                "passes_per_frame": ppf, "exchange_us": ex})(
                     cn["track_iterations"] / max(1, cn["track_calls"]),
                     float(exchange_us.get({v: k for k, v in KIND.items()}.get(allreduce_kind, ""), 0.0))),
             "ate_rmse_m": ate, "ate_frames": len(est_main) - 1, "abs_trajectory_rmse_m": raw,

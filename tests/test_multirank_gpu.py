@@ -53,12 +53,21 @@ def test_uniform_and_balanced_slabs_give_the_single_rank_trajectory(tmp_path):
     j1, t1 = run_bench([], 1, str(tmp_path / "t1.txt"), 0)
     ju, tu = run_bench(["--allreduce", "shm", "--slabs", "uniform"], 3, str(tmp_path / "tu.txt"), 29711)
     jb, tb = run_bench(["--allreduce", "shm", "--slabs", "balanced"], 3, str(tmp_path / "tb.txt"), 29713)
-    jp, tp = run_bench(["--allreduce", "shm"], 3, str(tmp_path / "tp.txt"), 29715)          # the default: --slabs auto = path
-    assert np.array_equal(t1, tu) and np.array_equal(t1, tb) and np.array_equal(t1, tp)
+    jp, tp = run_bench(["--allreduce", "shm", "--slabs", "path"], 3, str(tmp_path / "tp.txt"), 29715)
+    jc, tc = run_bench(["--allreduce", "shm", "--slabs", "cyclic"], 3, str(tmp_path / "tc.txt"), 29717)
+    ja, ta = run_bench(["--allreduce", "shm"], 3, str(tmp_path / "ta.txt"), 29721)          # the default: --slabs auto = whichever the model prices lower
+    jc4, tc4 = run_bench(["--allreduce", "shm", "--slabs", "cyclic", "--cyclic-block", "8"], 4, str(tmp_path / "tc4.txt"), 29719)
+    assert np.array_equal(t1, tu) and np.array_equal(t1, tb) and np.array_equal(t1, tp) and np.array_equal(t1, tc) and np.array_equal(t1, tc4)
+    # block-cyclic placement (tsdf_config::slab_stride): 128 layers over three ranks in blocks of 16, over four in blocks of 8
+    assert jc["config"]["slabs"] == "cyclic" and "block-cyclic: rank r owns the layers [16 r + 48 j" in jc["config"]["parallelism"]
+    assert jc4["config"]["slabs"] == "cyclic" and "[8 r + 32 j" in jc4["config"]["parallelism"]
+    cands = ja["scaling_model"]["busiest_share_of_the_candidates"]
+    assert np.array_equal(t1, ta) and set(cands) == {"cyclic", "path"} and ja["config"]["slabs"] == min(cands, key=cands.get)
+    assert abs(cands["cyclic"] - jc["scaling_model"]["busiest_share"]) < 1e-12 and abs(cands["path"] - jp["scaling_model"]["busiest_share"]) < 1e-12
     assert "uniform slabs, rank 0 owns layers [0, 43)" in ju["config"]["parallelism"]
     assert "balanced slabs, rank 0 owns layers [0, " in jb["config"]["parallelism"]
     assert int(jb["config"]["parallelism"].split("[0, ")[1].split(")")[0]) > 43
-    # --slabs auto with a known path: cuts that minimise the path-average of the busiest rank (tracking_sdf_amd.slab_cuts_for_path);
+    # --slabs path: cuts that minimise the path-average of the busiest rank (tracking_sdf_amd.slab_cuts_for_path);
     # the line carries DESIGN 6.1's model prediction next to the measured value
     assert "path slabs, rank 0 owns layers [0, " in jp["config"]["parallelism"] and jp["config"]["slabs"] == "path"
     sm = jp["scaling_model"]

@@ -40,10 +40,12 @@ def main():
     ap.add_argument("--frame-step", type=int, default=2)
     ap.add_argument("--passes", type=int, default=60)
     ap.add_argument("--max-range", type=float, default=6.0)
-    ap.add_argument("--slabs", default="uniform", choices=["uniform", "balanced", "path"],
+    ap.add_argument("--cyclic-block", type=int, default=0, help="--slabs cyclic: layers per block (0 = m / (2 N), two blocks per rank)")
+    ap.add_argument("--slabs", default="uniform", choices=["uniform", "balanced", "path", "cyclic"],
                     help="uniform: tsdf_slab_range (equal thickness); balanced: tsdf_slab_range_weighted on the frustum weights of the "
                          "reference's initial pose; path: on the weights accumulated over the WHOLE fr1/plant path (what bench.py's "
-                         "default --slabs auto does with the path it is going to run)")
+                         "--slabs path does with the path it is going to run); cyclic: block-cyclic placement (tsdf_config::slab_stride), "
+                         "bench.py's default where the volume allows it")
     ap.add_argument("--start-frame", type=int, default=0, help="where on the fr1/plant path the fused frames start (0, 480, 1000 ...)")
     ap.add_argument("--passes-per-frame", type=float, default=3.1, help="Gauss-Newton passes per frame of the bench stream (driver line)")
     ap.add_argument("--exchange-us", type=float, nargs="*", default=[0.0, 4.0, 10.0, 25.0],
@@ -79,9 +81,18 @@ def main():
         cuts = None
         if args.slabs == "path" and n > 1:
             cuts = ts.slab_cuts_for_path(ts.default_config(m=m), seq.K, w, h, full.R, full.t, n, halo)
+        blk = 0
+        if args.slabs == "cyclic" and n > 1:
+            blk = args.cyclic_block if args.cyclic_block > 0 else 1 << max(0, (m // (2 * n)).bit_length() - 1)
+            while blk < m and (n - 1) * blk < 2 * halo:
+                blk *= 2
+            if m & (m - 1) or m % blk or n * blk > m:
+                raise SystemExit(f"--slabs cyclic: no block size fits m={m}, {n} ranks, halo {halo}")
         for r in range(n):
             x0, x1 = (cuts[r], cuts[r + 1]) if cuts is not None else ts.slab_range(m, n, r) if weights is None else ts.slab_range_weighted(m, n, r, halo, weights)
-            sdf = ts.SDF(m, with_color=True, slab=(x0, x1), halo=halo)
+            if blk:
+                x0, x1 = r * blk, (r + 1) * blk
+            sdf = ts.SDF(m, with_color=True, slab=(x0, x1), halo=halo, slab_stride=n * blk if blk else 0)
             trk = ts.CameraTracking(sdf=sdf)
             trk.set_K(seq.K)
             sdf.set_timing(True)
@@ -110,7 +121,8 @@ def main():
                 A, b, st = trk.accumulate()
                 walls.append(time.perf_counter() - t0)
             pass_wall = float(np.median(walls))        # (host hiccups of a shared box: the median, not the mean)
-            rows.append({"rank": r, "slab": [x0, x1], "stored_layers": min(m, x1 + halo) - max(0, x0 - halo),
+            rows.append({"rank": r, "slab": [x0, x1], "block_stride": n * blk if blk else 0,
+                         "stored_layers": (len(range(x0, m, n * blk)) * (blk + 2 * halo)) if blk else min(m, x1 + halo) - max(0, x0 - halo),
                          "integrate_launch_us": 1e3 * tm["integrate_ms"] / max(1, tm["integrate_launches"]),
                          "integrate_call_to_completion_wall_us_median": 1e6 * wall,
                          "work_items_per_launch": cn["integrate_items"] / max(1, cn["integrate_calls"]),
