@@ -95,8 +95,11 @@ typedef struct tsdf_config {
                                 /* with its halo: rank r of N takes x0 = r*B, x1 = (r+1)*B, stride = N*B, so that      */
                                 /* every rank holds a share of every view (a camera that sweeps across the x axis     */
                                 /* leaves a plain slab with 1.7-3.6 x the mean work).  Needs m a power of   */
-                                /* two and a multiple of B = x1 - x0, and stride >= B + 2*halo.  Hot path only:          */
-                                /* tsdf_mesh*, tsdf_save / tsdf_load refuse such a handle (TSDF_E_BADARG).              */
+                                /* two and a multiple of B = x1 - x0, and stride >= B + 2*halo.  tsdf_download /          */
+                                /* _upload walk the blocks in increasing x; tsdf_mesh_extract meshes them one by one;    */
+                                /* tsdf_save writes every stored layer of every block, tsdf_load takes such a file of    */
+                                /* the same placement or any plain file that covers the blocks (a whole-volume one);    */
+                                /* only the *_with_halo uploads refuse such a handle (its layers are not one range).    */
 } tsdf_config;
 
 typedef struct tsdf_handle tsdf_handle;

@@ -441,10 +441,47 @@ def test_block_cyclic_shards_sum_to_whole(m, nr, block, with_color):
         far = np.array([[float(ranks[0][0].owned_x()[0] + block + halo + 1) + 0.5, m / 2, m / 2]])
         ranks[0][0].interpolate_distance(far)
     assert ei.value.code == ts.E_HALO
-    # what a block-cyclic handle refuses: meshes and checkpoints (hot path only)
-    for call in (lambda: ranks[0][0].mesh(), lambda: ranks[0][0].save("/tmp/_cyclic.tsdfvol")):
+    # marching cubes: every rank meshes the cubes whose base layer it owns, block by block; together they are the whole mesh
+    def tri_sorted(v, c=None):
+        key = v.reshape(len(v), -1).view(np.uint32)
+        order = np.lexsort(key.T[::-1])
+        return (v[order], c[order]) if c is not None else v[order]
+    if with_color:
+        vw_, cw_ = whole.mesh(with_color=True)
+        got = [gs.mesh(with_color=True) for gs, _ in ranks]
+        vr, cr = np.concatenate([g_[0] for g_ in got]), np.concatenate([g_[1] for g_ in got])
+        assert len(vw_) > 500 and len(vr) == len(vw_)
+        a_, b_ = tri_sorted(vw_, cw_), tri_sorted(vr, cr)
+        assert np.array_equal(a_[0].view(np.uint32), b_[0].view(np.uint32)) and np.array_equal(a_[1].view(np.uint32), b_[1].view(np.uint32))
+    else:
+        vw_ = whole.mesh()
+        vr = np.concatenate([gs.mesh() for gs, _ in ranks])
+        assert len(vw_) > 500 and np.array_equal(tri_sorted(vw_).view(np.uint32), tri_sorted(vr).view(np.uint32))
+    # checkpoints: a rank's own file restores it (every stored layer of every block); the WHOLE volume's file restores any
+    # placement; a file of another placement, and a rank's file in a plain handle, are refused
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        whole.save(td + "/whole.vol")
+        g0 = ranks[0][0]
+        g0.save(td + "/r0.vol")
+        want = g0.download() + (tuple(g0.download_color()) if with_color else ())
+        for src in ("/r0.vol", "/whole.vol"):
+            fresh, _ = make_gpu(m, seq.K, with_color=with_color, slab=(0, block), halo=halo, slab_stride=nr * block)
+            fresh.load(td + src)
+            have = fresh.download() + (tuple(fresh.download_color()) if with_color else ())
+            assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(want, have))
+            # ... halos included: the restored handle tracks like the one that was saved
+            trk = ts.CameraTracking(20, 0.001, 1.0, 0.01, fresh)
+            trk.set_K(seq.K)
+            trk.set_camera_transformation(*pose)
+            fresh.set_frame(xyz)
+            A1, b1, st1 = trk.accumulate()
+            assert np.array_equal(A1, parts[0][0]) and np.array_equal(b1, parts[0][1]) and st1 == parts[0][2]
+            fresh.close()
         with pytest.raises(ts.TsdfError):
-            call()
+            ranks[1][0].load(td + "/r0.vol")                  # rank 0's blocks are not rank 1's
+        with pytest.raises(ts.TsdfError):
+            whole.load(td + "/r0.vol")
     for gs, _ in ranks:
         gs.close()
     whole.close()

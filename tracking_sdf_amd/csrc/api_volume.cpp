@@ -21,30 +21,51 @@ using namespace tsdf_api;
 
 static int refuse_cyclic(tsdf_handle* h, const char* who) {
     if (h->grid.blk_own > 0)
-        return fail(h, TSDF_E_BADARG, "%s: not available for a handle with block-cyclic placement (slab_stride > 0): hot path only", who);
+        return fail(h, TSDF_E_BADARG, "%s: not available for a handle with block-cyclic placement (slab_stride > 0): its stored layers are not one range", who);
     return TSDF_OK;
 }
 
 int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64_t* n_triangles) {
     int rc = check_ready(h, false);
     if (rc) return rc;
-    if ((rc = refuse_cyclic(h, "tsdf_mesh_extract")) != TSDF_OK) return rc;
     if (n_triangles) *n_triangles = 0;
     h->mesh_ntri = -1;
     if (!(iso_level >= 0.0f && iso_level < 1.0f))                 // marching_cubes_sdf.cpp:246-252
         return fail(h, TSDF_E_BADARG, "tsdf_mesh_extract: iso level %g outside [0,1)", (double)iso_level);
     if (with_color && !h->crgb) return fail(h, TSDF_E_BADARG, "tsdf_mesh_extract: the volume keeps no colour");
     const Grid& g = h->grid;
-    MeshParams p{};
-    p.g = g;
-    p.extent[0] = h->cfg.width; p.extent[1] = h->cfg.height; p.extent[2] = h->cfg.depth;
-    p.iso = iso_level;
-    p.ci0 = g.own_x0 > 1 ? g.own_x0 : 1;
-    p.ci1 = g.own_x1 < g.m - 1 ? g.own_x1 : g.m - 1;              // cube layers [ci0, ci1): base voxels 1..m-2
-    if (p.ci1 > p.ci0 && g.xe < p.ci1 + 1)
-        return fail(h, TSDF_E_HALO, "tsdf_mesh_extract: a sharded volume needs halo >= 1 (cube layer %d reads layer %d)",
-                    p.ci1 - 1, p.ci1);
-    const size_t n_rows = (size_t)mesh_rows(p);
+    // The cubes whose base layer the handle owns: one piece for a plain slab; for a block-cyclic handle one piece per block,
+    // each a small slab of its own as far as the kernels are concerned (its stored layers start at the block's first one).
+    struct Piece { MeshParams p; const float2* dw; const float4* crgb; unsigned long long n; };
+    std::vector<Piece> pieces;
+    const long long mm = (long long)g.m * g.m;
+    try {
+        const int nb = g.blk_own > 0 ? g.n_blocks : 1;
+        for (int b = 0; b < nb; ++b) {
+            Piece pc{};
+            pc.p.g = g;
+            pc.dw = h->dw; pc.crgb = h->crgb;
+            if (g.blk_own > 0) {
+                const int first = g.blk_first + b * g.blk_stride;
+                pc.p.g.blk_own = 0;                                 // (a plain slab to the kernels)
+                pc.p.g.xs = first;                                  // may be negative: only (i - xs) with i >= 0 is ever formed
+                pc.p.g.xe = first + g.blk_layers > g.m ? g.m : first + g.blk_layers;
+                pc.p.g.own_x0 = g.own_x0 + b * g.blk_stride; pc.p.g.own_x1 = pc.p.g.own_x0 + g.blk_own;
+                pc.dw = h->dw + (long long)b * g.blk_layers * mm;
+                pc.crgb = h->crgb ? h->crgb + (long long)b * g.blk_layers * mm : nullptr;
+            }
+            pc.p.extent[0] = h->cfg.width; pc.p.extent[1] = h->cfg.height; pc.p.extent[2] = h->cfg.depth;
+            pc.p.iso = iso_level;
+            pc.p.ci0 = pc.p.g.own_x0 > 1 ? pc.p.g.own_x0 : 1;
+            pc.p.ci1 = pc.p.g.own_x1 < g.m - 1 ? pc.p.g.own_x1 : g.m - 1;   // cube layers [ci0, ci1): base voxels 1..m-2
+            if (pc.p.ci1 > pc.p.ci0 && pc.p.g.xe < pc.p.ci1 + 1)
+                return fail(h, TSDF_E_HALO, "tsdf_mesh_extract: a sharded volume needs halo >= 1 (cube layer %d reads layer %d)",
+                            pc.p.ci1 - 1, pc.p.ci1);
+            pieces.push_back(pc);
+        }
+    } catch (...) { return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: out of host memory"); }
+    size_t n_rows = 0;
+    for (const Piece& pc : pieces) { const size_t r = (size_t)mesh_rows(pc.p); if (r > n_rows) n_rows = r; }
     if (n_rows > (size_t)INT32_MAX) return fail(h, TSDF_E_BADARG, "tsdf_mesh_extract: too many rows");
     if (n_rows > h->mesh_rows_cap) {
         if (h->mesh_row_count) (void)hipFree(h->mesh_row_count);
@@ -62,13 +83,21 @@ int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64
         h->mesh_rows_cap = n_rows;
     }
     if (!h->mesh_total) HIP_TRY(h, hipHostMalloc((void**)&h->mesh_total, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-    h->mesh_total[0] = 0ull; h->mesh_total[1] = 0ull;
     unsigned long long* d_total = nullptr;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&d_total, h->mesh_total, 0));
-    HIP_TRY(h, launch_mesh_count(h->stream, p, h->dw, h->mesh_row_count, h->mesh_row_offset, h->mesh_group_sum,
-                                 h->mesh_group_base, d_total));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const unsigned long long n = h->mesh_total[0];
+    auto count = [&](Piece& pc) -> int {
+        h->mesh_total[0] = 0ull; h->mesh_total[1] = 0ull;
+        HIP_TRY(h, launch_mesh_count(h->stream, pc.p, pc.dw, h->mesh_row_count, h->mesh_row_offset, h->mesh_group_sum,
+                                     h->mesh_group_base, d_total));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        pc.n = h->mesh_total[0];
+        return TSDF_OK;
+    };
+    unsigned long long n = 0;
+    for (Piece& pc : pieces) {
+        if ((rc = count(pc)) != TSDF_OK) return rc;
+        n += pc.n;
+    }
     if (n > (unsigned long long)INT64_MAX / 64) return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: %llu triangles", n);
     if (n > h->mesh_verts_cap) {
         if (h->mesh_verts) (void)hipFree(h->mesh_verts);
@@ -88,13 +117,19 @@ int tsdf_mesh_extract(tsdf_handle* h, float iso_level, int32_t with_color, int64
             return fail(h, TSDF_E_NOMEM, "tsdf_mesh_extract: colours of %llu triangles", n);
         h->mesh_colors_cap = cap;
     }
-    if (n) {
-        HIP_TRY(h, launch_mesh_emit(h->stream, p, h->dw, h->crgb, h->mesh_row_count, h->mesh_row_offset, h->mesh_group_base,
-                                    h->mesh_desc, h->mesh_verts,
-                                    with_color ? h->mesh_colors : nullptr, n, (unsigned*)(d_total + 1)));
+    unsigned long long base = 0;
+    for (Piece& pc : pieces) {
+        if (!pc.n) continue;
+        const unsigned long long n_piece = pc.n;
+        if (pieces.size() > 1 && (rc = count(pc)) != TSDF_OK) return rc;       // the row tables hold the LAST piece counted: once more for this one
+        h->mesh_total[1] = 0ull;
+        HIP_TRY(h, launch_mesh_emit(h->stream, pc.p, pc.dw, pc.crgb, h->mesh_row_count, h->mesh_row_offset, h->mesh_group_base,
+                                    h->mesh_desc + base, h->mesh_verts + 9 * base,
+                                    with_color ? h->mesh_colors + 3 * base : nullptr, n_piece, (unsigned*)(d_total + 1)));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->mesh_total[1])
             return fail(h, TSDF_E_HALO, "tsdf_mesh_extract: a vertex colour reads outside the stored layers (halo >= 1 needed)");
+        base += n_piece;
     }
     h->mesh_ntri = (int64_t)n;
     h->mesh_has_color = with_color != 0;
@@ -244,7 +279,8 @@ struct VolHeader {                 // TSDFVOL2, little-endian, 80 bytes
     float width, height, depth, delta, epsilon;
     int32_t xs;                    // the file holds the x layers [xs, xe): the writer's slab AND its halo
     double origin[3];
-    int32_t xe, reserved;
+    int32_t xe, stride;            // stride > 0: a block-cyclic handle's file -- EVERY stored layer of every block, as they lie in
+                                   // memory ([xs, xe) is block 0's stored range, unclipped; blocks at x0 + b * stride); 0: one slab
 };
 static_assert(sizeof(VolHeader) == 80, "checkpoint header layout");
 
@@ -258,7 +294,6 @@ bool read_plane(FILE* f, long long plane_floats, int plane, long long first, flo
 int tsdf_save(tsdf_handle* h, const char* path) {
     int rc = check_ready(h, false);
     if (rc) return rc;
-    if ((rc = refuse_cyclic(h, "tsdf_save")) != TSDF_OK) return rc;
     if (!path) return fail(h, TSDF_E_BADARG, "tsdf_save: null path");
     const size_t n = (size_t)h->n_stored;              // slab + halo: a restored shard needs its halo layers too
     std::vector<float> buf;
@@ -268,6 +303,7 @@ int tsdf_save(tsdf_handle* h, const char* path) {
     std::memcpy(hd.magic, "TSDFVOL2", 8);
     hd.m = h->grid.m; hd.x0 = h->grid.own_x0; hd.x1 = h->grid.own_x1; hd.has_color = h->crgb ? 1 : 0;
     hd.xs = h->grid.xs; hd.xe = h->grid.xe;
+    if (h->grid.blk_own > 0) { hd.xs = h->grid.blk_first; hd.xe = h->grid.blk_first + h->grid.blk_layers; hd.stride = h->grid.blk_stride; }
     hd.width = h->cfg.width; hd.height = h->cfg.height; hd.depth = h->cfg.depth;
     hd.delta = h->cfg.delta; hd.epsilon = h->cfg.epsilon;
     std::memcpy(hd.origin, h->cfg.origin, sizeof hd.origin);
@@ -302,7 +338,6 @@ int tsdf_save(tsdf_handle* h, const char* path) {
 int tsdf_load(tsdf_handle* h, const char* path) {
     int rc = check_ready(h, false);
     if (rc) return rc;
-    if ((rc = refuse_cyclic(h, "tsdf_load")) != TSDF_OK) return rc;
     if (!path) return fail(h, TSDF_E_BADARG, "tsdf_load: null path");
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(h, TSDF_E_BADARG, "tsdf_load: cannot open %s", path);
@@ -327,14 +362,42 @@ int tsdf_load(tsdf_handle* h, const char* path) {
     }
     // every STORED layer of this handle (slab and halo) must come from the file: a halo left at its old contents
     // would silently break the 'halo == neighbour's interior' invariant the sharded tracker relies on
-    if (hd.xs > g.xs || hd.xe < g.xe || hd.xs < 0 || hd.xe > hd.m) {
-        std::fclose(f);
-        return fail(h, TSDF_E_HALO, "tsdf_load: file holds x layers [%d,%d), this handle stores [%d,%d) (slab [%d,%d) + halo %d)",
-                    hd.xs, hd.xe, g.xs, g.xe, g.own_x0, g.own_x1, h->cfg.halo);
-    }
-    const size_t n = (size_t)h->n_stored;
     const long long mm = (long long)g.m * g.m;
-    const long long plane_floats = (long long)(hd.xe - hd.xs) * mm, first = (long long)(g.xs - hd.xs) * mm;
+    // What goes where: pieces {first float of the piece in a plane of the file, first voxel in the handle, voxels}.
+    struct Piece { long long file_first, local_first, count; };
+    std::vector<Piece> pieces;
+    long long plane_floats = 0;
+    try {
+        if (hd.stride > 0) {
+            // a block-cyclic handle's own file: the same placement, read back as it was written
+            if (g.blk_own <= 0 || hd.stride != g.blk_stride || hd.x0 != g.own_x0 || hd.x1 != g.own_x1 || hd.xs != g.blk_first ||
+                hd.xe != g.blk_first + g.blk_layers) {
+                std::fclose(f);
+                return fail(h, TSDF_E_HALO, "tsdf_load: %s holds the blocks [%d,%d) + %d j with the stored range [%d,%d) of a block-cyclic handle; this handle is placed otherwise",
+                            path, hd.x0, hd.x1, hd.stride, hd.xs, hd.xe);
+            }
+            plane_floats = (long long)h->n_stored;
+            pieces.push_back({0, 0, (long long)h->n_stored});
+        } else {
+            if (hd.xs < 0 || hd.xe > hd.m || hd.xs >= hd.xe) { std::fclose(f); return fail(h, TSDF_E_BADARG, "tsdf_load: %s: bad layer range [%d,%d)", path, hd.xs, hd.xe); }
+            plane_floats = (long long)(hd.xe - hd.xs) * mm;
+            const int nb = g.blk_own > 0 ? g.n_blocks : 1;
+            for (int b = 0; b < nb; ++b) {
+                // the stored layers of the slab / of block b that lie in the grid
+                const int first = g.blk_own > 0 ? g.blk_first + b * g.blk_stride : g.xs;
+                const int lo = first < 0 ? 0 : first;
+                const int hi = g.blk_own > 0 ? (first + g.blk_layers > g.m ? g.m : first + g.blk_layers) : g.xe;
+                if (hd.xs > lo || hd.xe < hi) {
+                    std::fclose(f);
+                    return fail(h, TSDF_E_HALO, "tsdf_load: file holds x layers [%d,%d), this handle stores [%d,%d) (slab [%d,%d) + halo %d)",
+                                hd.xs, hd.xe, lo, hi, g.own_x0 + (g.blk_own > 0 ? b * g.blk_stride : 0), g.own_x1 + (g.blk_own > 0 ? b * g.blk_stride : 0), h->cfg.halo);
+                }
+                pieces.push_back({(long long)(lo - hd.xs) * mm, ((long long)(g.blk_own > 0 ? b * g.blk_layers : 0) + (lo - first)) * mm, (long long)(hi - lo) * mm});
+            }
+        }
+    } catch (...) { std::fclose(f); return fail(h, TSDF_E_NOMEM, "tsdf_load: out of host memory"); }
+    size_t n = 0;
+    for (const Piece& pc : pieces) if ((size_t)pc.count > n) n = (size_t)pc.count;
     {
         // the whole file must be there BEFORE anything is uploaded: a file cut inside its colour part must not leave the
         // handle with new D / W and old colour
@@ -349,11 +412,16 @@ int tsdf_load(tsdf_handle* h, const char* path) {
     std::vector<float> buf;
     try { buf.resize(n * 4); } catch (...) { std::fclose(f); return fail(h, TSDF_E_NOMEM, "tsdf_load: out of host memory"); }
     float* host[4] = {buf.data(), buf.data() + n, buf.data() + 2 * n, buf.data() + 3 * n};
-    bool ok = read_plane(f, plane_floats, 0, first, host[0], n) && read_plane(f, plane_floats, 1, first, host[1], n);
-    if (ok) rc = volume_io(h, false, false, 0, (int64_t)n, host);
-    if (ok && rc == TSDF_OK && h->crgb) {
-        for (int q = 0; q < 4 && ok; ++q) ok = read_plane(f, plane_floats, 2 + q, first, host[q], n);
-        if (ok) rc = volume_io(h, false, true, 0, (int64_t)n, host);
+    bool ok = true;
+    for (size_t i = 0; i < pieces.size() && ok && rc == TSDF_OK; ++i) {
+        const Piece& pc = pieces[i];
+        ok = read_plane(f, plane_floats, 0, pc.file_first, host[0], (size_t)pc.count) && read_plane(f, plane_floats, 1, pc.file_first, host[1], (size_t)pc.count);
+        if (ok) rc = volume_io(h, false, false, pc.local_first, pc.count, host);
+    }
+    for (size_t i = 0; i < pieces.size() && ok && rc == TSDF_OK && h->crgb; ++i) {
+        const Piece& pc = pieces[i];
+        for (int q = 0; q < 4 && ok; ++q) ok = read_plane(f, plane_floats, 2 + q, pc.file_first, host[q], (size_t)pc.count);
+        if (ok) rc = volume_io(h, false, true, pc.local_first, pc.count, host);
     }
     std::fclose(f);
     if (!ok) return fail(h, TSDF_E_BADARG, "tsdf_load: %s is truncated", path);
