@@ -531,15 +531,16 @@ def run(args):
             # A frame waits for its busiest rank (the all-reduce of every pass synchronises them): what a placement costs is the
             # busiest rank's share of THAT frame's frustum work (the layers it STORES, halo included), averaged over the frames
             # of the planned path -- DESIGN 6.1's model, also printed in the result line (1 for a single rank).
-            def busiest_share(owned):
-                if path is None:
-                    return 1.0
-                pick = np.unique(np.linspace(0, len(path[0]) - 1, min(32, len(path[0]))).astype(int))
-                shares = []
-                for k in pick:
+            prefix_sums = []              # of the frustum weights of (up to 24 of) the path's poses, made once per leg
+            if world > 1 and path is not None:
+                for k in np.unique(np.linspace(0, len(path[0]) - 1, min(24, len(path[0]))).astype(int)):
                     pre = np.concatenate([[0.0], np.cumsum(ts.frustum_layer_weights(cfg0, K, w, h, path[0][k], path[1][k], 5.0))])
                     if pre[-1] > 0:
-                        shares.append(max(sum(pre[min(m, b + self.halo)] - pre[max(0, a - self.halo)] for a, b in owned[r]) for r in range(world)) / pre[-1])
+                        prefix_sums.append(pre)
+
+            def busiest_share(owned):
+                shares = [max(sum(pre[min(m, b + self.halo)] - pre[max(0, a - self.halo)] for a, b in owned[r]) for r in range(world)) / pre[-1]
+                          for pre in prefix_sums]
                 return float(np.mean(shares)) if shares else 1.0
             self.busiest_share, self.placement_shares = 1.0, None
             x0, x1, stride, policy = 0, m, 0, None
