@@ -519,13 +519,12 @@ def run(args):
                     placements["balanced"] = (rb[rank][0], rb[rank][1], 0, [[tuple(x)] for x in rb])
                 # block-cyclic placement: two blocks per rank unless told otherwise; blocks must be wider than the halo allows
                 # (stride = N B >= B + 2 halo) and divide the power-of-two m
-                if m & (m - 1) == 0:
-                    blk = args.cyclic_block if args.cyclic_block > 0 else 1 << max(0, (m // (2 * world)).bit_length() - 1)
-                    while blk < m and (world - 1) * blk < 2 * self.halo:
-                        blk *= 2
-                    if blk > 0 and m % blk == 0 and world * blk <= m and (world - 1) * blk >= 2 * self.halo:
-                        placements["cyclic"] = (rank * blk, (rank + 1) * blk, world * blk,
-                                                [[(a, a + blk) for a in range(r * blk, m, world * blk)] for r in range(world)])
+                try:
+                    cx0, cx1, cst = ts.cyclic_range(m, world, rank, self.halo, args.cyclic_block)      # tsdf_cyclic_range
+                    blk = cx1 - cx0
+                    placements["cyclic"] = (cx0, cx1, cst, [[(a, a + blk) for a in range(r * blk, m, cst)] for r in range(world)])
+                except ts.TsdfError:
+                    pass
                 if args.slabs == "cyclic" and "cyclic" not in placements:
                     raise SystemExit(f"--slabs cyclic: no block size fits m={m}, {world} ranks, halo {self.halo}")
             # A frame waits for its busiest rank (the all-reduce of every pass synchronises them): what a placement costs is the

@@ -84,6 +84,28 @@ def test_slab_ranges_partition_the_axis():
         ts.slab_range(64, 4, 4)
 
 
+def test_cyclic_ranges_partition_the_axis_and_keep_the_blocks_apart():
+    """tsdf_cyclic_range: the blocks [x0 + j stride, x1 + j stride) of all ranks cover every layer exactly once; a rank's
+    stored ranges (block + halo) never overlap; block = 0 gives two blocks per rank where the halo allows; what cannot work
+    is refused."""
+    for m, n, halo in ((512, 8, 9), (512, 2, 9), (512, 3, 9), (128, 3, 5), (2048, 8, 24), (64, 2, 4), (256, 8, 6), (1024, 5, 14)):
+        owner = np.full(m, -1)
+        for r in range(n):
+            x0, x1, st = ts.cyclic_range(m, n, r, halo)
+            B = x1 - x0
+            assert B & (B - 1) == 0 and m % B == 0 and st == n * B and x0 == r * B and st >= B + 2 * halo
+            for a in range(x0, m, st):
+                assert (owner[a:a + B] == -1).all()
+                owner[a:a + B] = r
+        assert (owner >= 0).all()
+        if (n & (n - 1)) == 0 and (n - 1) * (m // (2 * n)) >= 2 * halo:
+            assert B == m // (2 * n)                       # two blocks per rank
+    assert ts.cyclic_range(512, 8, 3, 9, 16) == (48, 64, 128)              # a block size of the caller's choice
+    for bad in ((96, 2, 0, 2, 0), (64, 2, 0, 40, 0), (64, 8, 0, 2, 16), (64, 1, 0, 2, 0), (64, 2, 2, 2, 0), (64, 2, 0, 2, 12)):
+        with pytest.raises(ts.TsdfError):
+            ts.cyclic_range(*bad)
+
+
 def test_weighted_slab_ranges_partition_the_axis_and_balance_the_work():
     """tsdf_slab_range_weighted: contiguous non-empty slabs that partition the axis, deterministic; the largest cost
     (weights of the stored layers: slab + halo) is no larger than with equal slabs and within a layer's weight of the

@@ -83,11 +83,8 @@ def main():
             cuts = ts.slab_cuts_for_path(ts.default_config(m=m), seq.K, w, h, full.R, full.t, n, halo)
         blk = 0
         if args.slabs == "cyclic" and n > 1:
-            blk = args.cyclic_block if args.cyclic_block > 0 else 1 << max(0, (m // (2 * n)).bit_length() - 1)
-            while blk < m and (n - 1) * blk < 2 * halo:
-                blk *= 2
-            if m & (m - 1) or m % blk or n * blk > m:
-                raise SystemExit(f"--slabs cyclic: no block size fits m={m}, {n} ranks, halo {halo}")
+            c0, c1, _ = ts.cyclic_range(m, n, 0, halo, args.cyclic_block)          # tsdf_cyclic_range (raises when nothing fits)
+            blk = c1 - c0
         for r in range(n):
             x0, x1 = (cuts[r], cuts[r + 1]) if cuts is not None else ts.slab_range(m, n, r) if weights is None else ts.slab_range_weighted(m, n, r, halo, weights)
             if blk:

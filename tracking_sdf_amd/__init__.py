@@ -110,7 +110,7 @@ ABI_SYMBOLS = (
     "tsdf_set_frame_device", "tsdf_device_frame_released", "tsdf_set_frame_aos", "tsdf_track_aos", "tsdf_track_frame_aos", "tsdf_integrate_aos", "tsdf_default_preproc", "tsdf_set_depth_frame", "tsdf_queue_depth_frame", "tsdf_get_preprocessed", "tsdf_integrate", "tsdf_track", "tsdf_track_and_integrate", "tsdf_accumulate", "tsdf_gn_update", "tsdf_sample",
     "tsdf_download", "tsdf_upload", "tsdf_download_color", "tsdf_upload_color", "tsdf_upload_with_halo", "tsdf_upload_color_with_halo", "tsdf_reset", "tsdf_save", "tsdf_load",
     "tsdf_mesh_extract", "tsdf_mesh_read", "tsdf_mesh_device",
-    "tsdf_slab_range", "tsdf_slab_range_weighted", "tsdf_frustum_layer_weights", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
+    "tsdf_slab_range", "tsdf_cyclic_range", "tsdf_slab_range_weighted", "tsdf_frustum_layer_weights", "tsdf_halo_for", "tsdf_comm_unique_id", "tsdf_comm_init", "tsdf_comm_init_shm", "tsdf_comm_init_peer", "tsdf_comm_finalize", "tsdf_set_allreduce_hook",
     "tsdf_allreduce", "tsdf_host_set_pose", "tsdf_host_perturbed_rotations", "tsdf_host_gn_step", "tsdf_set_timing", "tsdf_read_timing", "tsdf_read_counters", "tsdf_synchronize", "tsdf_stream",
 )
 
@@ -191,6 +191,7 @@ def lib():
         "tsdf_save": (C.c_int, [H, C.c_char_p]),
         "tsdf_load": (C.c_int, [H, C.c_char_p]),
         "tsdf_slab_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, ip, ip]),
+        "tsdf_cyclic_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, ip, ip, ip]),
         "tsdf_slab_range_weighted": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip, ip]),
         "tsdf_frustum_layer_weights": (C.c_int, [C.POINTER(Config), dp, C.c_int32, C.c_int32, dp, dp, C.c_float, dp]),
         "tsdf_halo_for": (C.c_int32, [C.POINTER(Config), C.c_float]),
@@ -237,6 +238,16 @@ def slab_range(m: int, nranks: int, rank: int):
     if rc:
         raise TsdfError(rc, "tsdf_slab_range: bad argument")
     return int(x0.value), int(x1.value)
+
+
+def cyclic_range(m: int, nranks: int, rank: int, halo: int, block: int = 0):
+    """tsdf_cyclic_range: (x0, x1, stride) of the block-cyclic placement -- SDF(m, slab=(x0, x1), halo=halo, slab_stride=stride).
+    block = 0: two blocks per rank (m / (2 nranks), widened until the halo fits).  Raises when nothing fits."""
+    x0, x1, st = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib().tsdf_cyclic_range(m, nranks, rank, halo, block, C.byref(x0), C.byref(x1), C.byref(st))
+    if rc:
+        raise TsdfError(rc, f"tsdf_cyclic_range: no block-cyclic placement for m={m}, {nranks} ranks, halo {halo}, block {block}")
+    return int(x0.value), int(x1.value), int(st.value)
 
 
 def slab_range_weighted(m: int, nranks: int, rank: int, halo: int, layer_weight):

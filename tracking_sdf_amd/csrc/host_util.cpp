@@ -232,6 +232,23 @@ int tsdf_slab_range(int32_t m, int32_t nranks, int32_t rank, int32_t* x0, int32_
     return TSDF_OK;
 }
 
+// Block-cyclic placement (tsdf_config::slab_stride): rank r of N owns the blocks [r B + j N B, (r+1) B + j N B).  block = 0:
+// B = m / (2 N) rounded down to a power of two -- two blocks per rank, where the halo's work ((B + 2 halo) / B) and the balance
+// meet -- doubled until N B >= B + 2 halo.  TSDF_E_BADARG when no block fits (m not a power of two, the halo
+// too wide for the number of ranks, more ranks than blocks).
+int tsdf_cyclic_range(int32_t m, int32_t nranks, int32_t rank, int32_t halo, int32_t block, int32_t* x0, int32_t* x1, int32_t* stride) {
+    if (m <= 0 || (m & (m - 1)) != 0 || nranks < 2 || rank < 0 || rank >= nranks || halo < 0 || block < 0 || !x0 || !x1 || !stride) return TSDF_E_BADARG;
+    int64_t B = block;
+    if (B == 0) {
+        B = 1;
+        while (2 * B <= m / (2 * (int64_t)nranks)) B *= 2;
+        while (B < m && (int64_t)(nranks - 1) * B < 2 * (int64_t)halo) B *= 2;
+    }
+    if ((B & (B - 1)) != 0 || m % B != 0 || (int64_t)nranks * B > m || (int64_t)(nranks - 1) * B < 2 * (int64_t)halo) return TSDF_E_BADARG;
+    *x0 = (int32_t)(rank * B); *x1 = (int32_t)((rank + 1) * B); *stride = (int32_t)(nranks * B);
+    return TSDF_OK;
+}
+
 // Slabs of equal WORK instead of equal thickness.  The cost of a rank is the weight of the layers it STORES (slab + halo
 // per side: halo layers are integrated too); boundaries minimise the largest cost.  Monotone greedy under a bisected
 // bound: every rank computes the same boundaries from the same weights.
