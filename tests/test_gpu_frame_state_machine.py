@@ -144,3 +144,31 @@ def test_every_route_of_a_frame_gives_the_same_bits(seed, defer, monkeypatch):
             assert np.array_equal(np.asarray(x), np.asarray(y))
     for a, b in zip(want[1] + want[2], got[1] + got[2]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_every_route_at_full_image_size_with_the_host_ahead_of_the_gpu(seed, monkeypatch):
+    """The same walk where timing matters: 640x480 frames into a 256^3 volume, most frames integrated at the pose they arrive
+    with (no tracking: nothing makes the host wait, so it runs frames ahead of the GPU -- the conditions under which the two
+    cross-stream ordering bugs of round 6 showed), a few synchronised or tracked.  Same bits as the plain loop."""
+    import test_gpu_frame_state_machine as me
+    monkeypatch.delenv("TSDF_DEFER_PACK", raising=False)
+    for name, value in (("W", 640), ("H", 480), ("M", 256), ("N", 18)):
+        monkeypatch.setattr(me, name, value)
+    rng = np.random.default_rng(1000 + seed)
+    steps = plan(seed)
+    for k, st in enumerate(steps):
+        st["track"] = k > 0 and rng.random() < 0.35
+        st["integrate"] = True
+        st["sync"] = rng.random() < 0.1
+        st["accumulate"] = rng.random() < 0.15
+    seq = synth.Sequence(n_frames=me.N, width=me.W, height=me.H, noise=True, holes=0.02, step=3)
+    import functools
+    seq.frame = functools.lru_cache(maxsize=None)(seq.frame)          # (rendered on the CPU: once per frame, not once per route)
+    want, got = reference(seq, steps), mixed(seq, steps)
+    assert len(want[0]) == len(got[0])
+    for a, b in zip(want[0], got[0]):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    for a, b in zip(want[1] + want[2], got[1] + got[2]):
+        assert np.array_equal(a, b)
