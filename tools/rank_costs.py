@@ -46,6 +46,8 @@ def main():
                          "reference's initial pose; path: on the weights accumulated over the WHOLE fr1/plant path (what bench.py's "
                          "--slabs path does with the path it is going to run); cyclic: block-cyclic placement (tsdf_config::slab_stride), "
                          "bench.py's default where the volume allows it")
+    ap.add_argument("--path-window", type=int, nargs=2, default=None, metavar=("FIRST", "LAST"),
+                    help="--slabs path: cut for these poses of the path only (what bench.py does with the poses of its own run) instead of the whole path")
     ap.add_argument("--start-frame", type=int, default=0, help="where on the fr1/plant path the fused frames start (0, 480, 1000 ...)")
     ap.add_argument("--passes-per-frame", type=float, default=3.1, help="Gauss-Newton passes per frame of the bench stream (driver line)")
     ap.add_argument("--exchange-us", type=float, nargs="*", default=[0.0, 4.0, 10.0, 25.0],
@@ -80,7 +82,8 @@ def main():
             weights = ts.frustum_layer_weights(ts.default_config(m=m), seq.K, w, h, [[1, 0, 0], [0, 0, -1], [0, -1, 0]], [0, 0, 1])
         cuts = None
         if args.slabs == "path" and n > 1:
-            cuts = ts.slab_cuts_for_path(ts.default_config(m=m), seq.K, w, h, full.R, full.t, n, halo)
+            wa, wb = args.path_window if args.path_window else (0, len(full))
+            cuts = ts.slab_cuts_for_path(ts.default_config(m=m), seq.K, w, h, full.R[wa:wb], full.t[wa:wb], n, halo)
         blk = 0
         if args.slabs == "cyclic" and n > 1:
             c0, c1, _ = ts.cyclic_range(m, n, 0, halo, args.cyclic_block)          # tsdf_cyclic_range (raises when nothing fits)
