@@ -2,7 +2,7 @@
 //
 // A pass is one launch whose result the host waits for before it can launch the next one; hipLaunchKernel spends 2.5-2.8 us
 // of host time per launch on that critical path, a hand-written AQL dispatch 0.2 (tools/aql_probe.hip, profiles/
-// r06_pass_floor.json: 2.3-3.3 us less from submission to the host seeing the result at every grid shape; submit() adds the
+// r06_pass_floor.jsonl: 2.3-3.3 us less from submission to the host seeing the result at every grid shape; submit() adds the
 // 0.9 us read-back of the arguments that makes the doorbell safe).  Inside the frame loop that came to 0.3 us per pass
 // (+0.1-0.6 % frames/s, profiles/r05_aql_readback.json) -- not enough to pay for a second submission path, so the default
 // since round 6 is the HIP stream and this queue is an option.  The kernel is the SAME device code: the build also emits
